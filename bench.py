@@ -1,0 +1,265 @@
+#!/usr/bin/env python3
+"""bench.py - EM iterations/s (Model 4) and HMM genes/s on MI355X, one JSON line on rank 0.
+
+    python bench.py --gpus 1 --steps 50 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one EM iteration (E-step + M-step + convergence bookkeeping) over one synthetic
+DO-shaped sample of BASELINE.json configs[1]: 40M reads x 8 haplotypes x 120k isoforms
+(SURVEY.md §8d generator), resident in HBM before the timed region.  With N > 1 every rank holds
+its own 40M-read shard of a pooled sample (reads sharded, weak scaling) and the ranks exchange
+the H*L expected-count vector with one RCCL all-reduce per iteration; the value
+reported is shard-iterations/s summed over ranks.
+
+The same line carries `roofline` (E-step kernel, HIP-event time measured in the library on its
+own stream), `cpu_baseline` (the numpy oracle, 1 core, bounded sample) and an `hmm` object with
+the reconstruct numbers for BASELINE.json configs[2].
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--rows", type=int, default=40_000_000, help="reads per GPU")
+    ap.add_argument("--haps", type=int, default=8)
+    ap.add_argument("--loci", type=int, default=120_000)
+    ap.add_argument("--merge", action="store_true", help="merge identical rows in the device layout")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-hmm", action="store_true")
+    ap.add_argument("--cpu-rows", type=int, default=2_000_000)
+    ap.add_argument("--cpu-iters", type=int, default=10)
+    ap.add_argument("--hmm-samples", type=int, default=1)
+    ap.add_argument("--hmm-reps", type=int, default=5)
+    return ap.parse_args()
+
+
+class DevArray:
+    """__cuda_array_interface__ view of a raw device pointer, so torch can wrap the library's
+    partial-sum buffer for the RCCL all-reduce."""
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = dict(shape=(n,), typestr="<f8", data=(ptr, False), version=2)
+
+
+def em_bench(args, rank, world, torch, dist):
+    from gbrs_amd import _lib, synth, synth_torch
+    from gbrs_amd.engine import EmEngine
+    dev = f"cuda:{torch.cuda.current_device()}"
+    seed = synth.SEED_BASE_EM + 1 + rank
+    t0 = time.perf_counter()
+    prob = synth_torch.make_em_problem_device(args.rows, args.haps, args.loci, seed, dev)
+    t_gen = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    eng = EmEngine.from_device(
+        prob["R"], prob["L"], prob["H"], [t.data_ptr() for t in prob["indptr"]],
+        [t.data_ptr() for t in prob["indices"]], None, prob["eff_len"].data_ptr(),
+        device=torch.cuda.current_device(),
+        flags=_lib.GBRS_EM_MERGE_IDENTICAL_ROWS if args.merge else 0)
+    t_create = time.perf_counter() - t0
+    n_entries = prob["N"]
+    del prob
+    torch.cuda.empty_cache()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    acc_t = None
+    if world > 1:
+        p, n = eng.prepare_partial()
+        acc_t = torch.as_tensor(DevArray(p, n), device=dev)
+        eng.sync()
+        dist.all_reduce(acc_t)
+        torch.cuda.synchronize()
+        eng.finish_prepare(0.0)
+    else:
+        eng.prepare(0.0)
+
+    def run_steps(k):
+        if world == 1:
+            eng.step(k)
+            return
+        for _ in range(k):
+            eng.estep_partial()
+            eng.sync()
+            dist.all_reduce(acc_t)
+            torch.cuda.synchronize()
+            eng.finish_step(want_err=False)
+        eng.sync()
+
+    run_steps(args.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    run_steps(args.steps)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    inf = eng.info()
+    res = dict(dt=dt, t_gen=t_gen, t_create=t_create, N=n_entries, info=inf)
+    if world == 1:
+        res["estep_ms"] = inf.last_estep_ms
+        res["step_ms"] = inf.last_step_ms
+    else:
+        # per-launch E-step time: one un-pipelined timed step group without the collective
+        eng.step(min(args.steps, 10))
+        inf = eng.info()
+        res["estep_ms"] = inf.last_estep_ms
+        res["step_ms"] = inf.last_step_ms
+    eng.close()
+    return res
+
+
+def em_cpu_baseline(args):
+    """The numpy oracle (op-for-op restatement of the reference) on one core, bounded sample."""
+    import numpy as np
+    from gbrs_amd import synth
+    from oracle.em_oracle import EMOracle
+    R = min(args.cpu_rows, args.rows)
+    inc = synth.make_em_problem(R=R, H=args.haps, L=args.loci, seed=synth.SEED_BASE_EM + 1)
+    o = EMOracle(inc.num_rows, inc.num_loci, inc.num_haps, inc.indptr, inc.indices, None)
+    o.prepare(0.0, inc.effective_length(100))
+    o.em_step()
+    t0 = time.perf_counter()
+    n = 0
+    while n < args.cpu_iters and time.perf_counter() - t0 < 25.0:
+        o.em_step()
+        n += 1
+    dt = (time.perf_counter() - t0) / max(n, 1)
+    scale = args.rows / R
+    return dict(value=1.0 / (dt * scale), unit="iters/s", cores=1, kind="port",
+                sample=f"numpy oracle, {n} iterations at R={R} rows (N={inc.nnz} entries), "
+                       f"{dt * 1e3:.1f} ms/iter measured, scaled x{scale:g} linearly in rows to the "
+                       f"{args.rows}-row workload; host has {os.cpu_count()} cores, reference is single-threaded")
+
+
+def hmm_bench(args, torch):
+    import numpy as np
+    from gbrs_amd import synth
+    from gbrs_amd.hmm import DiplotypeHMM
+    prob = synth.make_hmm_problem(H=8)
+    chroms = prob.chroms
+    ns = args.hmm_samples
+    hmm = DiplotypeHMM(8, chroms, [len(prob.gene_ids[c]) for c in chroms], [prob.tprob[c] for c in chroms],
+                       device=torch.cuda.current_device())
+    rng = np.random.default_rng(1)
+    ex, av, ha = [], [], []
+    for c in chroms:
+        ids = prob.gene_ids[c]
+        e = np.array([prob.expr[g] for g in ids])
+        if ns > 1:
+            e = np.stack([e] + [rng.gamma(1.0, 5.0, size=e.shape) * (rng.random(e.shape) < 0.5)
+                                for _ in range(ns - 1)])
+        ex.append(e)
+        ha.append(np.array([g in prob.avecs for g in ids], dtype=np.uint8))
+        av.append(np.array([prob.avecs.get(g, np.zeros((8, 8))) for g in ids]))
+    hmm.set_expression(ex, av, ha, 1.5, 0.12)
+    hmm.run()
+    emis, tot = [], []
+    for _ in range(args.hmm_reps):
+        hmm.set_expression(ex, av, ha, 1.5, 0.12)    # includes the H2D copy of expr; kernel time is taken from events
+        hmm.run()
+        inf = hmm.info()
+        emis.append(inf.last_emission_ms)
+        tot.append(inf.last_emission_ms + inf.last_forward_ms + inf.last_backward_ms + inf.last_backtrace_ms)
+    inf = hmm.info()
+    ms = float(np.median(tot))
+    units = prob.num_genes * ns
+    out = dict(metric="HMM gene x sample /s (emission+forward+backward+posterior+Viterbi)",
+               value=units / (ms * 1e-3), unit="genes/s", ms_per_pass=ms, n_samples=ns,
+               genes=prob.num_genes, states=36,
+               kernels_ms=dict(emission=inf.last_emission_ms, forward_viterbi=inf.last_forward_ms,
+                               backward_posterior=inf.last_backward_ms, backtrace=inf.last_backtrace_ms),
+               roofline=dict(bound="hbm", achieved=inf.algorithmic_bytes * ns / (ms * 1e-3) / 1e9,
+                             peak=HBM_PEAK_GBS, unit="GB/s",
+                             frac=inf.algorithmic_bytes * ns / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=None,
+                             note="sequential recursion over genes: latency-bound, not bandwidth-bound"))
+    hmm.close()
+    if not args.no_cpu_baseline:
+        from oracle import hmm_oracle
+        sub = synth.make_hmm_problem(H=8, genes_per_chrom=[1500, 1500], seed=synth.SEED_HMM)
+        t0 = time.perf_counter()
+        hmm_oracle.reconstruct_arrays(sub.hap_names, sub.chroms, sub.gene_ids, sub.tprob, sub.expr, sub.avecs)
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = dict(value=sub.num_genes / dt, unit="genes/s", cores=1, kind="port",
+                                   sample=f"numpy oracle on 2 chromosomes x 1500 genes ({dt:.1f} s)")
+    return out
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: gbrs_amd has no CPU path")
+    torch.cuda.set_device(local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+    import __graft_entry__
+    if rank == 0:
+        __graft_entry__.build()
+    if world > 1:
+        dist.barrier()
+
+    em = em_bench(args, rank, world, torch, dist)
+    inf = em["info"]
+    ms_per_step = em["dt"] / args.steps * 1e3
+    value = world * args.steps / em["dt"]
+    algo = int(inf.algorithmic_bytes)
+    moved = int(inf.bytes_per_iter)
+    priced = min(algo, moved)
+    estep_s = em["estep_ms"] * 1e-3
+    line = {
+        "metric": "EM iterations/s (EMASE Model 4, 40M reads x 8 haplotypes x 120k isoforms per GPU)",
+        "value": value, "unit": "iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"configs[1]: single DO sample, R={args.rows} reads x H={args.haps} x "
+                               f"L={args.loci} isoforms, N={em['N']} alignment entries, quantify Model 4, "
+                               f"tol=0 fixed iterations" + (", rows sharded one 40M-read shard per GPU + "
+                               "RCCL all-reduce of the H*L vector per iteration" if world > 1 else ""),
+                   "layout": int(inf.layout), "merge_identical_rows": bool(args.merge),
+                   "device_rows": int(inf.num_device_rows), "device_words": int(inf.num_device_words)},
+        "roofline": {"bound": "hbm", "achieved": priced / estep_s / 1e9 if estep_s > 0 else None,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": priced / estep_s / 1e9 / HBM_PEAK_GBS if estep_s > 0 else None,
+                     "traffic": None, "kernel": "E-step", "kernel_ms": em["estep_ms"],
+                     "step_ms_events": em["step_ms"], "algorithmic_bytes": algo, "layout_bytes": moved,
+                     "priced_bytes": priced},
+        "setup_s": {"generate": em["t_gen"], "create_layout": em["t_create"]},
+    }
+    if rank == 0:
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = em_cpu_baseline(args)
+            line["speedup_vs_cpu"] = (value / world) / line["cpu_baseline"]["value"]
+        if not args.no_hmm:
+            line["hmm"] = hmm_bench(args, torch)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

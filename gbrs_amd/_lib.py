@@ -1,0 +1,149 @@
+"""ctypes binding of libgbrs_hip.so (include/gbrs_hip.h).
+
+There is no CPU fallback: importing this module without the built library, or calling into
+it without a visible gfx950 device, raises.  Build with ``python -c "import __graft_entry__ as g;
+g.build()"`` (or ``make -C gbrs_amd/csrc``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgbrs_hip.so")
+
+# names every build must export (checked by tests/test_abi.py against include/gbrs_hip.h)
+EXPORTS = [
+    "gbrs_last_error", "gbrs_abi_version", "gbrs_device_count",
+    "gbrs_em_create", "gbrs_em_create_device", "gbrs_em_prepare", "gbrs_em_step", "gbrs_em_run",
+    "gbrs_em_get", "gbrs_em_set_theta", "gbrs_em_group_sums", "gbrs_em_estep_partial",
+    "gbrs_em_finish_step", "gbrs_em_prepare_partial", "gbrs_em_finish_prepare", "gbrs_em_stream",
+    "gbrs_em_sync", "gbrs_em_info", "gbrs_em_alignment_counts", "gbrs_em_destroy",
+    "gbrs_hmm_create", "gbrs_hmm_set_expression", "gbrs_hmm_set_eprob", "gbrs_hmm_run",
+    "gbrs_hmm_get", "gbrs_hmm_info", "gbrs_hmm_destroy",
+]
+
+GBRS_OK = 0
+GBRS_ERR_INVALID = -1
+GBRS_ERR_HIP = -2
+GBRS_ERR_NO_DEVICE = -3
+GBRS_ERR_FLOAT = -4
+GBRS_ERR_UNSUPPORTED = -5
+GBRS_ERR_STATE = -6
+
+GBRS_EM_DEFAULT = 0
+GBRS_EM_MERGE_IDENTICAL_ROWS = 1
+
+
+class EmInfo(C.Structure):
+    _fields_ = [
+        ("num_rows", C.c_uint64), ("num_entries", C.c_uint64), ("num_device_rows", C.c_uint64),
+        ("num_device_words", C.c_uint64), ("bytes_per_iter", C.c_uint64),
+        ("algorithmic_bytes", C.c_uint64), ("last_estep_ms", C.c_double),
+        ("last_step_ms", C.c_double), ("num_loci", C.c_uint32), ("num_haps", C.c_uint32),
+        ("layout", C.c_uint32), ("reserved", C.c_uint32),
+    ]
+
+
+class HmmInfo(C.Structure):
+    _fields_ = [
+        ("total_genes", C.c_uint64), ("algorithmic_bytes", C.c_uint64),
+        ("last_emission_ms", C.c_double), ("last_forward_ms", C.c_double),
+        ("last_backward_ms", C.c_double), ("last_backtrace_ms", C.c_double),
+        ("num_states", C.c_int32), ("n_samples", C.c_int32),
+    ]
+
+
+class GbrsHipError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(message)
+        self.status = status
+
+
+_lib = None
+
+
+def load():
+    """Load libgbrs_hip.so (once).  Raises ImportError with build instructions if missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP library has not been built "
+            "(run `python -c 'import __graft_entry__ as g; g.build()'`). "
+            "gbrs_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, u32, u64, i64, dbl = C.c_void_p, C.c_int, C.c_uint32, C.c_uint64, C.c_int64, C.c_double
+    pp = C.POINTER(C.c_void_p)
+    lib.gbrs_last_error.restype = C.c_char_p
+    lib.gbrs_last_error.argtypes = []
+    lib.gbrs_abi_version.restype = i32
+    lib.gbrs_device_count.restype = i32
+    sigs = {
+        "gbrs_em_create": [u64, u32, u32, pp, pp, vp, vp, i32, u32, pp],
+        "gbrs_em_create_device": [u64, u32, u32, pp, pp, vp, vp, i32, u32, pp],
+        "gbrs_em_prepare": [vp, dbl],
+        "gbrs_em_step": [vp, i32, C.POINTER(dbl)],
+        "gbrs_em_run": [vp, i32, dbl, i32, C.POINTER(i32), vp, i32],
+        "gbrs_em_get": [vp, vp, vp],
+        "gbrs_em_set_theta": [vp, vp],
+        "gbrs_em_group_sums": [vp, i64, vp, vp, i32, vp],
+        "gbrs_em_estep_partial": [vp, pp, C.POINTER(u64)],
+        "gbrs_em_finish_step": [vp, C.POINTER(dbl)],
+        "gbrs_em_prepare_partial": [vp, pp, C.POINTER(u64)],
+        "gbrs_em_finish_prepare": [vp, dbl],
+        "gbrs_em_sync": [vp],
+        "gbrs_em_info": [vp, C.POINTER(EmInfo)],
+        "gbrs_em_alignment_counts": [vp, vp, vp, vp],
+        "gbrs_em_destroy": [vp],
+        "gbrs_hmm_create": [i32, i32, vp, vp, pp, i32, pp],
+        "gbrs_hmm_set_expression": [vp, i32, pp, pp, pp, dbl, dbl],
+        "gbrs_hmm_set_eprob": [vp, i32, pp],
+        "gbrs_hmm_run": [vp],
+        "gbrs_hmm_get": [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp],
+        "gbrs_hmm_info": [vp, C.POINTER(HmmInfo)],
+        "gbrs_hmm_destroy": [vp],
+    }
+    for name, args in sigs.items():
+        fn = getattr(lib, name)
+        fn.restype = i32
+        fn.argtypes = args
+    lib.gbrs_em_stream.restype = vp
+    lib.gbrs_em_stream.argtypes = [vp]
+    if lib.gbrs_abi_version() != 1:
+        raise ImportError("libgbrs_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(status):
+    """Map a gbrs_status to the exception the reference would have raised."""
+    if status == GBRS_OK:
+        return
+    msg = load().gbrs_last_error().decode(errors="replace")
+    if status == GBRS_ERR_FLOAT:
+        raise FloatingPointError(msg)
+    raise GbrsHipError(status, msg)
+
+
+def ptr(a):
+    """void* of a C-contiguous numpy array (or None)."""
+    if a is None:
+        return None
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def ptr_table(arrays):
+    """host array of H pointers to the given numpy arrays (kept alive by the caller)."""
+    tab = (C.c_void_p * len(arrays))()
+    for i, a in enumerate(arrays):
+        tab[i] = None if a is None else a.ctypes.data
+    return tab
+
+
+def raw_table(addresses):
+    tab = (C.c_void_p * len(addresses))()
+    for i, a in enumerate(addresses):
+        tab[i] = a
+    return tab

@@ -1,0 +1,94 @@
+// Shared host/device helpers for libgbrs_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/gbrs_hip.h"
+
+namespace gbrs {
+
+void set_error(const char *fmt, ...);
+int fail(int status, const char *fmt, ...);
+
+#define GBRS_HIP_CHECK(expr)                                                              \
+    do {                                                                                  \
+        hipError_t e__ = (expr);                                                          \
+        if (e__ != hipSuccess)                                                            \
+            return ::gbrs::fail(GBRS_ERR_HIP, "%s failed: %s (%s:%d)", #expr,            \
+                                hipGetErrorString(e__), __FILE__, __LINE__);              \
+    } while (0)
+
+#define GBRS_TRY(expr)                                                                    \
+    do {                                                                                  \
+        int s__ = (expr);                                                                 \
+        if (s__ != GBRS_OK) return s__;                                                   \
+    } while (0)
+
+int select_device(int device);
+
+// RAII device buffer (raw hipMalloc; sizes here are GBs, no pooling needed)
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    int alloc(size_t count) {
+        release();
+        n = count;
+        if (count == 0) return GBRS_OK;
+        hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T));
+        if (e != hipSuccess) {
+            p = nullptr;
+            return fail(GBRS_ERR_HIP, "hipMalloc(%zu bytes) failed: %s", count * sizeof(T),
+                        hipGetErrorString(e));
+        }
+        return GBRS_OK;
+    }
+    size_t bytes() const { return n * sizeof(T); }
+};
+
+constexpr int WAVE = 64;
+
+// ---- wave-level helpers (64-wide wavefronts) ---------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, WAVE);
+    return v;  // valid in lane 0
+}
+
+__device__ __forceinline__ double wave_sum_all(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
+    return v;  // same value in every lane (butterfly: fixed association)
+}
+
+// Block-wide sum, fixed association order (deterministic).  blockDim.x multiple of 64, <= 1024.
+__device__ __forceinline__ double block_sum(double v, double *lds /* >= 16 doubles */) {
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    v = wave_sum(v);
+    __syncthreads();
+    if (lane == 0) lds[wid] = v;
+    __syncthreads();
+    double r = 0.0;
+    if (wid == 0) {
+        const int nw = (blockDim.x + 63) >> 6;
+        r = (lane < nw) ? lds[lane] : 0.0;
+        r = wave_sum(r);
+    }
+    return r;  // valid in thread 0
+}
+
+}  // namespace gbrs

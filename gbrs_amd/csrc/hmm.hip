@@ -1,0 +1,651 @@
+// `gbrs reconstruct` HMM on MI355X (gfx950): emission model, forward + Viterbi, backward +
+// posterior, backtrace.  Reference: gbrs/gbrs_utils.py:63-98 and :463-599.
+//
+// Parallel decomposition: one workgroup per (sample, chromosome); the recursion over genes is
+// sequential by nature, so each step is made short instead: the S x S transition block of the
+// step is spread over S*LPS threads (LPS lanes per state, shuffle-reduced), the next step's
+// block is prefetched into registers while the current one is being reduced, and there is one
+// workgroup barrier per gene.  No dense contraction is reshaped for MFMA: the path is exp/log
+// and latency bound.
+#include "common.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+
+namespace gbrs {
+
+constexpr double TINY = 4.9406564584124654e-324;   // np.nextafter(0, 1)
+constexpr int MAX_H = 16;   // S <= 136 (CC-style 16 founders); DO is H = 8, S = 36
+
+// ------------------------------------------------------------------------------------------
+// Emission: one thread per (sample, gene).  Operation order follows get_genotype_probability:
+// builtin (sequential) sums, v / norm divisions, exp(d / (-2 sigma^2)), p / sum(p), log(p + tiny).
+// Compiled with -ffp-contract=off so a*a + s is never fused.
+// ------------------------------------------------------------------------------------------
+
+__device__ __forceinline__ double seq_norm(const double *v, int H, int stride) {
+    double s = 0.0;
+    for (int x = 0; x < H; ++x) s += v[x * stride] * v[x * stride];
+    return sqrt(s);
+}
+
+__global__ void __launch_bounds__(64)
+emission_kernel(int H, int S, int64_t n_genes, int n_samples, const double *__restrict__ expr,
+                const double *__restrict__ avecs, const uint8_t *__restrict__ has_avec,
+                const double *__restrict__ init_vec, double expr_threshold, double sigma,
+                double *__restrict__ eprob) {
+    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (id >= n_genes * n_samples) return;
+    const int64_t g = id % n_genes;
+    const double *e = expr + id * H;
+    double *out = eprob + id * S;
+    double esum = 0.0;
+    for (int x = 0; x < H; ++x) esum += e[x];
+    if (esum < expr_threshold) {
+        for (int s = 0; s < S; ++s) out[s] = init_vec[s];
+        return;
+    }
+    const bool naive = !has_avec[g];
+    const double sg = naive ? 0.450 : sigma;
+    const double denom = -2 * sg * sg;
+    const double *A = avecs + g * H * H;
+    // profile unit vector
+    double u[MAX_H];
+    {
+        const bool norm = esum > 1e-6;
+        const double nrm = norm ? seq_norm(e, H, 1) : 1.0;
+        for (int x = 0; x < H; ++x) u[x] = norm ? e[x] / nrm : e[x];
+    }
+    // per-haplotype specificity row: value accessor, sum and norm
+    double rn[MAX_H];       // norm to divide by, or 0 when the row is left as is
+    for (int i = 0; i < H; ++i) {
+        double s = 0.0, q = 0.0;
+        for (int x = 0; x < H; ++x) {
+            const double a = naive ? (x == i ? 1.0 : 0.0001) : A[i * H + x];
+            s += a;
+            q += a * a;
+        }
+        rn[i] = s > 1e-6 ? sqrt(q) : 0.0;
+    }
+    auto unit_row = [&](int i, int x) -> double {
+        const double a = naive ? (x == i ? 1.0 : 0.0001) : A[i * H + x];
+        return rn[i] != 0.0 ? a / rn[i] : a;
+    };
+    int s_idx = 0;
+    double psum = 0.0;
+    for (int i = 0; i < H; ++i) {
+        for (int j = i; j < H; ++j) {
+            double d = 0.0;
+            if (j == i) {
+                for (int x = 0; x < H; ++x) {
+                    const double t = u[x] - unit_row(i, x);
+                    d += t * t;
+                }
+            } else {
+                double gs = 0.0, gq = 0.0;
+                for (int x = 0; x < H; ++x) {
+                    const double w = unit_row(i, x) + unit_row(j, x);
+                    gs += w;
+                    gq += w * w;
+                }
+                const bool norm = gs > 1e-6;
+                const double gn = norm ? sqrt(gq) : 1.0;
+                for (int x = 0; x < H; ++x) {
+                    const double w = unit_row(i, x) + unit_row(j, x);
+                    const double t = u[x] - (norm ? w / gn : w);
+                    d += t * t;
+                }
+            }
+            const double p = exp(d / denom);
+            out[s_idx++] = p;
+            psum += p;
+        }
+    }
+    for (int s = 0; s < S; ++s) out[s] = log(out[s] / psum + TINY);
+}
+
+// ------------------------------------------------------------------------------------------
+// Forward + Viterbi.  Block = S*LPS threads rounded up to a wave; thread (j, q) owns row j of the
+// step's transition block T[i-1][j][:] at columns k = q + LPS*m.
+// ------------------------------------------------------------------------------------------
+
+struct ChromDesc {
+    int64_t gene_off;     // offset of the chromosome's first gene in the per-sample gene axis
+    int64_t trans_off;    // offset (in S*S blocks) of tprob[c][0] in the transition buffer
+    int64_t bp_off;       // offset (in S entries) of the chromosome's backpointer rows
+    int32_t n_genes, n_trans;
+};
+
+template <int LPS>
+__device__ __forceinline__ double group_sum(double v) {
+#pragma unroll
+    for (int off = LPS >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
+    return v;
+}
+
+template <int LPS>
+__device__ __forceinline__ void group_argmax(double &v, int &k) {
+#pragma unroll
+    for (int off = LPS >> 1; off > 0; off >>= 1) {
+        const double ov = __shfl_xor(v, off, WAVE);
+        const int ok = __shfl_xor(k, off, WAVE);
+        if (ov > v || (ov == v && ok < k)) { v = ov; k = ok; }
+    }
+}
+
+// log(sum_j exp(x[j])) over the S values in LDS, computed redundantly by every wave (no barrier).
+__device__ __forceinline__ double wave_logsumexp_lds(const double *x, int S) {
+    double s = 0.0;
+    for (int j = threadIdx.x & 63; j < S; j += 64) s += exp(x[j]);
+    return log(wave_sum_all(s));
+}
+__device__ __forceinline__ double wave_sum_lds(const double *x, int S) {
+    double s = 0.0;
+    for (int j = threadIdx.x & 63; j < S; j += 64) s += x[j];
+    return wave_sum_all(s);
+}
+
+template <int LPS, int KMAX, int MAXT>
+__global__ void __launch_bounds__(MAXT)
+forward_viterbi_kernel(int S, int64_t genes_per_sample, int64_t bp_per_sample,
+                       const ChromDesc *__restrict__ chroms, const double *__restrict__ tprob,
+                       const double *__restrict__ eprob, const double *__restrict__ init_vec,
+                       double *__restrict__ alpha, double *__restrict__ scaler,
+                       double *__restrict__ delta, uint16_t *__restrict__ bp,
+                       int32_t *__restrict__ last_state) {
+    extern __shared__ double lds[];           // a[2][S], d[2][S]
+    const ChromDesc cd = chroms[blockIdx.x];
+    const int sample = blockIdx.y;
+    const int n = cd.n_genes;
+    if (n <= 0) return;
+    const int j = threadIdx.x / LPS, q = threadIdx.x % LPS;
+    const bool active = j < S;
+    const int64_t g0 = (int64_t)sample * genes_per_sample + cd.gene_off;
+    const double *E = eprob + g0 * S;
+    double *AL = alpha + g0 * S, *DL = delta + g0 * S, *SC = scaler + g0;
+    uint16_t *BP = bp + ((int64_t)sample * bp_per_sample + cd.bp_off) * S;
+    const double *T = tprob + cd.trans_off * (int64_t)S * S;
+    double *a_buf = lds, *d_buf = lds + 2 * S;
+
+    // step 0
+    double a_own = 0.0, d_own = 0.0;      // unnormalised alpha / delta of state j (q == 0 lanes)
+    if (active && q == 0) {
+        const double v = init_vec[j] + E[j];
+        a_own = v;
+        d_own = v;
+        a_buf[j] = v;
+        d_buf[j] = v;
+        DL[j] = v;
+    }
+    // prefetch transition block 0
+    double tn[KMAX];
+    const int n_steps = min(n, cd.n_trans + 1);   // gene i needs T[i-1]
+    const bool phantom = cd.n_trans >= n;         // one more max-step with T[n-1] (backtrace quirk)
+#pragma unroll
+    for (int m = 0; m < KMAX; ++m) {
+        const int k = q + LPS * m;
+        tn[m] = (active && k < S && cd.n_trans > 0) ? T[(int64_t)j * S + k] : 0.0;
+    }
+    __syncthreads();
+    double z = wave_logsumexp_lds(a_buf, S);
+    if (active && q == 0) {
+        AL[j] = a_own - z;
+        if (j == 0) SC[0] = -z;
+    }
+    int cur = 0;
+    for (int i = 1; i <= n; ++i) {
+        const bool real = i < n_steps;            // produces alpha_i / delta_i
+        if (!real && !(i == n && phantom)) break;
+        double tc[KMAX];
+#pragma unroll
+        for (int m = 0; m < KMAX; ++m) tc[m] = tn[m];
+        if (i < cd.n_trans) {                     // prefetch T[i] for the next step
+            const double *Tn = T + (int64_t)i * S * S;
+#pragma unroll
+            for (int m = 0; m < KMAX; ++m) {
+                const int k = q + LPS * m;
+                if (active && k < S) tn[m] = Tn[(int64_t)j * S + k];
+            }
+        }
+        const double *a_prev = a_buf + cur * S, *d_prev = d_buf + cur * S;
+        double sum = 0.0, best = -DBL_MAX;
+        int best_k = 0x7fffffff;
+#pragma unroll
+        for (int m = 0; m < KMAX; ++m) {
+            const int k = q + LPS * m;
+            if (active && k < S) {
+                const double t = tc[m];
+                if (real) sum += exp((a_prev[k] - z) + t);
+                const double dv = d_prev[k] + t;
+                if (dv > best) { best = dv; best_k = k; }   // ascending k: first max kept
+            }
+        }
+        sum = group_sum<LPS>(sum);
+        group_argmax<LPS>(best, best_k);
+        const int nxt = cur ^ 1;
+        if (active && q == 0) {
+            BP[(int64_t)(i - 1) * S + j] = (uint16_t)best_k;
+            if (real) {
+                const double e = E[(int64_t)i * S + j];
+                a_own = log(sum + TINY) + e;
+                d_own = best + e;
+                a_buf[nxt * S + j] = a_own;
+                d_buf[nxt * S + j] = d_own;
+                DL[(int64_t)i * S + j] = d_own;
+            }
+        }
+        if (!real) break;
+        __syncthreads();
+        cur = nxt;
+        z = wave_logsumexp_lds(a_buf + cur * S, S);
+        if (active && q == 0) {
+            AL[(int64_t)i * S + j] = a_own - z;
+            if (j == 0) SC[i] = -z;
+        }
+    }
+    // sid = argmax delta[:, n-1] (first max)
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double *dl = DL + (int64_t)(n - 1) * S;
+        double b = dl[0];
+        int bk = 0;
+        for (int s = 1; s < S; ++s)
+            if (dl[s] > b) { b = dl[s]; bk = s; }
+        last_state[(int64_t)sample * gridDim.x + blockIdx.x] = bk;
+    }
+}
+
+// Backward + posterior.  tprob_t holds the transposed blocks: Tt[i][j][k] = T[i][k][j].
+template <int LPS, int KMAX, int MAXT>
+__global__ void __launch_bounds__(MAXT)
+backward_gamma_kernel(int S, int64_t genes_per_sample, const ChromDesc *__restrict__ chroms,
+                      const double *__restrict__ tprob_t, const double *__restrict__ eprob,
+                      const double *__restrict__ alpha, const double *__restrict__ scaler,
+                      double *__restrict__ beta, double *__restrict__ gamma) {
+    extern __shared__ double lds[];           // b[2][S], e[2][S], g[2][S]
+    const ChromDesc cd = chroms[blockIdx.x];
+    const int sample = blockIdx.y;
+    const int n = cd.n_genes;
+    if (n <= 0) return;
+    const int j = threadIdx.x / LPS, q = threadIdx.x % LPS;
+    const bool active = j < S;
+    const int64_t g0 = (int64_t)sample * genes_per_sample + cd.gene_off;
+    const double *E = eprob + g0 * S, *AL = alpha + g0 * S, *SC = scaler + g0;
+    double *BE = beta + g0 * S, *GA = gamma + g0 * S;
+    const double *Tt = tprob_t + cd.trans_off * (int64_t)S * S;
+    double *b_buf = lds, *e_buf = lds + 2 * S, *g_buf = lds + 4 * S;
+
+    // The reference indexes tprob[c][i] for i = n-2 .. 0, so it needs n_trans >= n-1
+    // (checked on the host).
+    int cur = 0;
+    double g_own = 0.0;
+    if (active && q == 0) {
+        const int64_t o = (int64_t)(n - 1) * S + j;
+        const double b = SC[n - 1];
+        BE[o] = b;
+        b_buf[j] = b;
+        e_buf[j] = E[o];
+        g_own = exp(AL[o] + b);
+        g_buf[j] = g_own;
+    }
+    double tn[KMAX];
+#pragma unroll
+    for (int m = 0; m < KMAX; ++m) {
+        const int k = q + LPS * m;
+        tn[m] = (active && k < S && n >= 2) ? Tt[((int64_t)(n - 2) * S + j) * S + k] : 0.0;
+    }
+    __syncthreads();
+    {
+        const double norm = wave_sum_lds(g_buf, S);
+        if (active && q == 0) GA[(int64_t)(n - 1) * S + j] = g_own / norm;
+    }
+    for (int i = n - 2; i >= 0; --i) {
+        double tc[KMAX];
+#pragma unroll
+        for (int m = 0; m < KMAX; ++m) tc[m] = tn[m];
+        if (i >= 1) {
+            const double *Tn = Tt + (int64_t)(i - 1) * S * S;
+#pragma unroll
+            for (int m = 0; m < KMAX; ++m) {
+                const int k = q + LPS * m;
+                if (active && k < S) tn[m] = Tn[(int64_t)j * S + k];
+            }
+        }
+        const double sc = SC[i];
+        const double *b_next = b_buf + cur * S, *e_next = e_buf + cur * S;
+        double sum = 0.0;
+#pragma unroll
+        for (int m = 0; m < KMAX; ++m) {
+            const int k = q + LPS * m;
+            if (active && k < S) sum += exp(((tc[m] + b_next[k]) + e_next[k]) + sc);
+        }
+        sum = group_sum<LPS>(sum);
+        const int nxt = cur ^ 1;
+        if (active && q == 0) {
+            const int64_t o = (int64_t)i * S + j;
+            const double b = log(sum);
+            BE[o] = b;
+            b_buf[nxt * S + j] = b;
+            e_buf[nxt * S + j] = E[o];
+            g_own = exp(AL[o] + b);
+            g_buf[nxt * S + j] = g_own;
+        }
+        __syncthreads();
+        cur = nxt;
+        const double norm = wave_sum_lds(g_buf + cur * S, S);
+        if (active && q == 0) GA[(int64_t)i * S + j] = g_own / norm;
+    }
+}
+
+// Backtrace (gbrs_utils.py:587-597): chase the backpointers from the last state.  One workgroup
+// per (sample, chromosome); the backpointer rows are staged through LDS in chunks so the
+// dependent chain runs at LDS latency.
+__global__ void __launch_bounds__(256)
+backtrace_kernel(int S, int BT_CHUNK, int64_t genes_per_sample, int64_t bp_per_sample, int64_t states_per_sample,
+                 int n_chrom, const ChromDesc *__restrict__ chroms, const uint16_t *__restrict__ bp,
+                 const int32_t *__restrict__ last_state, int32_t *__restrict__ states,
+                 int32_t *__restrict__ calls) {
+    extern __shared__ uint16_t stage[];        // BT_CHUNK * S
+    __shared__ int s_sid;
+    const ChromDesc cd = chroms[blockIdx.x];
+    const int sample = blockIdx.y;
+    const int n = cd.n_genes;
+    if (n <= 0) return;
+    const int m = min(n, cd.n_trans);
+    const uint16_t *BP = bp + ((int64_t)sample * bp_per_sample + cd.bp_off) * S;
+    int32_t *ST = states + (int64_t)sample * states_per_sample + cd.gene_off + blockIdx.x;
+    int32_t *CL = calls + (int64_t)sample * genes_per_sample + cd.gene_off;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) CL[i] = -1;
+    if (threadIdx.x == 0) {
+        s_sid = last_state[(int64_t)sample * n_chrom + blockIdx.x];
+        ST[m] = s_sid;
+    }
+    __syncthreads();
+    for (int hi = m; hi > 0; hi -= BT_CHUNK) {
+        const int lo = max(0, hi - BT_CHUNK);
+        const int cnt = (hi - lo) * S;
+        for (int x = threadIdx.x; x < cnt; x += blockDim.x) stage[x] = BP[(int64_t)lo * S + x];
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int sid = s_sid;
+            for (int i = hi - 1; i >= lo; --i) {
+                sid = stage[(i - lo) * S + sid];
+                ST[i] = sid;
+                CL[i] = sid;
+            }
+            s_sid = sid;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ void transpose_blocks_kernel(int S, int64_t n_blocks, const double *__restrict__ src,
+                                        double *__restrict__ dst) {
+    const int64_t total = n_blocks * S * S;
+    for (int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; x < total;
+         x += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = x / ((int64_t)S * S);
+        const int r = (int)(x - b * S * S);
+        const int jj = r / S, kk = r % S;
+        dst[x] = src[b * S * S + (int64_t)kk * S + jj];
+    }
+}
+
+}  // namespace gbrs
+
+using namespace gbrs;
+
+struct gbrs_hmm {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    int H = 0, S = 0, n_chrom = 0, n_samples = 0;
+    std::vector<ChromDesc> chroms;
+    int64_t total_genes = 0, total_trans = 0, total_bp = 0;
+    bool have_eprob = false, ran = false;
+    DevBuf<ChromDesc> d_chroms;
+    DevBuf<double> tprob, tprob_t, init_vec;
+    DevBuf<double> expr, avecs, eprob, alpha, beta, gamma, delta, scaler;
+    DevBuf<uint8_t> has_avec;
+    DevBuf<uint16_t> bp;
+    DevBuf<int32_t> last_state, states, calls;
+    double t_emis = 0, t_fwd = 0, t_bwd = 0, t_bt = 0;
+};
+
+namespace {
+
+int hmm_alloc_samples(gbrs_hmm *h, int n_samples) {
+    if (n_samples == h->n_samples && h->eprob.p) return GBRS_OK;
+    const size_t gs = (size_t)h->total_genes * n_samples;
+    GBRS_TRY(h->eprob.alloc(gs * h->S));
+    GBRS_TRY(h->alpha.alloc(gs * h->S));
+    GBRS_TRY(h->beta.alloc(gs * h->S));
+    GBRS_TRY(h->gamma.alloc(gs * h->S));
+    GBRS_TRY(h->delta.alloc(gs * h->S));
+    GBRS_TRY(h->scaler.alloc(gs));
+    GBRS_TRY(h->bp.alloc(std::max<size_t>((size_t)h->total_bp * n_samples * h->S, 1)));
+    GBRS_TRY(h->last_state.alloc((size_t)h->n_chrom * n_samples));
+    GBRS_TRY(h->states.alloc(((size_t)h->total_genes + h->n_chrom) * n_samples));
+    GBRS_TRY(h->calls.alloc(gs));
+    h->n_samples = n_samples;
+    return GBRS_OK;
+}
+
+template <int LPS, int KMAX, int MAXT>
+int hmm_launch(gbrs_hmm *h) {
+    const int S = h->S;
+    const int threads = ((S * LPS + 63) / 64) * 64;
+    dim3 grid(h->n_chrom, h->n_samples);
+    GBRS_HIP_CHECK(hipEventRecord(h->ev[1], h->stream));
+    hipLaunchKernelGGL((forward_viterbi_kernel<LPS, KMAX, MAXT>), grid, dim3(threads), 4 * S * sizeof(double),
+                       h->stream, S, h->total_genes, h->total_bp, h->d_chroms.p, h->tprob.p, h->eprob.p,
+                       h->init_vec.p, h->alpha.p, h->scaler.p, h->delta.p, h->bp.p, h->last_state.p);
+    GBRS_HIP_CHECK(hipEventRecord(h->ev[2], h->stream));
+    hipLaunchKernelGGL((backward_gamma_kernel<LPS, KMAX, MAXT>), grid, dim3(threads), 6 * S * sizeof(double),
+                       h->stream, S, h->total_genes, h->d_chroms.p, h->tprob_t.p, h->eprob.p, h->alpha.p,
+                       h->scaler.p, h->beta.p, h->gamma.p);
+    GBRS_HIP_CHECK(hipEventRecord(h->ev[3], h->stream));
+    const int bt_chunk = std::max(1, std::min(512, 32768 / S));   // <= 64 KiB of staged backpointers
+    hipLaunchKernelGGL(backtrace_kernel, grid, dim3(256), (size_t)bt_chunk * S * sizeof(uint16_t), h->stream,
+                       S, bt_chunk, h->total_genes, h->total_bp, h->total_genes + h->n_chrom, h->n_chrom,
+                       h->d_chroms.p, h->bp.p, h->last_state.p, h->states.p, h->calls.p);
+    GBRS_HIP_CHECK(hipEventRecord(h->ev[4], h->stream));
+    GBRS_HIP_CHECK(hipGetLastError());
+    GBRS_HIP_CHECK(hipStreamSynchronize(h->stream));
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, h->ev[1], h->ev[2]) == hipSuccess) h->t_fwd = ms;
+    if (hipEventElapsedTime(&ms, h->ev[2], h->ev[3]) == hipSuccess) h->t_bwd = ms;
+    if (hipEventElapsedTime(&ms, h->ev[3], h->ev[4]) == hipSuccess) h->t_bt = ms;
+    return GBRS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int gbrs_hmm_create(int num_haps, int n_chrom, const int32_t *n_genes, const int32_t *n_trans,
+                    const double *const *tprob, int device, gbrs_hmm_t **out) {
+    if (!out) return fail(GBRS_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (num_haps < 1 || num_haps > MAX_H) return fail(GBRS_ERR_INVALID, "num_haps must be in 1..%d", MAX_H);
+    if (n_chrom < 1 || !n_genes || !n_trans || !tprob) return fail(GBRS_ERR_INVALID, "bad chromosome tables");
+    GBRS_TRY(select_device(device));
+    gbrs_hmm *h = new gbrs_hmm();
+    struct Guard { gbrs_hmm *p; ~Guard() { if (p) gbrs_hmm_destroy(p); } } guard{h};
+    h->device = device;
+    h->H = num_haps;
+    h->S = num_haps * (num_haps + 1) / 2;
+    h->n_chrom = n_chrom;
+    const int S = h->S;
+    h->chroms.resize(n_chrom);
+    for (int c = 0; c < n_chrom; ++c) {
+        if (n_genes[c] < 1) return fail(GBRS_ERR_INVALID, "chromosome %d has no genes", c);
+        // the backward sweep reads tprob[c][i] for i = 0 .. n-2 (gbrs_utils.py:541-549)
+        if (n_trans[c] < n_genes[c] - 1)
+            return fail(GBRS_ERR_INVALID, "index %d is out of bounds for axis 0 with size %d (tprob of chromosome %d)",
+                        n_genes[c] - 2, n_trans[c], c);
+        if (n_trans[c] > 0 && !tprob[c]) return fail(GBRS_ERR_INVALID, "tprob[%d] is NULL", c);
+        ChromDesc &cd = h->chroms[c];
+        cd.gene_off = h->total_genes;
+        cd.trans_off = h->total_trans;
+        cd.bp_off = h->total_bp;
+        cd.n_genes = n_genes[c];
+        cd.n_trans = n_trans[c];
+        h->total_genes += n_genes[c];
+        h->total_trans += n_trans[c];
+        h->total_bp += std::min(n_genes[c], n_trans[c]);
+    }
+    GBRS_HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamDefault));
+    for (auto &e : h->ev) GBRS_HIP_CHECK(hipEventCreate(&e));
+    GBRS_TRY(h->d_chroms.alloc(n_chrom));
+    GBRS_HIP_CHECK(hipMemcpy(h->d_chroms.p, h->chroms.data(), n_chrom * sizeof(ChromDesc), hipMemcpyHostToDevice));
+    const size_t blk = (size_t)S * S;
+    GBRS_TRY(h->tprob.alloc(std::max<size_t>(h->total_trans * blk, 1)));
+    GBRS_TRY(h->tprob_t.alloc(std::max<size_t>(h->total_trans * blk, 1)));
+    for (int c = 0; c < n_chrom; ++c)
+        if (n_trans[c] > 0)
+            GBRS_HIP_CHECK(hipMemcpy(h->tprob.p + h->chroms[c].trans_off * blk, tprob[c],
+                                     (size_t)n_trans[c] * blk * sizeof(double), hipMemcpyHostToDevice));
+    if (h->total_trans > 0)
+        hipLaunchKernelGGL(transpose_blocks_kernel, dim3(2048), dim3(256), 0, h->stream, S, h->total_trans,
+                           h->tprob.p, h->tprob_t.p);
+    // init_vec (gbrs_utils.py:465-471): log(1/H^2) homozygous, log(2/H^2) heterozygous
+    std::vector<double> iv;
+    for (int a = 0; a < num_haps; ++a)
+        for (int b = a; b < num_haps; ++b)
+            iv.push_back(std::log((a == b ? 1.0 : 2.0) / (double)(num_haps * num_haps)));
+    GBRS_TRY(h->init_vec.alloc(S));
+    GBRS_HIP_CHECK(hipMemcpy(h->init_vec.p, iv.data(), S * sizeof(double), hipMemcpyHostToDevice));
+    GBRS_HIP_CHECK(hipDeviceSynchronize());
+    guard.p = nullptr;
+    *out = h;
+    return GBRS_OK;
+}
+
+int gbrs_hmm_set_expression(gbrs_hmm_t *h, int n_samples, const double *const *expr,
+                            const double *const *avecs, const uint8_t *const *has_avec,
+                            double expr_threshold, double sigma) {
+    if (!h || !expr || !avecs || !has_avec || n_samples < 1) return fail(GBRS_ERR_INVALID, "bad argument");
+    GBRS_TRY(select_device(h->device));
+    GBRS_TRY(hmm_alloc_samples(h, n_samples));
+    const int H = h->H;
+    GBRS_TRY(h->expr.alloc((size_t)h->total_genes * n_samples * H));
+    GBRS_TRY(h->avecs.alloc((size_t)h->total_genes * H * H));
+    GBRS_TRY(h->has_avec.alloc(h->total_genes));
+    for (int c = 0; c < h->n_chrom; ++c) {
+        const ChromDesc &cd = h->chroms[c];
+        if (!expr[c] || !avecs[c] || !has_avec[c]) return fail(GBRS_ERR_INVALID, "NULL table for chromosome %d", c);
+        for (int s = 0; s < n_samples; ++s)
+            GBRS_HIP_CHECK(hipMemcpy(h->expr.p + ((size_t)s * h->total_genes + cd.gene_off) * H,
+                                     expr[c] + (size_t)s * cd.n_genes * H,
+                                     (size_t)cd.n_genes * H * sizeof(double), hipMemcpyHostToDevice));
+        GBRS_HIP_CHECK(hipMemcpy(h->avecs.p + (size_t)cd.gene_off * H * H, avecs[c],
+                                 (size_t)cd.n_genes * H * H * sizeof(double), hipMemcpyHostToDevice));
+        GBRS_HIP_CHECK(hipMemcpy(h->has_avec.p + cd.gene_off, has_avec[c], cd.n_genes, hipMemcpyHostToDevice));
+    }
+    const int64_t total = h->total_genes * n_samples;
+    GBRS_HIP_CHECK(hipEventRecord(h->ev[0], h->stream));
+    hipLaunchKernelGGL(emission_kernel, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, h->stream, H, h->S,
+                       h->total_genes, n_samples, h->expr.p, h->avecs.p, h->has_avec.p, h->init_vec.p,
+                       expr_threshold, sigma, h->eprob.p);
+    GBRS_HIP_CHECK(hipEventRecord(h->ev[1], h->stream));
+    GBRS_HIP_CHECK(hipGetLastError());
+    GBRS_HIP_CHECK(hipStreamSynchronize(h->stream));
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, h->ev[0], h->ev[1]) == hipSuccess) h->t_emis = ms;
+    h->have_eprob = true;
+    h->ran = false;
+    return GBRS_OK;
+}
+
+int gbrs_hmm_set_eprob(gbrs_hmm_t *h, int n_samples, const double *const *eprob) {
+    if (!h || !eprob || n_samples < 1) return fail(GBRS_ERR_INVALID, "bad argument");
+    GBRS_TRY(select_device(h->device));
+    GBRS_TRY(hmm_alloc_samples(h, n_samples));
+    for (int c = 0; c < h->n_chrom; ++c) {
+        const ChromDesc &cd = h->chroms[c];
+        if (!eprob[c]) return fail(GBRS_ERR_INVALID, "eprob[%d] is NULL", c);
+        for (int s = 0; s < n_samples; ++s)
+            GBRS_HIP_CHECK(hipMemcpy(h->eprob.p + ((size_t)s * h->total_genes + cd.gene_off) * h->S,
+                                     eprob[c] + (size_t)s * cd.n_genes * h->S,
+                                     (size_t)cd.n_genes * h->S * sizeof(double), hipMemcpyHostToDevice));
+    }
+    h->have_eprob = true;
+    h->ran = false;
+    h->t_emis = 0;
+    return GBRS_OK;
+}
+
+int gbrs_hmm_run(gbrs_hmm_t *h) {
+    if (!h) return fail(GBRS_ERR_INVALID, "handle is NULL");
+    if (!h->have_eprob) return fail(GBRS_ERR_STATE, "no expression / emission data set");
+    GBRS_TRY(select_device(h->device));
+    const int S = h->S;
+    int rc;
+    if (S <= 48) rc = hmm_launch<16, 3, 768>(h);
+    else if (S <= 64) rc = hmm_launch<16, 4, 1024>(h);
+    else rc = hmm_launch<4, 34, 576>(h);      // S <= 136 (MAX_H = 16)
+    if (rc == GBRS_OK) h->ran = true;
+    return rc;
+}
+
+int gbrs_hmm_get(gbrs_hmm_t *h, int sample, int chrom, double *gamma, int32_t *states, int32_t *calls,
+                 double *alpha, double *beta, double *delta, double *scaler, double *eprob) {
+    if (!h) return fail(GBRS_ERR_INVALID, "handle is NULL");
+    if (sample < 0 || sample >= h->n_samples || chrom < 0 || chrom >= h->n_chrom)
+        return fail(GBRS_ERR_INVALID, "sample/chromosome out of range");
+    if (!h->ran && (gamma || states || calls || alpha || beta || delta || scaler))
+        return fail(GBRS_ERR_STATE, "run() has not been called");
+    GBRS_TRY(select_device(h->device));
+    const ChromDesc &cd = h->chroms[chrom];
+    const int S = h->S, n = cd.n_genes;
+    const size_t goff = (size_t)sample * h->total_genes + cd.gene_off;
+    std::vector<double> tmp((size_t)n * S);
+    auto fetch_t = [&](const double *dev, double *dst) -> int {   // device [n][S] -> host [S][n]
+        GBRS_HIP_CHECK(hipMemcpy(tmp.data(), dev + goff * S, tmp.size() * sizeof(double), hipMemcpyDeviceToHost));
+        for (int i = 0; i < n; ++i)
+            for (int s = 0; s < S; ++s) dst[(size_t)s * n + i] = tmp[(size_t)i * S + s];
+        return GBRS_OK;
+    };
+    if (gamma) GBRS_TRY(fetch_t(h->gamma.p, gamma));
+    if (alpha) GBRS_TRY(fetch_t(h->alpha.p, alpha));
+    if (beta) GBRS_TRY(fetch_t(h->beta.p, beta));
+    if (delta) GBRS_TRY(fetch_t(h->delta.p, delta));
+    if (scaler) GBRS_HIP_CHECK(hipMemcpy(scaler, h->scaler.p + goff, n * sizeof(double), hipMemcpyDeviceToHost));
+    if (eprob) GBRS_HIP_CHECK(hipMemcpy(eprob, h->eprob.p + goff * S, (size_t)n * S * sizeof(double), hipMemcpyDeviceToHost));
+    if (calls) GBRS_HIP_CHECK(hipMemcpy(calls, h->calls.p + goff, n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (states) {
+        const int m = std::min(n, cd.n_trans);
+        const size_t soff = (size_t)sample * (h->total_genes + h->n_chrom) + cd.gene_off + chrom;
+        GBRS_HIP_CHECK(hipMemcpy(states, h->states.p + soff, (m + 1) * sizeof(int32_t), hipMemcpyDeviceToHost));
+    }
+    return GBRS_OK;
+}
+
+int gbrs_hmm_info(gbrs_hmm_t *h, gbrs_hmm_info_t *info) {
+    if (!h || !info) return fail(GBRS_ERR_INVALID, "NULL argument");
+    std::memset(info, 0, sizeof(*info));
+    info->total_genes = h->total_genes;
+    info->algorithmic_bytes = (uint64_t)h->total_genes * (16ull * h->S * h->S + 64ull * h->S);
+    info->last_emission_ms = h->t_emis;
+    info->last_forward_ms = h->t_fwd;
+    info->last_backward_ms = h->t_bwd;
+    info->last_backtrace_ms = h->t_bt;
+    info->num_states = h->S;
+    info->n_samples = h->n_samples;
+    return GBRS_OK;
+}
+
+int gbrs_hmm_destroy(gbrs_hmm_t *h) {
+    if (!h) return GBRS_OK;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (auto &e : h->ev)
+        if (e) (void)hipEventDestroy(e);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return GBRS_OK;
+}
+
+}  // extern "C"

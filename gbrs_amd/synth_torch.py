@@ -1,0 +1,63 @@
+"""Full-size synthetic EM workload built directly in HBM with torch (bench.py only).
+
+Same recipe as gbrs_amd.synth.make_em_rows / rows_to_csc but with torch's
+generator, so a 40M-read DO-shaped sample is ready in a couple of seconds instead of minutes.
+PyTorch is plumbing here (device memory + sort); nothing in this file is on the measured path.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import synth
+
+
+def make_em_problem_device(R, H, L, seed, device="cuda:0"):
+    """Returns dict(indptr=[H int32 tensors L+1], indices=[H int32 tensors], eff_len (H x L) float64
+    tensor, N, groups info) with every array resident on `device`.  int32 tensors carry the
+    uint32 bit patterns the C ABI expects (all values < 2^31 at these sizes)."""
+    assert R < 2**31 and L < 2**24
+    rng = np.random.default_rng(seed)
+    sizes, starts, gene_of = synth._gene_layout(rng, L)
+    abundance = rng.lognormal(0.0, 2.0, size=L) * (rng.random(L) < 0.6)
+    p = abundance / abundance.sum()
+    raw_len = np.round(rng.lognormal(7.3, 0.6, size=L))
+    dev = torch.device(device)
+    g = torch.Generator(device=dev)
+    g.manual_seed(int(seed))
+    cdf = torch.from_numpy(np.cumsum(p)).to(dev)
+    cdf[-1] = 1.0
+    t = torch.searchsorted(cdf, torch.rand(R, generator=g, device=dev, dtype=torch.float64), right=True)
+    t.clamp_(max=L - 1)
+    true_hap = torch.randint(0, H, (R,), generator=g, device=dev, dtype=torch.int32)
+    mask = torch.zeros(R, dtype=torch.int32, device=dev)
+    for h in range(H):
+        hit = (torch.rand(R, generator=g, device=dev) < 0.85) | (true_hap == h)
+        mask |= hit.to(torch.int32) << h
+        del hit
+    gene_of_t = torch.from_numpy(gene_of).to(dev)[t]
+    sizes_t = torch.from_numpy(sizes).to(dev)[gene_of_t]
+    starts_t = torch.from_numpy(starts).to(dev)[gene_of_t]
+    sib = starts_t + (torch.rand(R, generator=g, device=dev, dtype=torch.float64) * sizes_t).to(torch.int64)
+    use_sib = (torch.rand(R, generator=g, device=dev) < 0.5) & (sib != t)
+    del gene_of_t, sizes_t, starts_t, true_hap
+    rows_all = torch.arange(R, device=dev, dtype=torch.int64)
+    indptr, indices = [], []
+    n_total = 0
+    bounds = torch.arange(L + 1, device=dev, dtype=torch.int64) * R
+    for h in range(H):
+        bit = ((mask >> h) & 1).bool()
+        k1 = t[bit] * R + rows_all[bit]
+        b2 = bit & use_sib
+        k2 = sib[b2] * R + rows_all[b2]
+        key, _ = torch.sort(torch.cat((k1, k2)))
+        del k1, k2, b2, bit
+        indices.append((key % R).to(torch.int32))
+        indptr.append(torch.searchsorted(key, bounds).to(torch.int32))
+        n_total += int(key.numel())
+        del key
+    eff = np.maximum(raw_len - 100 + 1.0, 1.0)
+    eff_len = torch.from_numpy(np.ascontiguousarray(np.tile(eff, (H, 1)))).to(dev)
+    torch.cuda.synchronize(dev)
+    return dict(indptr=indptr, indices=indices, eff_len=eff_len, N=n_total, R=R, H=H, L=L,
+                num_groups=len(sizes))

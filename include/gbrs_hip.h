@@ -1,0 +1,207 @@
+/*
+ * gbrs_hip.h - C ABI of libgbrs_hip.so: the MI355X (gfx950) implementation of the two
+ * numeric hot paths of churchill-lab/gbrs.
+ *
+ * The reference has no FFI seam (it is pure Python); the entry points below are cut at the
+ * seams its own callers use, so a maintainer can bind them with ctypes and
+ * keep `gbrs quantify` / `gbrs reconstruct` unchanged above this line.  All citations are
+ * relative to /root/reference/src/gbrs/.
+ *
+ *   EM  (gbrs quantify -M 4):   emase/EMfactory.py:20-287 as driven from
+ *                                gbrs/emase_utils.py:282-316
+ *   HMM (gbrs reconstruct):     gbrs/gbrs_utils.py:463-599
+ *
+ * Conventions
+ *   - plain pointers and sizes only; the caller owns every host buffer, the library copies in
+ *     during the call and never keeps a host pointer after it returns;
+ *   - every function returns 0 on success and a negative gbrs_status on failure, with the text
+ *     available from gbrs_last_error() (thread-local).  The Python shim turns that into the
+ *     RuntimeError / FloatingPointError the reference would have raised;
+ *   - calls are blocking and synchronous unless the name ends in _async; one HIP stream per
+ *     handle; different handles may be driven from different threads (ctypes drops the GIL);
+ *   - matrices named "H x L" are row-major with the haplotype index slowest, exactly the
+ *     ndarray layout of EMfactory.allelic_expression.
+ */
+#ifndef GBRS_HIP_H
+#define GBRS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GBRS_ABI_VERSION 1
+
+enum gbrs_status {
+    GBRS_OK = 0,
+    GBRS_ERR_INVALID = -1,      /* bad argument (RuntimeError in the reference)            */
+    GBRS_ERR_HIP = -2,          /* HIP runtime failure, message carries hipGetErrorString  */
+    GBRS_ERR_NO_DEVICE = -3,    /* no gfx950 device visible: there is NO CPU fallback      */
+    GBRS_ERR_FLOAT = -4,        /* 0/0 or overflow where the reference's np.seterr(all='raise')
+                                   (EMfactory.py:256) raises FloatingPointError              */
+    GBRS_ERR_UNSUPPORTED = -5,  /* models 1-3 (EMfactory.py:160-203): out of scope         */
+    GBRS_ERR_STATE = -6         /* call order violated (e.g. run before prepare)           */
+};
+
+const char *gbrs_last_error(void);
+int gbrs_abi_version(void);
+/* Number of visible HIP devices, or a negative status. */
+int gbrs_device_count(void);
+
+/* ------------------------------------------------------------------------------------------
+ * EM: EMASE Model 4 over the alignment incidence tensor.
+ * ---------------------------------------------------------------------------------------- */
+
+typedef struct gbrs_em gbrs_em_t;
+
+/* flags for gbrs_em_create* */
+#define GBRS_EM_DEFAULT 0u
+/* Merge rows with identical alignment patterns into one weighted row while building the device
+ * layout (what `gbrs compress`, gbrs/emase_utils.py:60-103, does as a separate command).  Same
+ * fixed point; off by default so that every input row is processed every iteration. */
+#define GBRS_EM_MERGE_IDENTICAL_ROWS 1u
+
+/*
+ * Replaces: AlignmentPropertyMatrix(h5file=...) as consumed by EMfactory.__init__
+ * (emase/Sparse3DMatrix.py:80-92 CSC branch, emase/AlignmentPropertyMatrix.py:72-73 count,
+ * emase/EMfactory.py:60-94 target_lengths).
+ *
+ *   num_rows  R reads / equivalence classes        num_loci  L isoforms      num_haps  H (<= 32)
+ *   indptr[h]   uint32[L+1]  column pointers of haplotype h's (R x L) CSC incidence matrix
+ *   indices[h]  uint32[nnz_h] row (read) ids, any order inside a column, no duplicates
+ *   count       double[R] EC multiplicities, or NULL (every row counts once)
+ *   eff_len     double[H*L] row-major max(len - read_length + 1, 1), or NULL (no length model)
+ *   device      HIP device ordinal
+ */
+int gbrs_em_create(uint64_t num_rows, uint32_t num_loci, uint32_t num_haps,
+                   const uint32_t *const *indptr, const uint32_t *const *indices,
+                   const double *count, const double *eff_len,
+                   int device, uint32_t flags, gbrs_em_t **out);
+
+/* Same, but every array pointer (indptr[h], indices[h], count, eff_len) is a DEVICE pointer on
+ * `device`; the pointer tables indptr/indices themselves are host arrays of H device pointers.
+ * The inputs are only read during the call. */
+int gbrs_em_create_device(uint64_t num_rows, uint32_t num_loci, uint32_t num_haps,
+                          const uint32_t *const *indptr, const uint32_t *const *indices,
+                          const double *count, const double *eff_len,
+                          int device, uint32_t flags, gbrs_em_t **out);
+
+/* Replaces EMfactory.prepare (EMfactory.py:95-111): theta0 = sum_r count[r]/nnz_row / eff_len,
+ * then the optional pseudocount rule (:105-111). */
+int gbrs_em_prepare(gbrs_em_t *em, double pseudocount);
+
+/* n_iters EM steps (EMfactory.update_allelic_expression, EMfactory.py:214-232) without looking
+ * at the stopping rule; err_sum_out (nullable) receives the last step's total TPM change. */
+int gbrs_em_step(gbrs_em_t *em, int n_iters, double *err_sum_out);
+
+/* Replaces EMfactory.run (EMfactory.py:234-287).  model must be 4.  Stops when
+ * err_sum <= 1e6*tol or after max_iters steps.  err_hist (nullable) receives up to
+ * err_hist_cap per-iteration err_sum values (the numbers the reference prints). */
+int gbrs_em_run(gbrs_em_t *em, int model, double tol, int max_iters,
+                int *n_iters_out, double *err_hist, int err_hist_cap);
+
+/* theta (H x L) = EMfactory.allelic_expression; expected_counts (H x L) = probability.sum(READ)
+ * of the last E-step (EMfactory.py:302).  Either pointer may be NULL. */
+int gbrs_em_get(gbrs_em_t *em, double *theta, double *expected_counts);
+
+/* Overwrite theta (H x L), e.g. to resume from a checkpoint. */
+int gbrs_em_set_theta(gbrs_em_t *em, const double *theta);
+
+/* Gene-level sums: EMfactory.get_allelic_expression(at_group_level=True) (EMfactory.py:140-142)
+ * and the grp_wise branch of report_read_counts (:305).  group_ptr int64[G+1], members int64[..]
+ * locus ids.  which: 0 = theta, 1 = expected counts.  out is (H x G) row-major. */
+int gbrs_em_group_sums(gbrs_em_t *em, int64_t num_groups, const int64_t *group_ptr,
+                       const int64_t *members, int which, double *out);
+
+/* Multi-GPU building blocks (rows sharded across ranks): one E-step over this
+ * handle's rows accumulated into the handle's own partial buffer; the caller all-reduces that
+ * buffer (RCCL) and then finishes the step.  partial_dev returns the DEVICE pointer of the
+ * (L x H, locus-major) float64 partial-sum buffer and its element count. */
+int gbrs_em_estep_partial(gbrs_em_t *em, void **partial_dev, uint64_t *n_elems);
+int gbrs_em_finish_step(gbrs_em_t *em, double *err_sum_out);
+/* Same pair for prepare(): partial sums of count/nnz_row, then the division and pseudocount. */
+int gbrs_em_prepare_partial(gbrs_em_t *em, void **partial_dev, uint64_t *n_elems);
+int gbrs_em_finish_prepare(gbrs_em_t *em, double pseudocount);
+/* The HIP stream (hipStream_t) the handle launches on, so the caller can order a collective. */
+void *gbrs_em_stream(gbrs_em_t *em);
+int gbrs_em_sync(gbrs_em_t *em);
+
+typedef struct gbrs_em_info {
+    uint64_t num_rows;          /* R as given                                               */
+    uint64_t num_entries;       /* N = sum_h nnz_h                                          */
+    uint64_t num_device_rows;   /* rows in the device layout (== R unless merged)           */
+    uint64_t num_device_words;  /* 32-bit (row, locus) words streamed per E-step            */
+    uint64_t bytes_per_iter;    /* bytes the E+M step kernels move per iteration (layout)   */
+    uint64_t algorithmic_bytes; /* 4N + 4(R+1) [+8R] + 8HL*2 [+8HL]             */
+    double   last_estep_ms;     /* HIP-event time of the last E-step kernel launch          */
+    double   last_step_ms;      /* HIP-event time of the last full EM step                  */
+    uint32_t num_loci, num_haps;
+    uint32_t layout;            /* 0 = csc-direct, 1 = packed row tiles                     */
+    uint32_t reserved;
+} gbrs_em_info_t;
+int gbrs_em_info(gbrs_em_t *em, gbrs_em_info_t *info);
+
+/* `--report-alignment-counts` (emase/AlignmentPropertyMatrix.py:389-459): all (H x L) outputs
+ * except locus_unique (L); integer-valued float64, exact.  Any pointer may be NULL. */
+int gbrs_em_alignment_counts(gbrs_em_t *em, double *aln_counts, double *allele_unique,
+                             double *locus_unique);
+
+int gbrs_em_destroy(gbrs_em_t *em);
+
+/* ------------------------------------------------------------------------------------------
+ * HMM: per-chromosome forward-backward + Viterbi over the S = H(H+1)/2 diplotype states.
+ * ---------------------------------------------------------------------------------------- */
+
+typedef struct gbrs_hmm gbrs_hmm_t;
+
+/*
+ * Replaces the `tprob = np.load(tprob_file)` tables as consumed by gbrs_utils.py:500-599.
+ *   n_genes[c]  genes on chromosome c (genome order)       n_trans[c]  len(tprob[c])
+ *   tprob[c]    double[n_trans[c]][S][S], natural-log, T[i][to][from], C order
+ * n_trans[c] may be n_genes[c]-1 (tables written by get_transition_prob, gbrs_utils.py:273-278)
+ * or >= n_genes[c] (DO tables); both backtrace conventions of gbrs_utils.py:589-596 are kept.
+ */
+int gbrs_hmm_create(int num_haps, int n_chrom, const int32_t *n_genes, const int32_t *n_trans,
+                    const double *const *tprob, int device, gbrs_hmm_t **out);
+
+/* Emission model on the device: gbrs_utils.py:463-492 with get_genotype_probability (:80-98).
+ *   expr[c]     double[n_samples][n_genes[c]][H]   gene-level TPM per haplotype
+ *   avecs[c]    double[n_genes[c]][H][H]           alignment specificity (row i = haplotype i)
+ *   has_avec[c] uint8[n_genes[c]]  0 -> naive avecs with sigma fixed 0.450 (:483-487)
+ */
+int gbrs_hmm_set_expression(gbrs_hmm_t *hmm, int n_samples, const double *const *expr,
+                            const double *const *avecs, const uint8_t *const *has_avec,
+                            double expr_threshold, double sigma);
+
+/* Alternative to set_expression: caller-computed log emissions eprob[c] double[n_samples][n_c][S]. */
+int gbrs_hmm_set_eprob(gbrs_hmm_t *hmm, int n_samples, const double *const *eprob);
+
+/* forward (:500-526) + Viterbi delta/backpointers (:567-579), backward + posterior (:530-560),
+ * backtrace (:580-598) for every (sample, chromosome). */
+int gbrs_hmm_run(gbrs_hmm_t *hmm);
+
+/* Results of one (sample, chromosome).  Every pointer is nullable.
+ *   gamma  double[S][n_c]  C order, as saved in genoprobs.npz (gbrs_utils.py:558-563)
+ *   states int32[n'+1]     ordered Viterbi path as saved in genotypes.npz, n' = min(n_c, n_trans)
+ *   calls  int32[n_c]      state index written to genotypes.tsv per gene, -1 = no entry
+ *   alpha, beta, delta  double[S][n_c];  scaler double[n_c];  eprob double[n_c][S]
+ */
+int gbrs_hmm_get(gbrs_hmm_t *hmm, int sample, int chrom, double *gamma, int32_t *states,
+                 int32_t *calls, double *alpha, double *beta, double *delta, double *scaler,
+                 double *eprob);
+
+typedef struct gbrs_hmm_info {
+    uint64_t total_genes;        /* sum_c n_genes[c]                                        */
+    uint64_t algorithmic_bytes;  /* per sample: sum_c n_c * (16 S^2 + 64 S)     */
+    double   last_emission_ms, last_forward_ms, last_backward_ms, last_backtrace_ms;
+    int32_t  num_states, n_samples;
+} gbrs_hmm_info_t;
+int gbrs_hmm_info(gbrs_hmm_t *hmm, gbrs_hmm_info_t *info);
+
+int gbrs_hmm_destroy(gbrs_hmm_t *hmm);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GBRS_HIP_H */

@@ -1,0 +1,52 @@
+import glob
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def golden_files(prefix):
+    return sorted(glob.glob(os.path.join(GOLD, prefix + "_*.npz")))
+
+
+def load_golden(path):
+    with np.load(path, allow_pickle=False) as z:
+        return {k: z[k] for k in z.files}
+
+
+def em_case_inputs(g):
+    """(R, L, H, indptr, indices, count, eff_len, groups, gtmask) from an em_*.npz fixture."""
+    H, L, R = int(g["num_haps"]), int(g["num_loci"]), int(g["num_rows"])
+    indptr = [g[f"indptr{h}"] for h in range(H)]
+    indices = [g[f"indices{h}"] for h in range(H)]
+    count = g["count"] if bool(g["has_count"]) else None
+    eff_len = g["eff_len"] if bool(g["has_len"]) else None
+    gp, gm = g["group_ptr"], g["group_members"]
+    groups = [list(gm[gp[i]:gp[i + 1]]) for i in range(len(gp) - 1)]
+    gtmask = g["gtmask"] if bool(g["has_mask"]) else None
+    return R, L, H, indptr, indices, count, eff_len, groups, gtmask
+
+
+def hmm_case_inputs(g):
+    H = int(g["num_haps"])
+    chroms = [str(c) for c in g["chroms"]]
+    out = dict(H=H, chroms=chroms)
+    for k in ("genes", "tprob", "expr", "has_avec", "avecs"):
+        out[k] = {c: g[f"{k}_{c}"] for c in chroms}
+    return out
+
+
+@pytest.fixture(scope="session")
+def hip_lib():
+    from gbrs_amd import _lib
+    return _lib.load()

@@ -1,0 +1,164 @@
+"""HIP EM path vs the reference goldens and vs the CPU oracle (needs an MI355X)."""
+import numpy as np
+import pytest
+
+from conftest import em_case_inputs, golden_files, load_golden
+
+pytestmark = pytest.mark.gpu
+
+# float64 path; the only differences from the reference are summation order (atomics / trees)
+# and theta*A/len vs sum(theta/den)/len rounding.  North-star tolerance is 1e-4 relative;
+# we hold the kernels to 1e-9.
+RTOL = 1e-9
+
+
+def make_factory(g, merge=False):
+    from gbrs_amd.alignment import AlignmentPropertyMatrix
+    from gbrs_amd.em import EMfactory
+    R, L, H, indptr, indices, count, eff_len, groups, gtmask = em_case_inputs(g)
+    apm = AlignmentPropertyMatrix(shape=(L, H, R), indptr=indptr, indices=indices, count=count,
+                                  haplotype_names=[chr(65 + h) for h in range(H)],
+                                  locus_names=[f"T{l:07d}" for l in range(L)])
+    apm.groups = groups
+    apm.gname = np.array([f"G{i:07d}" for i in range(len(groups))])
+    apm.num_groups = len(groups)
+    if gtmask is not None:
+        apm.mask_haplotype_loci(gtmask)
+    em = EMfactory(apm, merge_identical_rows=merge)
+    em.target_lengths = eff_len
+    return em
+
+
+def close(a, b, rtol=RTOL):
+    np.testing.assert_allclose(a, b, rtol=rtol, atol=1e-300)
+
+
+@pytest.mark.parametrize("merge", [False, True], ids=["rows", "merged"])
+@pytest.mark.parametrize("path", golden_files("em"), ids=lambda p: p.split("/")[-1][:-4])
+def test_em_matches_reference_golden(path, merge):
+    g = load_golden(path)
+    pc = float(g["pseudocount"])
+    em = make_factory(g, merge)
+    em.prepare(pseudocount=pc)
+    close(em.allelic_expression, g["theta0"])
+    # fixed iteration counts: tol=0 never stops early
+    done = 0
+    for k in (1, 2, 5):
+        if f"theta_iter{k}" not in g or k > int(g["num_iters"]):
+            continue
+        for _ in range(k - done):
+            em.update_allelic_expression(model=4)
+        done = k
+        close(em.allelic_expression, g[f"theta_iter{k}"])
+    # full run with the reference's stopping rule: identical iteration count and err sequence
+    em.prepare(pseudocount=pc)
+    em.run(model=4, tol=float(g["tol"]), max_iters=int(g["max_iters"]), verbose=False)
+    assert em.num_iters == int(g["num_iters"])
+    np.testing.assert_allclose(em.err_history, g["err_history"], rtol=1e-7)
+    close(em.allelic_expression, g["theta_final"])
+    close(em.expected_read_counts(), g["expected_counts"])
+    close(em.get_allelic_expression(at_group_level=True), g["gene_theta"])
+    close(em._group_sums(1), g["gene_counts"])
+    em.close()
+
+
+def test_em_c1_shape_vs_oracle():
+    """BASELINE config 1 (100k reads / 2 haplotypes / 5k isoforms) against the oracle."""
+    from gbrs_amd import synth
+    from gbrs_amd.alignment import AlignmentPropertyMatrix
+    from gbrs_amd.em import EMfactory
+    from oracle.em_oracle import EMOracle
+    inc = synth.make_em_problem(R=100_000, H=2, L=5_000, seed=synth.SEED_BASE_EM)
+    eff = inc.effective_length(100)
+    o = EMOracle(inc.num_rows, inc.num_loci, inc.num_haps, inc.indptr, inc.indices, None)
+    o.prepare(0.0, eff)
+    n = o.run(tol=1e-4, max_iters=999)
+    apm = AlignmentPropertyMatrix(shape=(inc.num_loci, inc.num_haps, inc.num_rows), indptr=inc.indptr,
+                                  indices=inc.indices, haplotype_names=inc.hap_names,
+                                  locus_names=inc.locus_names)
+    for merge in (False, True):
+        em = EMfactory(apm, merge_identical_rows=merge)
+        em.target_lengths = eff
+        em.prepare(0.0)
+        em.run(model=4, tol=1e-4, max_iters=999, verbose=False)
+        assert em.num_iters == n
+        close(em.allelic_expression, o.theta)
+        close(em.expected_read_counts(), o.expected_read_counts())
+        em.close()
+
+
+def test_em_properties_h8():
+    """Size-independent properties on a DO-shaped (H=8) problem: conservation of read mass,
+    row-permutation invariance, and EC-compression invariance (duplicated rows == count)."""
+    from gbrs_amd import synth
+    from gbrs_amd.alignment import AlignmentPropertyMatrix
+    from gbrs_amd.em import EMfactory
+    inc = synth.make_em_problem(R=200_000, H=8, L=3_000, seed=5)
+    eff = inc.effective_length(100)
+
+    def solve(inc_, iters=6):
+        apm = AlignmentPropertyMatrix(shape=(inc_.num_loci, inc_.num_haps, inc_.num_rows),
+                                      indptr=inc_.indptr, indices=inc_.indices, count=inc_.count)
+        em = EMfactory(apm)
+        em.target_lengths = eff
+        em.prepare(0.0)
+        em.run(model=4, tol=0.0, max_iters=iters, verbose=False)
+        th, cnt = em.allelic_expression.copy(), em.expected_read_counts()
+        em.close()
+        return th, cnt
+
+    th, cnt = solve(inc)
+    assert abs(cnt.sum() - inc.num_rows) < 1e-6 * inc.num_rows
+    assert abs((th * eff).sum() - inc.num_rows) < 1e-6 * inc.num_rows
+    # permute the rows
+    rng = np.random.default_rng(0)
+    perm = rng.permutation(inc.num_rows).astype(np.uint32)
+    import dataclasses
+    ind2 = []
+    for h in range(inc.num_haps):
+        new = perm[inc.indices[h]]
+        # keep rows ascending inside each column as a canonical CSC would
+        ptr = inc.indptr[h].astype(np.int64)
+        col = np.repeat(np.arange(inc.num_loci), np.diff(ptr))
+        order = np.lexsort((new, col))
+        ind2.append(new[order])
+    th2, _ = solve(dataclasses.replace(inc, indices=ind2))
+    close(th2, th, rtol=1e-9)
+    # EC compression
+    ec = synth.compress_rows(dataclasses.replace(inc, num_rows=20_000,
+                                                 indptr=[np.searchsorted(
+                                                     np.repeat(np.arange(inc.num_loci), np.diff(inc.indptr[h].astype(np.int64)))[inc.indices[h] < 20_000],
+                                                     np.arange(inc.num_loci + 1)).astype(np.uint32) for h in range(inc.num_haps)],
+                                                 indices=[inc.indices[h][inc.indices[h] < 20_000] for h in range(inc.num_haps)]))
+    sub = dataclasses.replace(inc, num_rows=20_000,
+                              indptr=[np.searchsorted(
+                                  np.repeat(np.arange(inc.num_loci), np.diff(inc.indptr[h].astype(np.int64)))[inc.indices[h] < 20_000],
+                                  np.arange(inc.num_loci + 1)).astype(np.uint32) for h in range(inc.num_haps)],
+                              indices=[inc.indices[h][inc.indices[h] < 20_000] for h in range(inc.num_haps)])
+    th_sub, _ = solve(sub)
+    th_ec, _ = solve(ec)
+    assert ec.num_rows < sub.num_rows
+    close(th_ec, th_sub, rtol=1e-9)
+
+
+def test_em_errors():
+    from gbrs_amd.alignment import AlignmentPropertyMatrix
+    from gbrs_amd.em import EMfactory
+    apm = AlignmentPropertyMatrix(shape=(3, 2, 4),
+                                  indptr=[np.array([0, 2, 3, 3], dtype=np.uint32), np.array([0, 1, 1, 2], dtype=np.uint32)],
+                                  indices=[np.array([0, 1, 2], dtype=np.uint32), np.array([0, 3], dtype=np.uint32)])
+    em = EMfactory(apm)
+    with pytest.raises(RuntimeError):
+        em.run(model=4)                      # not prepared
+    em.prepare()
+    with pytest.raises(RuntimeError, match="should be 1, 2, 3, or 4"):
+        em.run(model=7, verbose=False)
+    with pytest.raises(RuntimeError, match="not implemented"):
+        em.run(model=2, verbose=False)
+    em.run(model=4, tol=0.0, max_iters=3, verbose=False)
+    assert em.num_iters == 3
+    # theta forced to zero everywhere -> the reference raises FloatingPointError (np.seterr raise)
+    em.allelic_expression = np.zeros((2, 3))
+    with pytest.raises(FloatingPointError):
+        em.run(model=4, tol=0.0, max_iters=2, verbose=False)
+    em.close()

@@ -1,0 +1,128 @@
+"""HIP HMM path vs the reference goldens (needs an MI355X)."""
+import numpy as np
+import pytest
+
+from conftest import golden_files, hmm_case_inputs, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def build(c):
+    from gbrs_amd.hmm import DiplotypeHMM
+    chroms = c["chroms"]
+    return DiplotypeHMM(c["H"], chroms, [len(c["genes"][ch]) for ch in chroms], [c["tprob"][ch] for ch in chroms])
+
+
+@pytest.mark.parametrize("path", golden_files("hmm"), ids=lambda p: p.split("/")[-1][:-4])
+def test_hmm_matches_reference_golden(path):
+    g = load_golden(path)
+    c = hmm_case_inputs(g)
+    chroms = c["chroms"]
+    hmm = build(c)
+    hmm.set_expression([c["expr"][ch] for ch in chroms], [c["avecs"][ch] for ch in chroms],
+                       [c["has_avec"][ch] for ch in chroms], float(g["expr_threshold"]), float(g["sigma"]))
+    hmm.run()
+    want = ("gamma", "states", "calls", "alpha", "beta", "delta", "scaler", "eprob")
+    for ci, ch in enumerate(chroms):
+        r = hmm.get(ci, want=want)
+        # genotype calls and the ordered Viterbi path: bit-exact
+        np.testing.assert_array_equal(r["states"], g[f"states_{ch}"])
+        np.testing.assert_array_equal(r["calls"], g[f"calls_{ch}"])
+        # log-domain quantities: absolute tolerance on the log value (== relative on the probability)
+        np.testing.assert_allclose(r["eprob"], g[f"eprob_{ch}"], rtol=1e-10, atol=1e-10)
+        np.testing.assert_allclose(r["alpha"], g[f"alpha_{ch}"], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(r["scaler"], g[f"scaler_{ch}"], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(r["beta"], g[f"beta_{ch}"], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(r["delta"], g[f"delta_{ch}"], rtol=1e-9, atol=1e-9)
+        # posteriors: north-star 1e-4 relative; held to 1e-8
+        np.testing.assert_allclose(r["gamma"], g[f"gamma_{ch}"], rtol=1e-8, atol=1e-300)
+        np.testing.assert_allclose(r["gamma"].sum(axis=0), 1.0, rtol=1e-12)
+    hmm.close()
+
+
+@pytest.mark.parametrize("path", golden_files("hmm")[:2], ids=lambda p: p.split("/")[-1][:-4])
+def test_hmm_with_host_emissions_and_sample_batch(path):
+    """set_eprob path with the reference's own emissions, 3 identical samples in one launch."""
+    g = load_golden(path)
+    c = hmm_case_inputs(g)
+    chroms = c["chroms"]
+    hmm = build(c)
+    hmm.set_eprob([np.repeat(g[f"eprob_{ch}"][None], 3, axis=0) for ch in chroms])
+    hmm.run()
+    for s in range(3):
+        for ci, ch in enumerate(chroms):
+            r = hmm.get(ci, sample=s)
+            np.testing.assert_array_equal(r["states"], g[f"states_{ch}"])
+            np.testing.assert_array_equal(r["calls"], g[f"calls_{ch}"])
+            np.testing.assert_allclose(r["gamma"], g[f"gamma_{ch}"], rtol=1e-8, atol=1e-300)
+    hmm.close()
+
+
+def test_reconstruct_files(tmp_path, monkeypatch):
+    """End-to-end file interface of `gbrs reconstruct` against the golden genotypes.tsv."""
+    from gbrs_amd import hmm as H
+    from gbrs_amd.synth import diplotype_names
+    path = golden_files("hmm")[0]
+    g = load_golden(path)
+    c = hmm_case_inputs(g)
+    chroms = c["chroms"]
+    hn = [chr(65 + h) for h in range(c["H"])]
+    (tmp_path / "ref.fa.fai").write_text("".join(f"{ch}\t1000\t0\t60\t61\n" for ch in chroms) + "MT\t16299\t0\t60\t61\n")
+    monkeypatch.setenv("GBRS_DATA", str(tmp_path))
+    with open(tmp_path / "genes.tpm", "w") as fh:
+        fh.write("locus\t" + "\t".join(hn) + "\ttotal\n")
+        for ch in chroms:
+            for gid, v in zip(c["genes"][ch], c["expr"][ch]):
+                fh.write(str(gid) + "\t" + "\t".join(repr(float(x)) for x in v) + "\t" + repr(float(v.sum())) + "\n")
+    np.savez(tmp_path / "tprob.npz", **{ch: c["tprob"][ch] for ch in chroms})
+    av = {}
+    gp = {}
+    for ch in chroms:
+        for gid, has, a in zip(c["genes"][ch], c["has_avec"][ch], c["avecs"][ch]):
+            if has:
+                av[str(gid)] = a
+        arr = np.zeros(len(c["genes"][ch]), dtype=[("f0", "U24"), ("f1", "i8")])
+        arr["f0"] = c["genes"][ch]
+        gp[ch] = arr
+    np.savez(tmp_path / "avecs.npz", **av)
+    np.savez(tmp_path / "gpos.npz", **gp)
+    out = str(tmp_path / "out")
+    H.reconstruct(str(tmp_path / "genes.tpm"), str(tmp_path / "tprob.npz"), str(tmp_path / "avecs.npz"),
+                  str(tmp_path / "gpos.npz"), 1.5, 0.12, out)
+    assert open(out + ".genotypes.tsv").read() == str(g["tsv_text"])
+    gam = np.load(out + ".genoprobs.npz")
+    st = np.load(out + ".genotypes.npz")
+    names = diplotype_names(hn)
+    for ch in chroms:
+        np.testing.assert_allclose(gam[ch], g[f"gamma_{ch}"], rtol=1e-8, atol=1e-300)
+        assert list(st[ch]) == [names[s] for s in g[f"states_{ch}"]]
+
+
+def test_hmm_full_size_properties():
+    """DO-sized synthetic genome (20 chromosomes, 40k genes): posterior columns sum to one,
+    calls equal the oracle's on a sampled chromosome."""
+    from gbrs_amd import synth
+    from gbrs_amd.hmm import DiplotypeHMM
+    from oracle import hmm_oracle
+    prob = synth.make_hmm_problem(H=8)
+    chroms = prob.chroms
+    hmm = DiplotypeHMM(8, chroms, [len(prob.gene_ids[c]) for c in chroms], [prob.tprob[c] for c in chroms])
+    ex, av, ha = [], [], []
+    for c in chroms:
+        ids = prob.gene_ids[c]
+        ex.append(np.array([prob.expr[g] for g in ids]))
+        ha.append(np.array([g in prob.avecs for g in ids], dtype=np.uint8))
+        av.append(np.array([prob.avecs.get(g, np.zeros((8, 8))) for g in ids]))
+    hmm.set_expression(ex, av, ha, 1.5, 0.12)
+    hmm.run()
+    for ci, c in enumerate(chroms):
+        r = hmm.get(ci)
+        assert np.isfinite(r["gamma"]).all()
+        np.testing.assert_allclose(r["gamma"].sum(axis=0), 1.0, rtol=1e-12)
+        assert (r["calls"] >= 0).all()
+    c = chroms[-1]
+    res = hmm_oracle.reconstruct_arrays(prob.hap_names, [c], prob.gene_ids, prob.tprob, prob.expr, prob.avecs)
+    r = hmm.get(len(chroms) - 1)
+    np.testing.assert_array_equal(r["calls"], res[c]["calls"])
+    np.testing.assert_allclose(r["gamma"], res[c]["gamma"], rtol=1e-7, atol=1e-300)
+    hmm.close()
