@@ -33,6 +33,7 @@ GBRS_ERR_STATE = -6
 
 GBRS_EM_DEFAULT = 0
 GBRS_EM_MERGE_IDENTICAL_ROWS = 1
+GBRS_EM_LAYOUT_CSC = 2
 
 
 class EmInfo(C.Structure):

@@ -8,6 +8,7 @@
 // the update is theta'[h,l] = theta[h,l] * A[h,l] / eff_len[h,l], and the expected read counts
 // of that E-step are theta[h,l] * A[h,l].  Everything below computes den and A.
 #include "common.h"
+#include "em_layout.h"
 
 #include <algorithm>
 #include <cmath>
@@ -218,33 +219,6 @@ __global__ void group_sum_kernel(uint32_t H, int64_t G, const int64_t *__restric
 // the tiled layout.
 // ------------------------------------------------------------------------------------------
 
-__device__ __forceinline__ uint32_t find_column(const uint64_t *__restrict__ col_ptr, uint32_t lo,
-                                                uint32_t hi, uint64_t k) {
-    // largest c in [lo, hi] with col_ptr[c] <= k   (col_ptr non-decreasing, col_ptr[lo] <= k)
-    while (lo < hi) {
-        const uint32_t mid = lo + ((hi - lo + 1) >> 1);
-        if (col_ptr[mid] <= k) lo = mid; else hi = mid - 1;
-    }
-    return lo;
-}
-
-__device__ __forceinline__ uint32_t entry_column(const uint64_t *__restrict__ col_ptr, uint32_t ncols,
-                                                 uint64_t k, uint64_t n) {
-    // the wave's entries are consecutive: search the wave's first and last entry, then only
-    // inside that window (usually a single column)
-    const uint64_t kbase = k - (threadIdx.x & 63);
-    const uint64_t klast = min(kbase + 63, n - 1);
-    uint32_t c_first = 0, c_last = 0;
-    if ((threadIdx.x & 63) == 0) {
-        c_first = find_column(col_ptr, 0, ncols - 1, kbase);
-        c_last = find_column(col_ptr, c_first, ncols - 1, klast);
-    }
-    c_first = __shfl(c_first, 0, WAVE);
-    c_last = __shfl(c_last, 0, WAVE);
-    if (c_first == c_last) return c_first;
-    return find_column(col_ptr, c_first, c_last, k);
-}
-
 template <bool ONES>
 __global__ void __launch_bounds__(256)
 csc_den_kernel(uint64_t n, uint32_t ncols, uint32_t L, uint32_t H,
@@ -303,6 +277,8 @@ csc_rowstat_kernel(uint64_t n, uint32_t ncols, uint32_t L, const uint64_t *__res
     if (k < n) atomicAdd(&nnz_row[ent_row[k]], 1u);
 }
 
+#include "em_tiles.inc"
+
 }  // namespace gbrs
 
 using namespace gbrs;
@@ -319,6 +295,9 @@ struct gbrs_em {
     uint32_t L = 0, H = 0;
     bool has_count = false, has_len = false, prepared = false;
     uint32_t flags = 0;
+
+    int layout = 0;               // 0 = csc-direct, 1 = packed row tiles
+    TileLayout tl;
 
     // layout 0
     DevBuf<uint32_t> ent_row;
@@ -350,9 +329,57 @@ int em_check_float(gbrs_em *em, EmScalars &host) {
     return GBRS_OK;
 }
 
+// E-step over the tiled layout: tiles -> partials, long rows -> acc_extra, gather -> acc.
+template <int HT, bool ONES>
+int em_estep_tiles_h(gbrs_em *em) {
+    const TileLayout &tl = em->tl;
+    if (tl.n_tiles) {
+        const dim3 grid((unsigned)tl.n_tiles), block(TILE_THREADS);
+        if (tl.weighted)
+            hipLaunchKernelGGL((tile_estep_kernel<HT, true, ONES>), grid, block, 0, em->stream, em->H, tl.tiles.p,
+                               tl.words.p, tl.dict.p, tl.batch_row.p, tl.row_weight.p, em->theta.p, tl.partials.p,
+                               em->scalars.p);
+        else
+            hipLaunchKernelGGL((tile_estep_kernel<HT, false, ONES>), grid, block, 0, em->stream, em->H, tl.tiles.p,
+                               tl.words.p, tl.dict.p, (const uint32_t *)nullptr, (const double *)nullptr, em->theta.p,
+                               tl.partials.p, em->scalars.p);
+    }
+    return GBRS_OK;
+}
+
+template <bool ONES>
+int em_estep_tiles(gbrs_em *em) {
+    TileLayout &tl = em->tl;
+    switch (em->H) {
+        case 1: GBRS_TRY((em_estep_tiles_h<1, ONES>(em))); break;
+        case 2: GBRS_TRY((em_estep_tiles_h<2, ONES>(em))); break;
+        case 4: GBRS_TRY((em_estep_tiles_h<4, ONES>(em))); break;
+        case 8: GBRS_TRY((em_estep_tiles_h<8, ONES>(em))); break;
+        case 16: GBRS_TRY((em_estep_tiles_h<16, ONES>(em))); break;
+        default: GBRS_TRY((em_estep_tiles_h<0, ONES>(em))); break;
+    }
+    if (tl.n_long) {
+        GBRS_HIP_CHECK(hipMemsetAsync(tl.acc_extra.p, 0, tl.acc_extra.bytes(), em->stream));
+        hipLaunchKernelGGL(long_rows_estep_kernel<ONES>, dim3((unsigned)((tl.n_long + 3) / 4)), dim3(256), 0, em->stream,
+                           tl.n_long, em->H, tl.long_ptr.p, tl.long_loc.p, tl.long_mask.p, tl.long_weight.p,
+                           em->theta.p, tl.acc_extra.p, em->scalars.p);
+    }
+    uint32_t HP = 1;
+    while (HP < em->H) HP <<= 1;
+    const uint64_t elems = (uint64_t)em->L * em->H;
+    const unsigned light = (unsigned)((elems + 255) / 256);
+    const unsigned heavy = (unsigned)((tl.n_heavy + 3) / 4);
+    hipLaunchKernelGGL(gather_kernel, dim3(light + heavy), dim3(256), 0, em->stream, em->L, em->H, HP, light,
+                       (uint32_t)tl.n_heavy, tl.slot_ptr.p, tl.slot_list.p, tl.heavy_loci.p, tl.partials.p,
+                       tl.n_long ? tl.acc_extra.p : (const double *)nullptr, em->acc.p, em->scalars.p, ONES ? 0 : 1);
+    GBRS_HIP_CHECK(hipGetLastError());
+    return GBRS_OK;
+}
+
 // E-step: fills em->acc with A (sum of count/den per column).  ONES: theta treated as 1.
 template <bool ONES>
 int em_estep(gbrs_em *em) {
+    if (em->layout == 1) return em_estep_tiles<ONES>(em);
     const uint64_t n = em->N;
     const uint32_t ncols = em->H * em->L;
     GBRS_HIP_CHECK(hipMemsetAsync(em->acc.p, 0, em->acc.bytes(), em->stream));
@@ -531,6 +558,15 @@ int em_create_impl(uint64_t R, uint32_t L, uint32_t H, const uint32_t *const *in
         }
     }
     GBRS_HIP_CHECK(hipDeviceSynchronize());
+    if (!(flags & GBRS_EM_LAYOUT_CSC) && H <= 16 && n < 0xFFFFFFFFull) {
+        GBRS_TRY(build_tile_layout(em->tl, R, L, H, n, em->ent_row.p, em->col_ptr.p,
+                                   count ? em->count.p : nullptr, (flags & GBRS_EM_MERGE_IDENTICAL_ROWS) != 0,
+                                   em->stream));
+        em->layout = 1;
+        // the CSC copy and the per-row denominators are only needed by layout 0
+        em->ent_row.release();
+        em->den.release();
+    }
     guard.p = nullptr;
     *out = em;
     return GBRS_OK;
@@ -738,11 +774,21 @@ int gbrs_em_info(gbrs_em_t *em, gbrs_em_info_t *info) {
                               16 * HL + (em->has_len ? 8 * HL : 0);
     // layout 0: two passes over the row ids + den zero/atomic/read + theta/acc traffic
     info->bytes_per_iter = 8 * em->N + 8 * em->R * 3 + 8 * HL * 4;
+    if (em->layout == 1) {
+        const TileLayout &tl = em->tl;
+        info->num_device_rows = tl.n_rows + tl.n_long;
+        info->num_device_words = tl.n_batches * 64;
+        // E-step: word stream, tile headers, dictionary, theta gather + partial store per slot,
+        // [row weights]; gather: slot index + partials read back + acc store; M-step etc.: 5 H*L vectors
+        info->bytes_per_iter = 4 * tl.n_batches * 64 + 16 * tl.n_tiles + 4 * tl.n_slots +
+                               8 * tl.n_slots * em->H * 3 + 4 * tl.n_slots + 4 * ((uint64_t)em->L + 1) +
+                               (tl.weighted ? 4 * tl.n_batches + 8 * tl.n_rows : 0) + 8 * HL * 6;
+    }
     info->last_estep_ms = em->last_estep_ms;
     info->last_step_ms = em->last_step_ms;
     info->num_loci = em->L;
     info->num_haps = em->H;
-    info->layout = 0;
+    info->layout = em->layout;
     return GBRS_OK;
 }
 

@@ -1,0 +1,94 @@
+// Device layout of the alignment incidence tensor for the tiled E-step ("packed row tiles").
+// Built once per handle by build_tile_layout() (em_layout.hip) from the reference's CSC arrays.
+//
+//   word   = one (row, locus) pair of a read: [ local locus index | last-word-of-row | hap mask ]
+//            bits [0,H) mask, bit H last flag, bits [H+1,32) index into the tile's dictionary.
+//   batch  = 64 consecutive words = what one wavefront takes per step; rows never straddle a
+//            batch (zero words pad the tail), so a batch is self-contained.
+//   tile   = a run of batches processed by one workgroup with one locus dictionary of at most
+//            D_MAX loci, so that theta and the partial sums of the tile live in LDS.
+//   slot   = one (tile, dictionary entry): the tile's partial sum for that locus, H doubles in
+//            `partials`; `slot_ptr/slot_list` is the inverted index locus -> slots the gather
+//            kernel walks in fixed order (no float atomics in global memory, bit-reproducible
+//            across launches up to LDS atomic order inside a tile).
+#pragma once
+#include "common.h"
+
+namespace gbrs {
+
+constexpr int TILE_THREADS = 512;              // 8 waves per workgroup
+constexpr int TILE_WAVES = TILE_THREADS / 64;
+constexpr int TILE_WORDS = 8192 - 64;          // unpadded words per tile (sort capacity 8192)
+constexpr int MAX_ROW_WORDS = 32;              // rows with more distinct loci go to the long-row path
+constexpr int LDS_THETA_DOUBLES = 4096;        // theta of the tile: D_MAX * H doubles (32 KiB)
+constexpr int LDS_ACC_DOUBLES = 4096 + 64;     // privatised partial sums (32.5 KiB)
+constexpr int HEAVY_SLOTS = 32;                // loci with more slots get a whole wave in the gather
+
+struct TileHdr {
+    uint32_t batch_base;   // first batch of the tile in `words`
+    uint32_t n_batches;
+    uint32_t dict_base;    // first slot / dictionary entry of the tile
+    uint32_t dict_count;   // D
+};
+
+struct TileLayout {
+    // sizes
+    uint64_t n_pairs = 0;        // (row, locus) pairs = unpadded words
+    uint64_t n_rows_in = 0;      // rows with at least one alignment
+    uint64_t n_rows = 0;         // rows in the layout (after optional merging), short rows only
+    uint64_t n_long = 0;         // rows with more than MAX_ROW_WORDS loci
+    uint64_t n_tiles = 0, n_batches = 0, n_slots = 0, n_heavy = 0;
+    uint32_t d_max = 0;          // dictionary capacity used when cutting tiles
+    bool weighted = false;       // per-row weights present (count given or rows merged)
+
+    DevBuf<uint32_t> words;          // n_batches * 64
+    DevBuf<TileHdr> tiles;           // n_tiles
+    DevBuf<uint32_t> dict;           // n_slots: global locus of each slot
+    DevBuf<uint32_t> batch_row;      // n_batches: ordinal of the first row of each batch (weighted)
+    DevBuf<double> row_weight;       // n_rows (weighted)
+    DevBuf<uint32_t> slot_ptr;       // L + 1
+    DevBuf<uint32_t> slot_list;      // n_slots, grouped by locus, ascending slot inside a locus
+    DevBuf<uint32_t> heavy_loci;     // loci with more than HEAVY_SLOTS slots
+    DevBuf<double> partials;         // n_slots * H
+    // long rows (kept in pair form)
+    DevBuf<uint64_t> long_ptr;       // n_long + 1 offsets into long_loc / long_mask
+    DevBuf<uint32_t> long_loc, long_mask;
+    DevBuf<double> long_weight;      // n_long
+    DevBuf<double> acc_extra;        // L*H, global-atomic target of the long-row kernel
+};
+
+// ent_row / col_ptr: the concatenated CSC arrays already on the device (column c = h*L + l).
+// count: device pointer or nullptr.  Returns GBRS_OK or a status with the message set.
+int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L, uint32_t H, uint64_t N,
+                      const uint32_t *ent_row, const uint64_t *col_ptr, const double *count,
+                      bool merge_identical_rows, hipStream_t stream);
+
+// shared by em.hip and em_layout.hip -----------------------------------------------------------
+__device__ __forceinline__ uint32_t find_column(const uint64_t *__restrict__ col_ptr, uint32_t lo,
+                                                uint32_t hi, uint64_t k) {
+    // largest c in [lo, hi] with col_ptr[c] <= k   (col_ptr non-decreasing, col_ptr[lo] <= k)
+    while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo + 1) >> 1);
+        if (col_ptr[mid] <= k) lo = mid; else hi = mid - 1;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ uint32_t entry_column(const uint64_t *__restrict__ col_ptr, uint32_t ncols,
+                                                 uint64_t k, uint64_t n) {
+    // the wave's entries are consecutive: search the wave's first and last entry, then only
+    // inside that window (usually a single column)
+    const uint64_t kbase = k - (threadIdx.x & 63);
+    const uint64_t klast = min(kbase + 63, n - 1);
+    uint32_t c_first = 0, c_last = 0;
+    if ((threadIdx.x & 63) == 0) {
+        c_first = find_column(col_ptr, 0, ncols - 1, kbase);
+        c_last = find_column(col_ptr, c_first, ncols - 1, klast);
+    }
+    c_first = __shfl(c_first, 0, WAVE);
+    c_last = __shfl(c_last, 0, WAVE);
+    if (c_first == c_last) return c_first;
+    return find_column(col_ptr, c_first, c_last, k);
+}
+
+}  // namespace gbrs

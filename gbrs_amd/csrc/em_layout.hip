@@ -1,0 +1,632 @@
+// Builds the packed-row-tile device layout (em_layout.h) from the reference's CSC arrays, entirely
+// on the device.  rocPRIM provides the radix sorts and scans (setup plumbing, run once per
+// handle); every transformation kernel is written here.
+//
+// Pipeline
+//   entries (h, l, r)  --sort by (r, l, h)-->  (row, locus) pairs with a haplotype mask
+//   rows  --sort by (first locus, hash of locus list, hash of masks)-->  similar rows adjacent
+//   [optional] identical adjacent rows merged into one weighted row (what `gbrs compress` does)
+//   tiles cut where the running count of distinct locus lists or of words crosses a chunk border
+//   per tile: locus dictionary (LDS bitonic sort + unique), rows padded so none straddles a
+//   64-word batch, words emitted with dictionary-local indices
+//   inverted index locus -> slots for the gather kernel
+#include "em_layout.h"
+
+#include <rocprim/rocprim.hpp>
+
+#include <algorithm>
+
+namespace gbrs {
+namespace {
+
+// ---- rocPRIM wrappers with one reusable temporary buffer ------------------------------------
+struct Scratch {
+    DevBuf<unsigned char> buf;
+    int reserve(size_t bytes) {
+        if (bytes <= buf.n) return GBRS_OK;
+        return buf.alloc(bytes + (bytes >> 2) + 256);
+    }
+};
+
+#define GBRS_PRIM(expr) GBRS_HIP_CHECK(expr)
+
+template <typename T>
+int exclusive_scan(Scratch &sc, const T *in, T *out, size_t n, hipStream_t s) {
+    if (n == 0) return GBRS_OK;
+    size_t bytes = 0;
+    GBRS_PRIM(rocprim::exclusive_scan(nullptr, bytes, in, out, T(0), n, rocprim::plus<T>(), s));
+    GBRS_TRY(sc.reserve(bytes));
+    GBRS_PRIM(rocprim::exclusive_scan(sc.buf.p, bytes, in, out, T(0), n, rocprim::plus<T>(), s));
+    return GBRS_OK;
+}
+
+template <typename T>
+int inclusive_scan(Scratch &sc, const T *in, T *out, size_t n, hipStream_t s) {
+    if (n == 0) return GBRS_OK;
+    size_t bytes = 0;
+    GBRS_PRIM(rocprim::inclusive_scan(nullptr, bytes, in, out, n, rocprim::plus<T>(), s));
+    GBRS_TRY(sc.reserve(bytes));
+    GBRS_PRIM(rocprim::inclusive_scan(sc.buf.p, bytes, in, out, n, rocprim::plus<T>(), s));
+    return GBRS_OK;
+}
+
+int sort_keys64(Scratch &sc, const uint64_t *in, uint64_t *out, size_t n, unsigned end_bit, hipStream_t s) {
+    if (n == 0) return GBRS_OK;
+    size_t bytes = 0;
+    GBRS_PRIM(rocprim::radix_sort_keys(nullptr, bytes, in, out, n, 0u, end_bit, s));
+    GBRS_TRY(sc.reserve(bytes));
+    GBRS_PRIM(rocprim::radix_sort_keys(sc.buf.p, bytes, in, out, n, 0u, end_bit, s));
+    return GBRS_OK;
+}
+
+template <typename K>
+int sort_pairs(Scratch &sc, const K *kin, K *kout, const uint32_t *vin, uint32_t *vout, size_t n,
+               unsigned end_bit, hipStream_t s) {
+    if (n == 0) return GBRS_OK;
+    size_t bytes = 0;
+    GBRS_PRIM(rocprim::radix_sort_pairs(nullptr, bytes, kin, kout, vin, vout, n, 0u, end_bit, s));
+    GBRS_TRY(sc.reserve(bytes));
+    GBRS_PRIM(rocprim::radix_sort_pairs(sc.buf.p, bytes, kin, kout, vin, vout, n, 0u, end_bit, s));
+    return GBRS_OK;
+}
+
+template <typename T>
+int fetch_last_plus(const T *scan_out, const T *in, size_t n, T &total, hipStream_t s) {
+    // total of an exclusive scan = last output + last input
+    T a = 0, b = 0;
+    if (n) {
+        GBRS_HIP_CHECK(hipMemcpyAsync(&a, scan_out + n - 1, sizeof(T), hipMemcpyDeviceToHost, s));
+        GBRS_HIP_CHECK(hipMemcpyAsync(&b, in + n - 1, sizeof(T), hipMemcpyDeviceToHost, s));
+        GBRS_HIP_CHECK(hipStreamSynchronize(s));
+    }
+    total = a + b;
+    return GBRS_OK;
+}
+
+unsigned bits_for(uint64_t max_value) {
+    unsigned b = 1;
+    while (b < 64 && (max_value >> b)) ++b;
+    return b;
+}
+
+inline unsigned grid_for(uint64_t n, unsigned block = 256) { return (unsigned)((n + block - 1) / block); }
+
+// ---- kernels --------------------------------------------------------------------------------
+
+struct BuildFlags {
+    unsigned int duplicate;      // the same (row, locus, haplotype) stored twice
+    unsigned int dict_overflow;  // a tile dictionary exceeded its capacity (internal error)
+    unsigned int bad_row;        // row id >= R
+    unsigned int n_long;         // rows with more than MAX_ROW_WORDS loci
+};
+
+__global__ void __launch_bounds__(256)
+make_keys_kernel(uint64_t n, uint32_t ncols, uint32_t L, uint64_t R, const uint64_t *__restrict__ col_ptr,
+                 const uint32_t *__restrict__ ent_row, uint64_t *__restrict__ keys, BuildFlags *flags) {
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k - (threadIdx.x & 63) >= n) return;
+    const bool live = k < n;
+    const uint32_t c = entry_column(col_ptr, ncols, live ? k : n - 1, n);
+    if (!live) return;
+    const uint32_t h = c / L, l = c - h * L;
+    const uint32_t r = ent_row[k];
+    if (r >= R) flags->bad_row = 1;
+    keys[k] = ((uint64_t)r << 32) | ((uint64_t)l << 5) | h;
+}
+
+__global__ void pair_flag_kernel(uint64_t n, const uint64_t *__restrict__ keys, uint32_t *__restrict__ flag,
+                                 BuildFlags *flags) {
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    uint32_t f = 1;
+    if (k > 0) {
+        const uint64_t a = keys[k - 1], b = keys[k];
+        if (a == b) flags->duplicate = 1;
+        f = (a >> 5) != (b >> 5);
+    }
+    flag[k] = f;
+}
+
+__global__ void emit_pairs_kernel(uint64_t n, const uint64_t *__restrict__ keys, const uint32_t *__restrict__ flag,
+                                  const uint32_t *__restrict__ pidx, uint32_t *__restrict__ prow,
+                                  uint32_t *__restrict__ ploc, uint32_t *__restrict__ pmask) {
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n || !flag[k]) return;
+    const uint64_t key = keys[k];
+    uint32_t mask = 0;
+    for (uint64_t j = k; j < n && (keys[j] >> 5) == (key >> 5); ++j) mask |= 1u << (uint32_t)(keys[j] & 31);
+    const uint32_t p = pidx[k];
+    prow[p] = (uint32_t)(key >> 32);
+    ploc[p] = (uint32_t)((key >> 5) & 0x7FFFFFFu);
+    pmask[p] = mask;
+}
+
+__global__ void row_flag_kernel(uint64_t np, const uint32_t *__restrict__ prow, uint32_t *__restrict__ flag) {
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= np) return;
+    flag[p] = (p == 0) || prow[p] != prow[p - 1];
+}
+
+__global__ void row_start_kernel(uint64_t np, uint64_t nrows, const uint32_t *__restrict__ flag,
+                                 const uint32_t *__restrict__ ridx, const uint32_t *__restrict__ prow,
+                                 uint32_t *__restrict__ rowstart, uint32_t *__restrict__ row_orig) {
+    const uint64_t p = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p == 0) rowstart[nrows] = (uint32_t)np;
+    if (p >= np || !flag[p]) return;
+    rowstart[ridx[p]] = (uint32_t)p;
+    row_orig[ridx[p]] = prow[p];
+}
+
+__device__ __forceinline__ uint32_t mix32(uint32_t h, uint32_t v) {
+    h ^= v + 0x9e3779b9u + (h << 6) + (h >> 2);
+    h *= 0x85ebca6bu;
+    h ^= h >> 13;
+    return h;
+}
+
+__global__ void row_key_kernel(uint64_t nrows, unsigned loc_shift, const uint32_t *__restrict__ rowstart,
+                               const uint32_t *__restrict__ ploc, const uint32_t *__restrict__ pmask,
+                               uint64_t *__restrict__ key, uint32_t *__restrict__ ident, BuildFlags *flags) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrows) return;
+    ident[r] = (uint32_t)r;
+    const uint32_t a = rowstart[r], b = rowstart[r + 1];
+    if (b - a > MAX_ROW_WORDS) {
+        key[r] = ~0ull;
+        atomicAdd(&flags->n_long, 1u);
+        return;
+    }
+    uint32_t hl = 0x811c9dc5u, hm = 0x01000193u;
+    for (uint32_t p = a; p < b; ++p) {
+        hl = mix32(hl, ploc[p]);
+        hm = mix32(hm, pmask[p]);
+    }
+    const uint64_t primary = (ploc[a] >> loc_shift) & 0xFFFFFFu;
+    uint64_t k = (primary << 40) | ((uint64_t)(hl & 0xFFFFFFu) << 16) | (hm & 0xFFFFu);
+    if (k == ~0ull) k -= 1;
+    key[r] = k;
+}
+
+__device__ __forceinline__ bool same_loci(const uint32_t *__restrict__ rowstart, const uint32_t *__restrict__ ploc,
+                                          uint32_t ra, uint32_t rb) {
+    const uint32_t a = rowstart[ra], na = rowstart[ra + 1] - a;
+    const uint32_t b = rowstart[rb], nb = rowstart[rb + 1] - b;
+    if (na != nb) return false;
+    for (uint32_t j = 0; j < na; ++j)
+        if (ploc[a + j] != ploc[b + j]) return false;
+    return true;
+}
+
+// head[i] = 1 when sorted row i starts a new (merged) row
+__global__ void merge_flag_kernel(uint64_t n, int merge, const uint64_t *__restrict__ skey,
+                                  const uint32_t *__restrict__ srow, const uint32_t *__restrict__ rowstart,
+                                  const uint32_t *__restrict__ ploc, const uint32_t *__restrict__ pmask,
+                                  uint32_t *__restrict__ head) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t f = 1;
+    if (merge && i > 0 && skey[i] == skey[i - 1]) {
+        const uint32_t ra = srow[i - 1], rb = srow[i];
+        if (same_loci(rowstart, ploc, ra, rb)) {
+            const uint32_t a = rowstart[ra], b = rowstart[rb], cnt = rowstart[ra + 1] - a;
+            bool eq = true;
+            for (uint32_t j = 0; j < cnt; ++j) eq &= pmask[a + j] == pmask[b + j];
+            if (eq) f = 0;
+        }
+    }
+    head[i] = f;
+}
+
+// per sorted row: merged ordinal m = incl[i] - 1; accumulate weights, record representative
+__global__ void merged_rows_kernel(uint64_t n, const uint32_t *__restrict__ head, const uint32_t *__restrict__ hincl,
+                                   const uint32_t *__restrict__ srow, const uint32_t *__restrict__ row_orig,
+                                   const double *__restrict__ count, uint32_t *__restrict__ hrow,
+                                   double *__restrict__ weight) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t m = hincl[i] - 1;
+    if (head[i]) hrow[m] = srow[i];
+    if (weight) atomicAdd(&weight[m], count ? count[row_orig[srow[i]]] : 1.0);
+}
+
+__global__ void row_len_kernel(uint64_t m_rows, const uint32_t *__restrict__ hrow, const uint32_t *__restrict__ rowstart,
+                               const uint32_t *__restrict__ ploc, uint32_t *__restrict__ npm,
+                               uint32_t *__restrict__ dnew) {
+    const uint64_t m = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= m_rows) return;
+    const uint32_t r = hrow[m];
+    const uint32_t cnt = rowstart[r + 1] - rowstart[r];
+    npm[m] = cnt;
+    const bool newlist = (m == 0) || !same_loci(rowstart, ploc, hrow[m - 1], r);
+    dnew[m] = newlist ? cnt : 0;
+}
+
+__global__ void tile_flag_kernel(uint64_t m_rows, uint32_t tile_words, uint32_t dseg, const uint32_t *__restrict__ npm,
+                                 const uint32_t *__restrict__ wordoff, const uint32_t *__restrict__ dincl,
+                                 uint32_t *__restrict__ tflag) {
+    const uint64_t m = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= m_rows) return;
+    uint32_t f = 1;
+    if (m > 0) {
+        const uint32_t dc = dincl[m] - npm[m], dp = dincl[m - 1] - npm[m - 1];
+        f = (wordoff[m] / tile_words != wordoff[m - 1] / tile_words) || (dc / dseg != dp / dseg);
+    }
+    tflag[m] = f;
+}
+
+__global__ void tile_start_kernel(uint64_t m_rows, uint64_t n_tiles, const uint32_t *__restrict__ tflag,
+                                  const uint32_t *__restrict__ tincl, uint32_t *__restrict__ tile_row) {
+    const uint64_t m = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m == 0) tile_row[n_tiles] = (uint32_t)m_rows;
+    if (m >= m_rows || !tflag[m]) return;
+    tile_row[tincl[m] - 1] = (uint32_t)m;
+}
+
+// one thread per tile: padded offset of every row so that no row straddles a 64-word batch
+__global__ void tile_pad_kernel(uint64_t n_tiles, const uint32_t *__restrict__ tile_row, const uint32_t *__restrict__ npm,
+                                uint32_t *__restrict__ rowpad, uint32_t *__restrict__ nbatch) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tiles) return;
+    uint32_t off = 0;
+    for (uint32_t m = tile_row[t]; m < tile_row[t + 1]; ++m) {
+        const uint32_t cnt = npm[m];
+        if ((off & 63u) + cnt > 64u) off = (off + 63u) & ~63u;
+        rowpad[m] = off;
+        off += cnt;
+    }
+    nbatch[t] = (off + 63u) >> 6;
+}
+
+// one workgroup per tile: sorted unique loci of the tile -> tmpdict[t * dcap ...], dcount[t]
+constexpr int SORT_CAP = 8192;
+__global__ void __launch_bounds__(512)
+tile_dict_kernel(uint32_t dcap, const uint32_t *__restrict__ tile_row, const uint32_t *__restrict__ hrow,
+                 const uint32_t *__restrict__ rowstart, const uint32_t *__restrict__ ploc,
+                 const uint32_t *__restrict__ wordoff, uint32_t *__restrict__ tmpdict,
+                 uint32_t *__restrict__ dcount, BuildFlags *flags) {
+    __shared__ uint32_t a[SORT_CAP];
+    __shared__ uint32_t s_count;
+    const uint32_t t = blockIdx.x;
+    const uint32_t m0 = tile_row[t], m1 = tile_row[t + 1];
+    const uint32_t w0 = wordoff[m0];
+    for (int i = threadIdx.x; i < SORT_CAP; i += blockDim.x) a[i] = 0xFFFFFFFFu;
+    if (threadIdx.x == 0) s_count = 0;
+    __syncthreads();
+    for (uint32_t m = m0 + threadIdx.x; m < m1; m += blockDim.x) {
+        const uint32_t r = hrow[m], p0 = rowstart[r], cnt = rowstart[r + 1] - p0;
+        const uint32_t o = wordoff[m] - w0;
+        for (uint32_t j = 0; j < cnt; ++j)
+            if (o + j < SORT_CAP) a[o + j] = ploc[p0 + j]; else flags->dict_overflow = 1;
+    }
+    __syncthreads();
+    // bitonic sort of SORT_CAP keys in LDS
+    for (int k = 2; k <= SORT_CAP; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = threadIdx.x; i < SORT_CAP; i += blockDim.x) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const uint32_t x = a[i], y = a[ixj];
+                    const bool up = (i & k) == 0;
+                    if ((x > y) == up) { a[i] = y; a[ixj] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+    // unique (order preserved by giving each thread a contiguous chunk)
+    const int per = SORT_CAP / 512;
+    const int lo = threadIdx.x * per;
+    int mine = 0;
+    for (int i = lo; i < lo + per; ++i)
+        mine += (a[i] != 0xFFFFFFFFu) && (i == 0 || a[i] != a[i - 1]);
+    __shared__ uint32_t s_scan[512];
+    s_scan[threadIdx.x] = mine;
+    __syncthreads();
+    for (int off = 1; off < 512; off <<= 1) {
+        uint32_t v = threadIdx.x >= off ? s_scan[threadIdx.x - off] : 0;
+        __syncthreads();
+        s_scan[threadIdx.x] += v;
+        __syncthreads();
+    }
+    uint32_t pos = s_scan[threadIdx.x] - mine;
+    for (int i = lo; i < lo + per; ++i) {
+        if ((a[i] != 0xFFFFFFFFu) && (i == 0 || a[i] != a[i - 1])) {
+            if (pos < dcap) tmpdict[(uint64_t)t * dcap + pos] = a[i]; else flags->dict_overflow = 1;
+            ++pos;
+        }
+    }
+    if (threadIdx.x == 511) dcount[t] = s_scan[511];
+}
+
+__global__ void tile_hdr_kernel(uint64_t n_tiles, uint32_t dcap, const uint32_t *__restrict__ batch_base,
+                                const uint32_t *__restrict__ nbatch, const uint32_t *__restrict__ dict_base,
+                                const uint32_t *__restrict__ dcount, const uint32_t *__restrict__ tmpdict,
+                                TileHdr *__restrict__ hdr, uint32_t *__restrict__ dict) {
+    const uint32_t t = blockIdx.x;
+    if (t >= n_tiles) return;
+    const uint32_t d = dcount[t], db = dict_base[t];
+    if (threadIdx.x == 0) hdr[t] = TileHdr{batch_base[t], nbatch[t], db, d};
+    for (uint32_t j = threadIdx.x; j < d; j += blockDim.x) dict[db + j] = tmpdict[(uint64_t)t * dcap + j];
+}
+
+// one thread per (merged) row: emit its words at the padded position
+__global__ void emit_words_kernel(uint64_t m_rows, uint32_t H, const uint32_t *__restrict__ tincl,
+                                  const TileHdr *__restrict__ hdr, const uint32_t *__restrict__ dict,
+                                  const uint32_t *__restrict__ hrow, const uint32_t *__restrict__ rowstart,
+                                  const uint32_t *__restrict__ ploc, const uint32_t *__restrict__ pmask,
+                                  const uint32_t *__restrict__ rowpad, uint32_t *__restrict__ words,
+                                  uint32_t *__restrict__ batch_row) {
+    const uint64_t m = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= m_rows) return;
+    const TileHdr th = hdr[tincl[m] - 1];
+    const uint32_t r = hrow[m], p0 = rowstart[r], cnt = rowstart[r + 1] - p0;
+    const uint32_t off = rowpad[m];
+    const uint64_t base = (uint64_t)th.batch_base * 64 + off;
+    const uint32_t *d = dict + th.dict_base;
+    for (uint32_t j = 0; j < cnt; ++j) {
+        const uint32_t l = ploc[p0 + j];
+        uint32_t lo = 0, hi = th.dict_count;          // lower_bound; l is present by construction
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (d[mid] < l) lo = mid + 1; else hi = mid;
+        }
+        words[base + j] = pmask[p0 + j] | ((j + 1 == cnt ? 1u : 0u) << H) | (lo << (H + 1));
+    }
+    if (batch_row && (off & 63u) == 0) batch_row[th.batch_base + (off >> 6)] = (uint32_t)m;
+}
+
+__global__ void iota_kernel(uint64_t n, uint32_t *__restrict__ v) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] = (uint32_t)i;
+}
+
+__global__ void slot_ptr_kernel(uint32_t L, uint64_t n_slots, const uint32_t *__restrict__ sorted_loc,
+                                uint32_t *__restrict__ slot_ptr) {
+    const uint32_t l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l > L) return;
+    uint64_t lo = 0, hi = n_slots;                   // first index with sorted_loc >= l
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (sorted_loc[mid] < l) lo = mid + 1; else hi = mid;
+    }
+    slot_ptr[l] = (uint32_t)lo;
+}
+
+__global__ void long_rows_kernel(uint64_t n_long, uint64_t first, const uint32_t *__restrict__ srow,
+                                 const uint32_t *__restrict__ rowstart, const uint32_t *__restrict__ row_orig,
+                                 const double *__restrict__ count, uint64_t *__restrict__ len,
+                                 double *__restrict__ weight) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_long) return;
+    const uint32_t r = srow[first + i];
+    len[i] = rowstart[r + 1] - rowstart[r];
+    weight[i] = count ? count[row_orig[r]] : 1.0;
+}
+
+__global__ void long_copy_kernel(uint64_t n_long, uint64_t first, const uint32_t *__restrict__ srow,
+                                 const uint32_t *__restrict__ rowstart, const uint32_t *__restrict__ ploc,
+                                 const uint32_t *__restrict__ pmask, const uint64_t *__restrict__ long_ptr,
+                                 uint32_t *__restrict__ long_loc, uint32_t *__restrict__ long_mask) {
+    const uint64_t i = blockIdx.x;
+    if (i >= n_long) return;
+    const uint32_t r = srow[first + i], p0 = rowstart[r], cnt = rowstart[r + 1] - p0;
+    const uint64_t o = long_ptr[i];
+    for (uint32_t j = threadIdx.x; j < cnt; j += blockDim.x) {
+        long_loc[o + j] = ploc[p0 + j];
+        long_mask[o + j] = pmask[p0 + j];
+    }
+}
+
+}  // namespace
+
+int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L, uint32_t H, uint64_t N,
+                      const uint32_t *ent_row, const uint64_t *col_ptr, const double *count,
+                      bool merge, hipStream_t s) {
+    if (H > 16) return fail(GBRS_ERR_INVALID, "the tiled layout packs the haplotype mask in 16 bits (H <= 16)");
+    if (N >= 0xFFFFFFFFull || L >= (1u << 27))
+        return fail(GBRS_ERR_INVALID, "the tiled layout needs N < 2^32 entries and L < 2^27 loci per handle");
+    Scratch sc;
+    DevBuf<BuildFlags> d_flags;
+    GBRS_TRY(d_flags.alloc(1));
+    GBRS_HIP_CHECK(hipMemsetAsync(d_flags.p, 0, sizeof(BuildFlags), s));
+    BuildFlags hf{};
+    auto read_flags = [&]() -> int {
+        GBRS_HIP_CHECK(hipMemcpyAsync(&hf, d_flags.p, sizeof(hf), hipMemcpyDeviceToHost, s));
+        GBRS_HIP_CHECK(hipStreamSynchronize(s));
+        return GBRS_OK;
+    };
+    out.d_max = std::min<uint32_t>(1024, LDS_THETA_DOUBLES / H);
+    const uint32_t dseg = out.d_max - MAX_ROW_WORDS;
+    out.weighted = merge || count != nullptr;
+    out.n_pairs = out.n_rows = out.n_rows_in = out.n_long = out.n_tiles = out.n_batches = out.n_slots = 0;
+    GBRS_TRY(out.slot_ptr.alloc((size_t)L + 1));
+    GBRS_HIP_CHECK(hipMemsetAsync(out.slot_ptr.p, 0, out.slot_ptr.bytes(), s));
+    if (N == 0) { GBRS_HIP_CHECK(hipStreamSynchronize(s)); return GBRS_OK; }
+
+    // 1. entries -> sorted (row, locus, hap) keys
+    DevBuf<uint64_t> keys, keys2;
+    GBRS_TRY(keys.alloc(N));
+    GBRS_TRY(keys2.alloc(N));
+    hipLaunchKernelGGL(make_keys_kernel, dim3(grid_for(N)), dim3(256), 0, s, N, H * L, L, R, col_ptr, ent_row,
+                       keys.p, d_flags.p);
+    GBRS_TRY(sort_keys64(sc, keys.p, keys2.p, N, 32 + bits_for(R - 1), s));
+    keys.release();
+    // 2. pairs
+    DevBuf<uint32_t> pflag, pidx;
+    GBRS_TRY(pflag.alloc(N));
+    GBRS_TRY(pidx.alloc(N));
+    hipLaunchKernelGGL(pair_flag_kernel, dim3(grid_for(N)), dim3(256), 0, s, N, keys2.p, pflag.p, d_flags.p);
+    GBRS_TRY(exclusive_scan(sc, pflag.p, pidx.p, N, s));
+    uint32_t P32 = 0;
+    GBRS_TRY(fetch_last_plus(pidx.p, pflag.p, N, P32, s));
+    GBRS_TRY(read_flags());
+    if (hf.bad_row) return fail(GBRS_ERR_INVALID, "indices hold a row id >= num_rows");
+    if (hf.duplicate) return fail(GBRS_ERR_INVALID, "duplicate (row, locus, haplotype) entry: the CSC arrays must be canonical");
+    const uint64_t P = P32;
+    out.n_pairs = P;
+    DevBuf<uint32_t> prow, ploc, pmask;
+    GBRS_TRY(prow.alloc(P));
+    GBRS_TRY(ploc.alloc(P));
+    GBRS_TRY(pmask.alloc(P));
+    hipLaunchKernelGGL(emit_pairs_kernel, dim3(grid_for(N)), dim3(256), 0, s, N, keys2.p, pflag.p, pidx.p, prow.p,
+                       ploc.p, pmask.p);
+    GBRS_HIP_CHECK(hipStreamSynchronize(s));
+    keys2.release(); pflag.release(); pidx.release();
+    // 3. rows
+    DevBuf<uint32_t> rflag, ridx;
+    GBRS_TRY(rflag.alloc(P));
+    GBRS_TRY(ridx.alloc(P));
+    hipLaunchKernelGGL(row_flag_kernel, dim3(grid_for(P)), dim3(256), 0, s, P, prow.p, rflag.p);
+    GBRS_TRY(exclusive_scan(sc, rflag.p, ridx.p, P, s));
+    uint32_t R1 = 0;
+    GBRS_TRY(fetch_last_plus(ridx.p, rflag.p, P, R1, s));
+    out.n_rows_in = R1;
+    DevBuf<uint32_t> rowstart, row_orig;
+    GBRS_TRY(rowstart.alloc((size_t)R1 + 1));
+    GBRS_TRY(row_orig.alloc(R1));
+    hipLaunchKernelGGL(row_start_kernel, dim3(grid_for(P)), dim3(256), 0, s, P, (uint64_t)R1, rflag.p, ridx.p, prow.p,
+                       rowstart.p, row_orig.p);
+    GBRS_HIP_CHECK(hipStreamSynchronize(s));
+    rflag.release(); ridx.release(); prow.release();
+    // 4. order rows so that similar rows are adjacent
+    DevBuf<uint64_t> rkey, skey;
+    DevBuf<uint32_t> ident, srow;
+    GBRS_TRY(rkey.alloc(R1)); GBRS_TRY(skey.alloc(R1)); GBRS_TRY(ident.alloc(R1)); GBRS_TRY(srow.alloc(R1));
+    const unsigned lbits = bits_for(L - 1);
+    hipLaunchKernelGGL(row_key_kernel, dim3(grid_for(R1)), dim3(256), 0, s, (uint64_t)R1, lbits > 24 ? lbits - 24 : 0u,
+                       rowstart.p, ploc.p, pmask.p, rkey.p, ident.p, d_flags.p);
+    GBRS_TRY(sort_pairs<uint64_t>(sc, rkey.p, skey.p, ident.p, srow.p, R1, 64, s));
+    GBRS_TRY(read_flags());
+    rkey.release(); ident.release();
+    const uint64_t n_long = hf.n_long, n_short = R1 - n_long;
+    out.n_long = n_long;
+    // 5. optional merge of identical adjacent rows + weights
+    DevBuf<uint32_t> head, hincl, hrow;
+    uint64_t M = n_short;
+    if (n_short) {
+        GBRS_TRY(head.alloc(n_short)); GBRS_TRY(hincl.alloc(n_short));
+        hipLaunchKernelGGL(merge_flag_kernel, dim3(grid_for(n_short)), dim3(256), 0, s, n_short, merge ? 1 : 0, skey.p,
+                           srow.p, rowstart.p, ploc.p, pmask.p, head.p);
+        GBRS_TRY(inclusive_scan(sc, head.p, hincl.p, n_short, s));
+        uint32_t m32 = 0;
+        GBRS_HIP_CHECK(hipMemcpyAsync(&m32, hincl.p + n_short - 1, 4, hipMemcpyDeviceToHost, s));
+        GBRS_HIP_CHECK(hipStreamSynchronize(s));
+        M = m32;
+        GBRS_TRY(hrow.alloc(M));
+        if (out.weighted) {
+            GBRS_TRY(out.row_weight.alloc(M));
+            GBRS_HIP_CHECK(hipMemsetAsync(out.row_weight.p, 0, out.row_weight.bytes(), s));
+        }
+        hipLaunchKernelGGL(merged_rows_kernel, dim3(grid_for(n_short)), dim3(256), 0, s, n_short, head.p, hincl.p, srow.p,
+                           row_orig.p, count, hrow.p, out.weighted ? out.row_weight.p : nullptr);
+        GBRS_HIP_CHECK(hipStreamSynchronize(s));
+        head.release(); hincl.release();
+    }
+    skey.release();
+    out.n_rows = M;
+    // 6. long rows keep their pair form
+    if (n_long) {
+        DevBuf<uint64_t> llen;
+        GBRS_TRY(llen.alloc(n_long));
+        GBRS_TRY(out.long_ptr.alloc(n_long + 1));
+        GBRS_TRY(out.long_weight.alloc(n_long));
+        hipLaunchKernelGGL(long_rows_kernel, dim3(grid_for(n_long)), dim3(256), 0, s, n_long, n_short, srow.p, rowstart.p,
+                           row_orig.p, count, llen.p, out.long_weight.p);
+        GBRS_TRY(exclusive_scan(sc, llen.p, out.long_ptr.p, n_long, s));
+        uint64_t tot = 0;
+        GBRS_TRY(fetch_last_plus(out.long_ptr.p, llen.p, n_long, tot, s));
+        GBRS_HIP_CHECK(hipMemcpyAsync(out.long_ptr.p + n_long, &tot, 8, hipMemcpyHostToDevice, s));
+        GBRS_TRY(out.long_loc.alloc(tot));
+        GBRS_TRY(out.long_mask.alloc(tot));
+        hipLaunchKernelGGL(long_copy_kernel, dim3((unsigned)n_long), dim3(64), 0, s, n_long, n_short, srow.p, rowstart.p,
+                           ploc.p, pmask.p, out.long_ptr.p, out.long_loc.p, out.long_mask.p);
+        GBRS_TRY(out.acc_extra.alloc((size_t)L * H));
+        GBRS_HIP_CHECK(hipStreamSynchronize(s));
+    }
+    srow.release(); row_orig.release();
+    if (M == 0) { GBRS_HIP_CHECK(hipStreamSynchronize(s)); return GBRS_OK; }
+    // 7. tiles
+    DevBuf<uint32_t> npm, dnew, wordoff, dincl, tflag, tincl;
+    GBRS_TRY(npm.alloc(M)); GBRS_TRY(dnew.alloc(M)); GBRS_TRY(wordoff.alloc(M)); GBRS_TRY(dincl.alloc(M));
+    GBRS_TRY(tflag.alloc(M)); GBRS_TRY(tincl.alloc(M));
+    hipLaunchKernelGGL(row_len_kernel, dim3(grid_for(M)), dim3(256), 0, s, M, hrow.p, rowstart.p, ploc.p, npm.p, dnew.p);
+    GBRS_TRY(exclusive_scan(sc, npm.p, wordoff.p, M, s));
+    GBRS_TRY(inclusive_scan(sc, dnew.p, dincl.p, M, s));
+    hipLaunchKernelGGL(tile_flag_kernel, dim3(grid_for(M)), dim3(256), 0, s, M, (uint32_t)TILE_WORDS, dseg, npm.p,
+                       wordoff.p, dincl.p, tflag.p);
+    GBRS_TRY(inclusive_scan(sc, tflag.p, tincl.p, M, s));
+    uint32_t T32 = 0;
+    GBRS_HIP_CHECK(hipMemcpyAsync(&T32, tincl.p + M - 1, 4, hipMemcpyDeviceToHost, s));
+    GBRS_HIP_CHECK(hipStreamSynchronize(s));
+    const uint64_t T = T32;
+    out.n_tiles = T;
+    dnew.release(); dincl.release();
+    DevBuf<uint32_t> tile_row;
+    GBRS_TRY(tile_row.alloc(T + 1));
+    hipLaunchKernelGGL(tile_start_kernel, dim3(grid_for(M)), dim3(256), 0, s, M, T, tflag.p, tincl.p, tile_row.p);
+    tflag.release();
+    // 8. padding so that no row straddles a batch, batch offsets
+    DevBuf<uint32_t> rowpad, nbatch, batch_base;
+    GBRS_TRY(rowpad.alloc(M)); GBRS_TRY(nbatch.alloc(T)); GBRS_TRY(batch_base.alloc(T));
+    hipLaunchKernelGGL(tile_pad_kernel, dim3(grid_for(T, 64)), dim3(64), 0, s, T, tile_row.p, npm.p, rowpad.p, nbatch.p);
+    GBRS_TRY(exclusive_scan(sc, nbatch.p, batch_base.p, T, s));
+    uint32_t NB = 0;
+    GBRS_TRY(fetch_last_plus(batch_base.p, nbatch.p, T, NB, s));
+    out.n_batches = NB;
+    // 9. per-tile dictionaries
+    const uint32_t dcap = out.d_max;
+    DevBuf<uint32_t> tmpdict, dcount, dict_base;
+    GBRS_TRY(tmpdict.alloc((size_t)T * dcap)); GBRS_TRY(dcount.alloc(T)); GBRS_TRY(dict_base.alloc(T));
+    hipLaunchKernelGGL(tile_dict_kernel, dim3((unsigned)T), dim3(512), 0, s, dcap, tile_row.p, hrow.p, rowstart.p, ploc.p,
+                       wordoff.p, tmpdict.p, dcount.p, d_flags.p);
+    GBRS_TRY(exclusive_scan(sc, dcount.p, dict_base.p, T, s));
+    uint32_t NS = 0;
+    GBRS_TRY(fetch_last_plus(dict_base.p, dcount.p, T, NS, s));
+    GBRS_TRY(read_flags());
+    if (hf.dict_overflow) return fail(GBRS_ERR_INVALID, "internal error: a tile dictionary overflowed its capacity");
+    out.n_slots = NS;
+    GBRS_TRY(out.tiles.alloc(T));
+    GBRS_TRY(out.dict.alloc(std::max<uint32_t>(NS, 1)));
+    hipLaunchKernelGGL(tile_hdr_kernel, dim3((unsigned)T), dim3(64), 0, s, T, dcap, batch_base.p, nbatch.p, dict_base.p,
+                       dcount.p, tmpdict.p, out.tiles.p, out.dict.p);
+    // 10. words
+    GBRS_TRY(out.words.alloc((size_t)NB * 64));
+    GBRS_HIP_CHECK(hipMemsetAsync(out.words.p, 0, out.words.bytes(), s));
+    if (out.weighted) GBRS_TRY(out.batch_row.alloc(NB));
+    hipLaunchKernelGGL(emit_words_kernel, dim3(grid_for(M)), dim3(256), 0, s, M, H, tincl.p, out.tiles.p, out.dict.p,
+                       hrow.p, rowstart.p, ploc.p, pmask.p, rowpad.p, out.words.p,
+                       out.weighted ? out.batch_row.p : nullptr);
+    GBRS_HIP_CHECK(hipStreamSynchronize(s));
+    tmpdict.release(); dcount.release(); dict_base.release(); batch_base.release(); nbatch.release();
+    rowpad.release(); tincl.release(); npm.release(); wordoff.release(); tile_row.release();
+    hrow.release(); rowstart.release(); ploc.release(); pmask.release();
+    // 11. inverted index locus -> slots (ascending slot inside a locus: radix sort is stable)
+    GBRS_TRY(out.slot_list.alloc(std::max<uint32_t>(NS, 1)));
+    if (NS) {
+        DevBuf<uint32_t> sid, sloc;
+        GBRS_TRY(sid.alloc(NS)); GBRS_TRY(sloc.alloc(NS));
+        hipLaunchKernelGGL(iota_kernel, dim3(grid_for(NS)), dim3(256), 0, s, (uint64_t)NS, sid.p);
+        GBRS_TRY(sort_pairs<uint32_t>(sc, out.dict.p, sloc.p, sid.p, out.slot_list.p, NS, bits_for(L - 1), s));
+        hipLaunchKernelGGL(slot_ptr_kernel, dim3(grid_for((uint64_t)L + 1)), dim3(256), 0, s, L, (uint64_t)NS, sloc.p,
+                           out.slot_ptr.p);
+        GBRS_HIP_CHECK(hipStreamSynchronize(s));
+    }
+    GBRS_TRY(out.partials.alloc(std::max<size_t>((size_t)NS * H, 1)));
+    // 12. loci with many slots get a whole wave in the gather kernel
+    {
+        std::vector<uint32_t> sp((size_t)L + 1), heavy;
+        GBRS_HIP_CHECK(hipMemcpyAsync(sp.data(), out.slot_ptr.p, sp.size() * 4, hipMemcpyDeviceToHost, s));
+        GBRS_HIP_CHECK(hipStreamSynchronize(s));
+        for (uint32_t l = 0; l < L; ++l)
+            if (sp[l + 1] - sp[l] > (uint32_t)HEAVY_SLOTS) heavy.push_back(l);
+        out.n_heavy = heavy.size();
+        GBRS_TRY(out.heavy_loci.alloc(std::max<size_t>(heavy.size(), 1)));
+        if (!heavy.empty())
+            GBRS_HIP_CHECK(hipMemcpyAsync(out.heavy_loci.p, heavy.data(), heavy.size() * 4, hipMemcpyHostToDevice, s));
+        GBRS_HIP_CHECK(hipStreamSynchronize(s));
+    }
+    GBRS_HIP_CHECK(hipGetLastError());
+    return GBRS_OK;
+}
+
+}  // namespace gbrs

@@ -61,6 +61,9 @@ typedef struct gbrs_em gbrs_em_t;
  * layout (what `gbrs compress`, gbrs/emase_utils.py:60-103, does as a separate command).  Same
  * fixed point; off by default so that every input row is processed every iteration. */
 #define GBRS_EM_MERGE_IDENTICAL_ROWS 1u
+/* Keep the reference's CSC arrays as the device layout (two passes with global float64 atomics).
+ * The default is the packed-row-tile layout; this one is the simple cross-check. */
+#define GBRS_EM_LAYOUT_CSC 2u
 
 /*
  * Replaces: AlignmentPropertyMatrix(h5file=...) as consumed by EMfactory.__init__

@@ -12,7 +12,10 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-9
 
 
-def make_factory(g, merge=False):
+LAYOUTS = {"tiles": dict(), "tiles_merged": dict(merge_identical_rows=True), "csc": dict(csc_layout=True)}
+
+
+def make_factory(g, layout="tiles"):
     from gbrs_amd.alignment import AlignmentPropertyMatrix
     from gbrs_amd.em import EMfactory
     R, L, H, indptr, indices, count, eff_len, groups, gtmask = em_case_inputs(g)
@@ -24,7 +27,7 @@ def make_factory(g, merge=False):
     apm.num_groups = len(groups)
     if gtmask is not None:
         apm.mask_haplotype_loci(gtmask)
-    em = EMfactory(apm, merge_identical_rows=merge)
+    em = EMfactory(apm, **LAYOUTS[layout])
     em.target_lengths = eff_len
     return em
 
@@ -33,13 +36,15 @@ def close(a, b, rtol=RTOL):
     np.testing.assert_allclose(a, b, rtol=rtol, atol=1e-300)
 
 
-@pytest.mark.parametrize("merge", [False, True], ids=["rows", "merged"])
+@pytest.mark.parametrize("layout", list(LAYOUTS))
 @pytest.mark.parametrize("path", golden_files("em"), ids=lambda p: p.split("/")[-1][:-4])
-def test_em_matches_reference_golden(path, merge):
+def test_em_matches_reference_golden(path, layout):
     g = load_golden(path)
     pc = float(g["pseudocount"])
-    em = make_factory(g, merge)
+    em = make_factory(g, layout)
+    expect_layout = 0 if (layout == "csc" or int(g["num_haps"]) > 16) else 1
     em.prepare(pseudocount=pc)
+    assert em.info().layout == expect_layout
     close(em.allelic_expression, g["theta0"])
     # fixed iteration counts: tol=0 never stops early
     done = 0
@@ -76,8 +81,8 @@ def test_em_c1_shape_vs_oracle():
     apm = AlignmentPropertyMatrix(shape=(inc.num_loci, inc.num_haps, inc.num_rows), indptr=inc.indptr,
                                   indices=inc.indices, haplotype_names=inc.hap_names,
                                   locus_names=inc.locus_names)
-    for merge in (False, True):
-        em = EMfactory(apm, merge_identical_rows=merge)
+    for kw in LAYOUTS.values():
+        em = EMfactory(apm, **kw)
         em.target_lengths = eff
         em.prepare(0.0)
         em.run(model=4, tol=1e-4, max_iters=999, verbose=False)
