@@ -40,6 +40,7 @@ def parse():
     ap.add_argument("--haps", type=int, default=8)
     ap.add_argument("--loci", type=int, default=120_000)
     ap.add_argument("--merge", action="store_true", help="merge identical rows in the device layout")
+    ap.add_argument("--flags", type=int, default=0, help="extra gbrs_em_create flags (tuning)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hmm", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=2_000_000)
@@ -69,7 +70,7 @@ def em_bench(args, rank, world, torch, dist):
         prob["R"], prob["L"], prob["H"], [t.data_ptr() for t in prob["indptr"]],
         [t.data_ptr() for t in prob["indices"]], None, prob["eff_len"].data_ptr(),
         device=torch.cuda.current_device(),
-        flags=_lib.GBRS_EM_MERGE_IDENTICAL_ROWS if args.merge else 0)
+        flags=(_lib.GBRS_EM_MERGE_IDENTICAL_ROWS if args.merge else 0) | args.flags)
     t_create = time.perf_counter() - t0
     n_entries = prob["N"]
     del prob
@@ -240,7 +241,8 @@ def main():
                                f"tol=0 fixed iterations" + (", rows sharded one 40M-read shard per GPU + "
                                "RCCL all-reduce of the H*L vector per iteration" if world > 1 else ""),
                    "layout": int(inf.layout), "merge_identical_rows": bool(args.merge),
-                   "device_rows": int(inf.num_device_rows), "device_words": int(inf.num_device_words)},
+                   "device_rows": int(inf.num_device_rows), "device_words": int(inf.num_device_words),
+                   "tiles": int(inf.num_tiles), "slots": int(inf.num_slots), "long_rows": int(inf.num_long_rows)},
         "roofline": {"bound": "hbm", "achieved": priced / estep_s / 1e9 if estep_s > 0 else None,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": priced / estep_s / 1e9 / HBM_PEAK_GBS if estep_s > 0 else None,

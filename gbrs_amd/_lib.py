@@ -43,6 +43,7 @@ class EmInfo(C.Structure):
         ("algorithmic_bytes", C.c_uint64), ("last_estep_ms", C.c_double),
         ("last_step_ms", C.c_double), ("num_loci", C.c_uint32), ("num_haps", C.c_uint32),
         ("layout", C.c_uint32), ("reserved", C.c_uint32),
+        ("num_tiles", C.c_uint64), ("num_slots", C.c_uint64), ("num_long_rows", C.c_uint64),
     ]
 
 

@@ -561,6 +561,12 @@ int em_create_impl(uint64_t R, uint32_t L, uint32_t H, const uint32_t *const *in
     if (!(flags & GBRS_EM_LAYOUT_CSC) && H <= 16 && n < 0xFFFFFFFFull) {
         GBRS_TRY(build_tile_layout(em->tl, R, L, H, n, em->ent_row.p, em->col_ptr.p,
                                    count ? em->count.p : nullptr, (flags & GBRS_EM_MERGE_IDENTICAL_ROWS) != 0,
+                                   /* interleave by default only when rows are distinct patterns (EC counts given or
+                                      rows merged): raw reads come in long runs of identical rows that the
+                                      E-step's per-lane register accumulation wants contiguous */
+                                   (flags & GBRS_EM_FORCE_INTERLEAVE) ||
+                                       (!(flags & GBRS_EM_NO_INTERLEAVE) &&
+                                        (count != nullptr || (flags & GBRS_EM_MERGE_IDENTICAL_ROWS))),
                                    em->stream));
         em->layout = 1;
         // the CSC copy and the per-row denominators are only needed by layout 0
@@ -777,6 +783,9 @@ int gbrs_em_info(gbrs_em_t *em, gbrs_em_info_t *info) {
     if (em->layout == 1) {
         const TileLayout &tl = em->tl;
         info->num_device_rows = tl.n_rows + tl.n_long;
+        info->num_tiles = tl.n_tiles;
+        info->num_slots = tl.n_slots;
+        info->num_long_rows = tl.n_long;
         info->num_device_words = tl.n_batches * 64;
         // E-step: word stream, tile headers, dictionary, theta gather + partial store per slot,
         // [row weights]; gather: slot index + partials read back + acc store; M-step etc.: 5 H*L vectors

@@ -1,8 +1,10 @@
 // Device layout of the alignment incidence tensor for the tiled E-step ("packed row tiles").
 // Built once per handle by build_tile_layout() (em_layout.hip) from the reference's CSC arrays.
 //
-//   word   = one (row, locus) pair of a read: [ local locus index | last-word-of-row | hap mask ]
-//            bits [0,H) mask, bit H last flag, bits [H+1,32) index into the tile's dictionary.
+//   word   = one (row, locus) pair of a read: [ local locus index | rem | pos | hap mask ]
+//            bits [0,H) mask; PB bits pos = words of the row before this one; PB bits rem = words
+//            of the row after it; the rest = index into the tile's dictionary.  PB = 5 (rows of up
+//            to 32 loci) for H <= 8, 4 (16 loci) for H <= 16.
 //   batch  = 64 consecutive words = what one wavefront takes per step; rows never straddle a
 //            batch (zero words pad the tail), so a batch is self-contained.
 //   tile   = a run of batches processed by one workgroup with one locus dictionary of at most
@@ -19,9 +21,14 @@ namespace gbrs {
 constexpr int TILE_THREADS = 512;              // 8 waves per workgroup
 constexpr int TILE_WAVES = TILE_THREADS / 64;
 constexpr int TILE_WORDS = 8192 - 64;          // unpadded words per tile (sort capacity 8192)
-constexpr int MAX_ROW_WORDS = 32;              // rows with more distinct loci go to the long-row path
-constexpr int LDS_THETA_DOUBLES = 4096;        // theta of the tile: D_MAX * H doubles (32 KiB)
-constexpr int LDS_ACC_DOUBLES = 4096 + 64;     // privatised partial sums (32.5 KiB)
+// rows with more distinct loci than this go to the long-row path
+__host__ __device__ constexpr int pos_bits(int H) { return H <= 8 ? 5 : 4; }
+__host__ __device__ constexpr int max_row_words(int H) { return 1 << pos_bits(H); }
+#ifndef GBRS_LDS_DOUBLES
+#define GBRS_LDS_DOUBLES 4096
+#endif
+constexpr int LDS_THETA_DOUBLES = GBRS_LDS_DOUBLES;        // theta of the tile: D_MAX * H doubles
+constexpr int LDS_ACC_DOUBLES = GBRS_LDS_DOUBLES + 64;     // privatised partial sums
 constexpr int HEAVY_SLOTS = 32;                // loci with more slots get a whole wave in the gather
 
 struct TileHdr {
@@ -61,7 +68,7 @@ struct TileLayout {
 // count: device pointer or nullptr.  Returns GBRS_OK or a status with the message set.
 int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L, uint32_t H, uint64_t N,
                       const uint32_t *ent_row, const uint64_t *col_ptr, const double *count,
-                      bool merge_identical_rows, hipStream_t stream);
+                      bool merge_identical_rows, bool interleave, hipStream_t stream);
 
 // shared by em.hip and em_layout.hip -----------------------------------------------------------
 __device__ __forceinline__ uint32_t find_column(const uint64_t *__restrict__ col_ptr, uint32_t lo,

@@ -97,7 +97,7 @@ struct BuildFlags {
     unsigned int duplicate;      // the same (row, locus, haplotype) stored twice
     unsigned int dict_overflow;  // a tile dictionary exceeded its capacity (internal error)
     unsigned int bad_row;        // row id >= R
-    unsigned int n_long;         // rows with more than MAX_ROW_WORDS loci
+    unsigned int n_long;         // rows with more than max_row_words(H) loci
 };
 
 __global__ void __launch_bounds__(256)
@@ -164,14 +164,14 @@ __device__ __forceinline__ uint32_t mix32(uint32_t h, uint32_t v) {
     return h;
 }
 
-__global__ void row_key_kernel(uint64_t nrows, unsigned loc_shift, const uint32_t *__restrict__ rowstart,
+__global__ void row_key_kernel(uint64_t nrows, uint32_t max_row, unsigned loc_shift, const uint32_t *__restrict__ rowstart,
                                const uint32_t *__restrict__ ploc, const uint32_t *__restrict__ pmask,
                                uint64_t *__restrict__ key, uint32_t *__restrict__ ident, BuildFlags *flags) {
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= nrows) return;
     ident[r] = (uint32_t)r;
     const uint32_t a = rowstart[r], b = rowstart[r + 1];
-    if (b - a > MAX_ROW_WORDS) {
+    if (b - a > max_row) {
         key[r] = ~0ull;
         atomicAdd(&flags->n_long, 1u);
         return;
@@ -252,6 +252,40 @@ __global__ void tile_flag_kernel(uint64_t m_rows, uint32_t tile_words, uint32_t 
         f = (wordoff[m] / tile_words != wordoff[m - 1] / tile_words) || (dc / dseg != dp / dseg);
     }
     tflag[m] = f;
+}
+
+// interleave: rows of one locus list are dealt round-robin against the other lists of the tile so
+// that the 64 words of a batch spread over as many dictionary entries as possible (LDS atomic
+// conflicts in the E-step come from lanes that share a partial-sum copy AND a locus)
+__global__ void group_flag_kernel(uint64_t m_rows, const uint32_t *__restrict__ dnew, const uint32_t *__restrict__ tflag,
+                                  uint32_t *__restrict__ gflag, uint32_t *__restrict__ gpos) {
+    const uint64_t m = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= m_rows) return;
+    const uint32_t f = (dnew[m] > 0) || tflag[m];
+    gflag[m] = f;
+    gpos[m] = f ? (uint32_t)m : 0u;
+}
+
+__global__ void interleave_key_kernel(uint64_t m_rows, const uint32_t *__restrict__ tincl, const uint32_t *__restrict__ gstart,
+                                      const uint32_t *__restrict__ gord, uint64_t *__restrict__ key,
+                                      uint32_t *__restrict__ ident) {
+    const uint64_t m = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= m_rows) return;
+    const uint64_t rank = (uint32_t)m - gstart[m];
+    key[m] = ((uint64_t)(tincl[m] - 1) << 40) | ((rank & 0x3FFFu) << 26) | (gord[m] & 0x3FFFFFFu);
+    ident[m] = (uint32_t)m;
+}
+
+__global__ void permute_rows_kernel(uint64_t m_rows, const uint32_t *__restrict__ perm, const uint32_t *__restrict__ hrow,
+                                    const uint32_t *__restrict__ npm, const double *__restrict__ weight,
+                                    uint32_t *__restrict__ hrow2, uint32_t *__restrict__ npm2,
+                                    double *__restrict__ weight2) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m_rows) return;
+    const uint32_t m = perm[i];
+    hrow2[i] = hrow[m];
+    npm2[i] = npm[m];
+    if (weight) weight2[i] = weight[m];
 }
 
 __global__ void tile_start_kernel(uint64_t m_rows, uint64_t n_tiles, const uint32_t *__restrict__ tflag,
@@ -359,6 +393,7 @@ __global__ void emit_words_kernel(uint64_t m_rows, uint32_t H, const uint32_t *_
     const uint64_t m = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= m_rows) return;
     const TileHdr th = hdr[tincl[m] - 1];
+    const uint32_t PB = pos_bits(H);
     const uint32_t r = hrow[m], p0 = rowstart[r], cnt = rowstart[r + 1] - p0;
     const uint32_t off = rowpad[m];
     const uint64_t base = (uint64_t)th.batch_base * 64 + off;
@@ -370,7 +405,7 @@ __global__ void emit_words_kernel(uint64_t m_rows, uint32_t H, const uint32_t *_
             const uint32_t mid = (lo + hi) >> 1;
             if (d[mid] < l) lo = mid + 1; else hi = mid;
         }
-        words[base + j] = pmask[p0 + j] | ((j + 1 == cnt ? 1u : 0u) << H) | (lo << (H + 1));
+        words[base + j] = pmask[p0 + j] | (j << H) | ((cnt - 1 - j) << (H + PB)) | (lo << (H + 2 * PB));
     }
     if (batch_row && (off & 63u) == 0) batch_row[th.batch_base + (off >> 6)] = (uint32_t)m;
 }
@@ -421,7 +456,7 @@ __global__ void long_copy_kernel(uint64_t n_long, uint64_t first, const uint32_t
 
 int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L, uint32_t H, uint64_t N,
                       const uint32_t *ent_row, const uint64_t *col_ptr, const double *count,
-                      bool merge, hipStream_t s) {
+                      bool merge, bool interleave, hipStream_t s) {
     if (H > 16) return fail(GBRS_ERR_INVALID, "the tiled layout packs the haplotype mask in 16 bits (H <= 16)");
     if (N >= 0xFFFFFFFFull || L >= (1u << 27))
         return fail(GBRS_ERR_INVALID, "the tiled layout needs N < 2^32 entries and L < 2^27 loci per handle");
@@ -436,7 +471,7 @@ int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L, uint32_t H, uint6
         return GBRS_OK;
     };
     out.d_max = std::min<uint32_t>(1024, LDS_THETA_DOUBLES / H);
-    const uint32_t dseg = out.d_max - MAX_ROW_WORDS;
+    const uint32_t dseg = out.d_max - max_row_words(H);
     out.weighted = merge || count != nullptr;
     out.n_pairs = out.n_rows = out.n_rows_in = out.n_long = out.n_tiles = out.n_batches = out.n_slots = 0;
     GBRS_TRY(out.slot_ptr.alloc((size_t)L + 1));
@@ -493,7 +528,8 @@ int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L, uint32_t H, uint6
     DevBuf<uint32_t> ident, srow;
     GBRS_TRY(rkey.alloc(R1)); GBRS_TRY(skey.alloc(R1)); GBRS_TRY(ident.alloc(R1)); GBRS_TRY(srow.alloc(R1));
     const unsigned lbits = bits_for(L - 1);
-    hipLaunchKernelGGL(row_key_kernel, dim3(grid_for(R1)), dim3(256), 0, s, (uint64_t)R1, lbits > 24 ? lbits - 24 : 0u,
+    hipLaunchKernelGGL(row_key_kernel, dim3(grid_for(R1)), dim3(256), 0, s, (uint64_t)R1, (uint32_t)max_row_words(H),
+                       lbits > 24 ? lbits - 24 : 0u,
                        rowstart.p, ploc.p, pmask.p, rkey.p, ident.p, d_flags.p);
     GBRS_TRY(sort_pairs<uint64_t>(sc, rkey.p, skey.p, ident.p, srow.p, R1, 64, s));
     GBRS_TRY(read_flags());
@@ -560,10 +596,45 @@ int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L, uint32_t H, uint6
     GBRS_HIP_CHECK(hipStreamSynchronize(s));
     const uint64_t T = T32;
     out.n_tiles = T;
-    dnew.release(); dincl.release();
+    dincl.release();
     DevBuf<uint32_t> tile_row;
     GBRS_TRY(tile_row.alloc(T + 1));
     hipLaunchKernelGGL(tile_start_kernel, dim3(grid_for(M)), dim3(256), 0, s, M, T, tflag.p, tincl.p, tile_row.p);
+    // 7b. interleave the locus lists inside each tile (tile membership and sizes are unchanged)
+    if (interleave) {
+        DevBuf<uint32_t> gflag, gpos, gstart, gord, ident, perm, hrow2, npm2;
+        DevBuf<uint64_t> ikey, ikey2;
+        DevBuf<double> weight2;
+        GBRS_TRY(gflag.alloc(M)); GBRS_TRY(gpos.alloc(M)); GBRS_TRY(gstart.alloc(M)); GBRS_TRY(gord.alloc(M));
+        hipLaunchKernelGGL(group_flag_kernel, dim3(grid_for(M)), dim3(256), 0, s, M, dnew.p, tflag.p, gflag.p, gpos.p);
+        {
+            size_t bytes = 0;
+            GBRS_PRIM(rocprim::inclusive_scan(nullptr, bytes, gpos.p, gstart.p, (size_t)M, rocprim::maximum<uint32_t>(), s));
+            GBRS_TRY(sc.reserve(bytes));
+            GBRS_PRIM(rocprim::inclusive_scan(sc.buf.p, bytes, gpos.p, gstart.p, (size_t)M, rocprim::maximum<uint32_t>(), s));
+        }
+        GBRS_TRY(inclusive_scan(sc, gflag.p, gord.p, M, s));
+        GBRS_HIP_CHECK(hipStreamSynchronize(s));
+        gflag.release(); gpos.release();
+        GBRS_TRY(ikey.alloc(M)); GBRS_TRY(ikey2.alloc(M)); GBRS_TRY(ident.alloc(M)); GBRS_TRY(perm.alloc(M));
+        hipLaunchKernelGGL(interleave_key_kernel, dim3(grid_for(M)), dim3(256), 0, s, M, tincl.p, gstart.p, gord.p, ikey.p,
+                           ident.p);
+        GBRS_TRY(sort_pairs<uint64_t>(sc, ikey.p, ikey2.p, ident.p, perm.p, M, 40 + bits_for(T), s));
+        GBRS_HIP_CHECK(hipStreamSynchronize(s));
+        ikey.release(); ikey2.release(); ident.release(); gstart.release(); gord.release();
+        GBRS_TRY(hrow2.alloc(M)); GBRS_TRY(npm2.alloc(M));
+        if (out.weighted) GBRS_TRY(weight2.alloc(M));
+        hipLaunchKernelGGL(permute_rows_kernel, dim3(grid_for(M)), dim3(256), 0, s, M, perm.p, hrow.p, npm.p,
+                           out.weighted ? out.row_weight.p : (const double *)nullptr, hrow2.p, npm2.p,
+                           out.weighted ? weight2.p : (double *)nullptr);
+        GBRS_HIP_CHECK(hipMemcpyAsync(hrow.p, hrow2.p, M * 4, hipMemcpyDeviceToDevice, s));
+        GBRS_HIP_CHECK(hipMemcpyAsync(npm.p, npm2.p, M * 4, hipMemcpyDeviceToDevice, s));
+        if (out.weighted)
+            GBRS_HIP_CHECK(hipMemcpyAsync(out.row_weight.p, weight2.p, M * 8, hipMemcpyDeviceToDevice, s));
+        GBRS_TRY(exclusive_scan(sc, npm.p, wordoff.p, M, s));
+        GBRS_HIP_CHECK(hipStreamSynchronize(s));
+    }
+    dnew.release();
     tflag.release();
     // 8. padding so that no row straddles a batch, batch offsets
     DevBuf<uint32_t> rowpad, nbatch, batch_base;

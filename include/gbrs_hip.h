@@ -64,6 +64,11 @@ typedef struct gbrs_em gbrs_em_t;
 /* Keep the reference's CSC arrays as the device layout (two passes with global float64 atomics).
  * The default is the packed-row-tile layout; this one is the simple cross-check. */
 #define GBRS_EM_LAYOUT_CSC 2u
+/* Tuning switches for the order of rows inside a tile.  Interleaving deals the tile's locus lists
+ * round-robin across the 64 lanes of a batch (fewer LDS atomic conflicts when every row is a
+ * distinct pattern); by default it is on iff `count` is given or rows are merged. */
+#define GBRS_EM_NO_INTERLEAVE 4u
+#define GBRS_EM_FORCE_INTERLEAVE 8u
 
 /*
  * Replaces: AlignmentPropertyMatrix(h5file=...) as consumed by EMfactory.__init__
@@ -142,6 +147,9 @@ typedef struct gbrs_em_info {
     uint32_t num_loci, num_haps;
     uint32_t layout;            /* 0 = csc-direct, 1 = packed row tiles                     */
     uint32_t reserved;
+    uint64_t num_tiles;         /* layout 1: workgroup tiles                                */
+    uint64_t num_slots;         /* layout 1: (tile, locus) partial-sum slots                */
+    uint64_t num_long_rows;     /* layout 1: rows handled by the long-row kernel            */
 } gbrs_em_info_t;
 int gbrs_em_info(gbrs_em_t *em, gbrs_em_info_t *info);
 
