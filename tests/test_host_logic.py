@@ -1,0 +1,136 @@
+"""Host-side mirror logic (no GPU): containers, file parsing, report text, CLI surface."""
+import numpy as np
+import pytest
+
+from conftest import em_case_inputs, golden_files, load_golden
+
+
+def golden(name):
+    return load_golden([p for p in golden_files("em") if p.endswith(f"em_{name}.npz")][0])
+
+
+def make_apm(g):
+    from gbrs_amd.alignment import AlignmentPropertyMatrix
+    R, L, H, indptr, indices, count, eff_len, groups, gtmask = em_case_inputs(g)
+    apm = AlignmentPropertyMatrix(shape=(L, H, R), indptr=indptr, indices=indices, count=count,
+                                  haplotype_names=[chr(65 + h) for h in range(H)],
+                                  locus_names=[f"T{l:07d}" for l in range(L)])
+    return apm, groups, gtmask, eff_len
+
+
+def test_report_text_matches_reference_digits():
+    """The writer reproduces the reference's TSV byte for byte given the reference's numbers."""
+    from gbrs_amd.em import _write_report
+    import io, os, tempfile
+    g = golden("h8_count_len")
+    H = int(g["num_haps"])
+    hn = [chr(65 + h) for h in range(H)]
+    ln = [f"T{l:07d}" for l in range(int(g["num_loci"]))]
+    gn = [f"G{i:07d}" for i in range(len(g["group_ptr"]) - 1)]
+    theta = g["theta_final"] * (1000000.0 / g["theta_final"].sum())       # report_depths(tpm=True)
+    cases = [("text_isoforms_tpm", ln, theta),
+             ("text_isoforms_counts", ln, g["expected_counts"]),
+             ("text_genes_counts", gn, g["gene_counts"])]
+    for key, names, vals in cases:
+        with tempfile.TemporaryDirectory() as d:
+            p = os.path.join(d, "r.tsv")
+            _write_report(p, hn, names, vals, vals.sum(axis=0), "as-is", None)
+            assert open(p).read() == str(g[key]), key
+    # gene TPM: the reference first rescales theta in place (isoform report), then groups, then rescales
+    from oracle.em_oracle import EMOracle
+    R, L, H, indptr, indices, count, eff_len, groups, gtmask = em_case_inputs(g)
+    gene = np.asfortranarray(EMOracle.group_sums(theta, groups))      # memory order of scipy's product
+    gene = gene * (1000000.0 / gene.sum())
+    with tempfile.TemporaryDirectory() as d:
+        p = os.path.join(d, "r.tsv")
+        _write_report(p, hn, gn, gene, gene.sum(axis=0), "as-is", None)
+        assert open(p).read() == str(g["text_genes_tpm"])
+
+
+def test_mask_haplotype_loci_matches_oracle():
+    from oracle.em_oracle import EMOracle
+    g = golden("h8_mask")
+    apm, groups, gtmask, _ = make_apm(g)
+    R, L, H, indptr, indices, count, eff_len, _, _ = em_case_inputs(g)
+    o = EMOracle(R, L, H, indptr, indices, count)
+    o.apply_genotype_mask(gtmask)
+    apm.mask_haplotype_loci(gtmask)
+    for h in range(H):
+        np.testing.assert_array_equal(apm.indptr[h], o.indptr[h])
+        np.testing.assert_array_equal(apm.indices[h], o.indices[h])
+
+
+def test_length_file_and_groups(tmp_path):
+    from gbrs_amd.alignment import AlignmentPropertyMatrix
+    from gbrs_amd.em import read_length_file
+    g = golden("h8_len")
+    apm, groups, _, eff_len = make_apm(g)
+    lf = tmp_path / "len.tsv"
+    with open(lf, "w") as fh:
+        for l, name in enumerate(apm.lname):
+            for hn in apm.hname:
+                fh.write(f"{name}_{hn}\t{int(g['raw_length'][l])}\n")
+    np.testing.assert_array_equal(read_length_file(apm, str(lf), 100), eff_len)
+    gf = tmp_path / "g2t.tsv"
+    with open(gf, "w") as fh:
+        for i, mem in enumerate(groups):
+            fh.write(f"G{i:07d}\t" + "\t".join(apm.lname[m] for m in mem) + "\n")
+    apm.load_groups(str(gf))
+    gp, gm = apm.group_csr()
+    np.testing.assert_array_equal(gp, g["group_ptr"])
+    np.testing.assert_array_equal(gm, g["group_members"])
+    with open(gf, "a") as fh:
+        fh.write("GX\tNOPE\n")
+    with pytest.raises(KeyError):
+        apm.load_groups(str(gf))
+    # npz mirror round trip
+    apm.save_npz(str(tmp_path / "a.npz"))
+    b = AlignmentPropertyMatrix(npzfile=str(tmp_path / "a.npz"))
+    assert b.shape == apm.shape and b.hname == apm.hname and b.lname == apm.lname
+    for h in range(apm.num_haplotypes):
+        np.testing.assert_array_equal(b.indices[h], apm.indices[h])
+
+
+def test_container_validation():
+    from gbrs_amd.alignment import AlignmentPropertyMatrix
+    with pytest.raises(RuntimeError, match="three positive integers"):
+        AlignmentPropertyMatrix(shape=(3, 0, 4))
+    with pytest.raises(RuntimeError, match="does not match"):
+        AlignmentPropertyMatrix(shape=(3, 2, 4), haplotype_names=["A"])
+    with pytest.raises(RuntimeError, match="Malformed"):
+        AlignmentPropertyMatrix(shape=(2, 1, 4), indptr=[np.array([0, 1, 3])], indices=[np.array([0])])
+
+
+def test_cli_surface_and_error_swallowing(tmp_path, capsys):
+    from gbrs_amd import cli
+    p = cli.build_parser()
+    f = tmp_path / "x.npz"
+    f.write_bytes(b"")
+    a = p.parse_args(["quantify", "-i", str(f)])
+    assert (a.outbase, a.multiread_model, a.pseudocount, a.max_iters, a.tolerance) == \
+        ("gbrs.quantified", 4, 0.0, 999, 0.0001)
+    assert not a.report_alignment_counts and not a.report_posterior
+    r = p.parse_args(["reconstruct", "-e", str(f), "-t", str(f)])
+    assert (r.expr_threshold, r.sigma, r.outbase, r.avec_file, r.gpos_file) == (1.5, 0.12, None, None, None)
+    # like the reference, a failing subcommand logs and still exits 0
+    assert cli.main(["quantify", "-i", str(f), "-M", "9"]) == 0
+    assert cli.main(["quantify", "-i", str(f)]) == 0
+
+
+def test_genotype_mask_parsing(tmp_path):
+    from gbrs_amd.quantify import genotype_mask
+    g = golden("h8_mask")
+    apm, groups, gtmask, _ = make_apm(g)
+    apm.groups = groups
+    apm.gname = np.array([f"G{i:07d}" for i in range(len(groups))])
+    apm.num_groups = len(groups)
+    gt = tmp_path / "gt.tsv"
+    with open(gt, "w") as fh:
+        fh.write("#Gene_ID\tDiplotype\n")
+        for i, mem in enumerate(groups):
+            hs = np.flatnonzero(gtmask[:, mem[0]])
+            code = "".join(apm.hname[h] for h in (hs if len(hs) == 2 else [hs[0], hs[0]]))
+            fh.write(f"G{i:07d}\t{code}\n")
+    m, cg, ct = genotype_mask(apm, str(gt))
+    np.testing.assert_array_equal(m, gtmask)
+    assert cg["G0000000"] is not None and ct[apm.lname[groups[0][0]]] == cg["G0000000"]
