@@ -1,0 +1,54 @@
+"""`--report-alignment-counts`: alignment counts, allele-unique and locus-unique read counts per
+locus or gene (emase/AlignmentPropertyMatrix.py:389-459 and _bundle_inline :155-188), computed by
+libgbrs_hip (gbrs_alignment_counts).  Integer sums, exact."""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _lib
+
+
+def alignment_counts(apm, grp_wise=False, device=0):
+    """Returns (aln (H x Lo), allele_unique (H x Lo), locus_unique (Lo), names)."""
+    lib = _lib.load()
+    L, H, R = apm.shape
+    group = None
+    Lo = L
+    names = apm.lname
+    if grp_wise:
+        if not apm.num_groups:
+            raise RuntimeError('No group information is available for bundling.')
+        group = np.full(L, -1, dtype=np.int32)
+        for g, members in enumerate(apm.groups):
+            group[np.asarray(members, dtype=np.int64)] = g
+        if (group < 0).any():
+            # loci outside every gene vanish from the bundled matrix; park them in a scratch column
+            group = np.where(group < 0, apm.num_groups, group).astype(np.int32)
+            Lo = apm.num_groups + 1
+        else:
+            Lo = apm.num_groups
+        names = list(apm.gname)
+    aln = np.empty((H, Lo)); uniq = np.empty((H, Lo)); lu = np.empty(Lo)
+    cnt = None if apm.count is None else np.ascontiguousarray(apm.count, dtype=np.float64)
+    _lib.check(lib.gbrs_alignment_counts(R, L, H, _lib.ptr_table(apm.indptr), _lib.ptr_table(apm.indices),
+                                         _lib.ptr(cnt), _lib.ptr(group), Lo, device,
+                                         _lib.ptr(aln), _lib.ptr(uniq), _lib.ptr(lu)))
+    if grp_wise and Lo != apm.num_groups:
+        aln, uniq, lu = aln[:, :-1], uniq[:, :-1], lu[:-1]
+    return aln, uniq, lu, names
+
+
+def report_alignment_counts(apm, filename, grp_wise=False, device=0):
+    """File format of AlignmentPropertyMatrix.report_alignment_counts (:442-459)."""
+    aln, uniq, lu, names = alignment_counts(apm, grp_wise=grp_wise, device=device)
+    cntdata = np.vstack((aln, uniq))
+    cntdata = np.vstack((cntdata, lu))
+    with open(filename, 'w') as fhout:
+        fhout.write('locus\t' + '\t'.join([f'aln_{h}' for h in apm.hname]) + '\t')
+        fhout.write('\t'.join([f'uniq_{h}' for h in apm.hname]) + '\t')
+        fhout.write('locus_uniq' + '\n')
+        for locus_id in range(len(names)):
+            lout = [names[locus_id]]
+            lout.extend(list(map(str, cntdata[:, locus_id].ravel())))
+            fhout.write('\t'.join(lout))
+            fhout.write('\n')

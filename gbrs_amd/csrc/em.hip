@@ -561,28 +561,12 @@ int em_ensure_hist(gbrs_em *em, int cap) {
     return GBRS_OK;
 }
 
-int em_create_impl(uint64_t R, uint32_t L, uint32_t H, const uint32_t *const *indptr,
-                   const uint32_t *const *indices, const double *count, const double *eff_len,
-                   int device, uint32_t flags, bool on_device, gbrs_em_t **out) {
-    if (!out) return fail(GBRS_ERR_INVALID, "out is NULL");
-    *out = nullptr;
-    if (H < 1 || H > 32 || L < 1 || R < 1 || R > 0xFFFFFFFFull)
-        return fail(GBRS_ERR_INVALID, "The shape must be a tuple of three positive integers (H <= 32, R < 2^32).");
-    if (!indptr || !indices) return fail(GBRS_ERR_INVALID, "indptr/indices tables are NULL");
-    GBRS_TRY(select_device(device));
-    gbrs_em *em = new gbrs_em();
-    struct Guard { gbrs_em *p; ~Guard() { if (p) gbrs_em_destroy(p); } } guard{em};
-    em->device = device;
-    em->R = R; em->L = L; em->H = H; em->flags = flags;
-    em->has_count = count != nullptr;
-    em->has_len = eff_len != nullptr;
-    GBRS_HIP_CHECK(hipStreamCreateWithFlags(&em->stream, hipStreamDefault));
-    GBRS_HIP_CHECK(hipEventCreate(&em->ev0));
-    GBRS_HIP_CHECK(hipEventCreate(&em->ev1));
-    GBRS_HIP_CHECK(hipEventCreate(&em->ev2));
+// Concatenate the per-haplotype CSC arrays on the device: column id c = h*L + l, col_ptr[c] is the
+// offset of the column's first entry in ent_row.  Validates monotone indptr and (host inputs) row ids.
+int upload_csc(uint64_t R, uint32_t L, uint32_t H, const uint32_t *const *indptr,
+               const uint32_t *const *indices, bool on_device, DevBuf<uint32_t> &ent_row,
+               DevBuf<uint64_t> &col_ptr_dev, uint64_t &n_out) {
     const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-
-    // column pointers of the concatenated entry array: column id c = h*L + l
     std::vector<uint64_t> col_ptr((size_t)H * L + 1);
     std::vector<uint32_t> tmp(L + 1);
     uint64_t n = 0;
@@ -604,16 +588,48 @@ int em_create_impl(uint64_t R, uint32_t L, uint32_t H, const uint32_t *const *in
     }
     hap_off[H] = n;
     col_ptr[(size_t)H * L] = n;
-    em->N = n;
-    GBRS_TRY(em->col_ptr.alloc(col_ptr.size()));
-    GBRS_HIP_CHECK(hipMemcpy(em->col_ptr.p, col_ptr.data(), em->col_ptr.bytes(), hipMemcpyHostToDevice));
-    GBRS_TRY(em->ent_row.alloc(std::max<uint64_t>(n, 1)));
+    GBRS_TRY(col_ptr_dev.alloc(col_ptr.size()));
+    GBRS_HIP_CHECK(hipMemcpy(col_ptr_dev.p, col_ptr.data(), col_ptr_dev.bytes(), hipMemcpyHostToDevice));
+    GBRS_TRY(ent_row.alloc(std::max<uint64_t>(n, 1)));
     for (uint32_t h = 0; h < H; ++h) {
         const uint64_t cnt = hap_off[h + 1] - hap_off[h];
         if (cnt == 0) continue;
         if (!indices[h]) return fail(GBRS_ERR_INVALID, "indices[%u] is NULL", h);
-        GBRS_HIP_CHECK(hipMemcpy(em->ent_row.p + hap_off[h], indices[h], cnt * sizeof(uint32_t), kind));
+        if (!on_device) {
+            const uint32_t *ix = indices[h];
+            uint32_t mx = 0;
+            for (uint64_t k = 0; k < cnt; ++k) mx = ix[k] > mx ? ix[k] : mx;
+            if (mx >= R) return fail(GBRS_ERR_INVALID, "indices[%u] holds row id %u >= num_rows", h, mx);
+        }
+        GBRS_HIP_CHECK(hipMemcpy(ent_row.p + hap_off[h], indices[h], cnt * sizeof(uint32_t), kind));
     }
+    n_out = n;
+    return GBRS_OK;
+}
+
+int em_create_impl(uint64_t R, uint32_t L, uint32_t H, const uint32_t *const *indptr,
+                   const uint32_t *const *indices, const double *count, const double *eff_len,
+                   int device, uint32_t flags, bool on_device, gbrs_em_t **out) {
+    if (!out) return fail(GBRS_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (H < 1 || H > 32 || L < 1 || R < 1 || R > 0xFFFFFFFFull)
+        return fail(GBRS_ERR_INVALID, "The shape must be a tuple of three positive integers (H <= 32, R < 2^32).");
+    if (!indptr || !indices) return fail(GBRS_ERR_INVALID, "indptr/indices tables are NULL");
+    GBRS_TRY(select_device(device));
+    gbrs_em *em = new gbrs_em();
+    struct Guard { gbrs_em *p; ~Guard() { if (p) gbrs_em_destroy(p); } } guard{em};
+    em->device = device;
+    em->R = R; em->L = L; em->H = H; em->flags = flags;
+    em->has_count = count != nullptr;
+    em->has_len = eff_len != nullptr;
+    GBRS_HIP_CHECK(hipStreamCreateWithFlags(&em->stream, hipStreamDefault));
+    GBRS_HIP_CHECK(hipEventCreate(&em->ev0));
+    GBRS_HIP_CHECK(hipEventCreate(&em->ev1));
+    GBRS_HIP_CHECK(hipEventCreate(&em->ev2));
+    const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    uint64_t n = 0;
+    GBRS_TRY(upload_csc(R, L, H, indptr, indices, on_device, em->ent_row, em->col_ptr, n));
+    em->N = n;
     const size_t LH = (size_t)L * H;
     GBRS_TRY(em->den.alloc(R));
     GBRS_TRY(em->theta.alloc(LH));
@@ -637,21 +653,6 @@ int em_create_impl(uint64_t R, uint32_t L, uint32_t H, const uint32_t *const *in
         hipLaunchKernelGGL(transpose_hl_to_lh, dim3(1024), dim3(256), 0, em->stream, L, H,
                            em->scratch_hl.p, em->eff_len.p);
         GBRS_HIP_CHECK(hipStreamSynchronize(em->stream));
-    }
-    // row ids must be < R (a faulting kernel can take the whole node down: check on the host side
-    // of the boundary, once)
-    {
-        // max over ent_row via a tiny reduction on the device would do; the copy below is only
-        // taken for host inputs, where the data is already here
-        if (!on_device) {
-            for (uint32_t h = 0; h < H; ++h) {
-                const uint64_t cnt = hap_off[h + 1] - hap_off[h];
-                const uint32_t *ix = indices[h];
-                uint32_t mx = 0;
-                for (uint64_t k = 0; k < cnt; ++k) mx = ix[k] > mx ? ix[k] : mx;
-                if (cnt && mx >= R) return fail(GBRS_ERR_INVALID, "indices[%u] holds row id %u >= num_rows", h, mx);
-            }
-        }
     }
     GBRS_HIP_CHECK(hipDeviceSynchronize());
     if (!(flags & GBRS_EM_LAYOUT_CSC) && H <= 16 && n < 0xFFFFFFFFull) {
@@ -899,9 +900,46 @@ int gbrs_em_info(gbrs_em_t *em, gbrs_em_info_t *info) {
     return GBRS_OK;
 }
 
-int gbrs_em_alignment_counts(gbrs_em_t *em, double *, double *, double *) {
-    if (!em) return fail(GBRS_ERR_INVALID, "handle is NULL");
-    return fail(GBRS_ERR_UNSUPPORTED, "alignment counts are not implemented yet");
+int gbrs_alignment_counts(uint64_t R, uint32_t L, uint32_t H, const uint32_t *const *indptr,
+                          const uint32_t *const *indices, const double *count, const int32_t *locus_group,
+                          uint32_t num_out_loci, int device, double *aln_counts, double *allele_unique,
+                          double *locus_unique) {
+    if (H < 1 || H > 32 || L < 1 || R < 1 || R > 0xFFFFFFFFull || !indptr || !indices)
+        return fail(GBRS_ERR_INVALID, "The shape must be a tuple of three positive integers (H <= 32, R < 2^32).");
+    const uint32_t Lout = locus_group ? num_out_loci : L;
+    if (Lout < 1 || Lout >= (1u << 27)) return fail(GBRS_ERR_INVALID, "bad number of output loci");
+    if (locus_group)
+        for (uint32_t l = 0; l < L; ++l)
+            if (locus_group[l] < 0 || (uint32_t)locus_group[l] >= Lout)
+                return fail(GBRS_ERR_INVALID, "locus_group[%u] out of range", l);
+    GBRS_TRY(select_device(device));
+    hipStream_t s = nullptr;
+    GBRS_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamDefault));
+    struct SG { hipStream_t s; ~SG() { (void)hipStreamDestroy(s); } } sg{s};
+    DevBuf<uint32_t> ent_row;
+    DevBuf<uint64_t> col_ptr;
+    uint64_t n = 0;
+    GBRS_TRY(upload_csc(R, L, H, indptr, indices, false, ent_row, col_ptr, n));
+    DevBuf<double> d_count, d_aln, d_uniq, d_lu;
+    DevBuf<int32_t> d_group;
+    if (count) {
+        GBRS_TRY(d_count.alloc(R));
+        GBRS_HIP_CHECK(hipMemcpy(d_count.p, count, R * sizeof(double), hipMemcpyHostToDevice));
+    }
+    if (locus_group) {
+        GBRS_TRY(d_group.alloc(L));
+        GBRS_HIP_CHECK(hipMemcpy(d_group.p, locus_group, L * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    GBRS_TRY(d_aln.alloc((size_t)H * Lout));
+    GBRS_TRY(d_uniq.alloc((size_t)H * Lout));
+    GBRS_TRY(d_lu.alloc(Lout));
+    GBRS_HIP_CHECK(hipDeviceSynchronize());
+    GBRS_TRY(alignment_counts_device(R, L, H, n, ent_row.p, col_ptr.p, count ? d_count.p : nullptr,
+                                     locus_group ? d_group.p : nullptr, Lout, d_aln.p, d_uniq.p, d_lu.p, s));
+    if (aln_counts) GBRS_HIP_CHECK(hipMemcpy(aln_counts, d_aln.p, d_aln.bytes(), hipMemcpyDeviceToHost));
+    if (allele_unique) GBRS_HIP_CHECK(hipMemcpy(allele_unique, d_uniq.p, d_uniq.bytes(), hipMemcpyDeviceToHost));
+    if (locus_unique) GBRS_HIP_CHECK(hipMemcpy(locus_unique, d_lu.p, d_lu.bytes(), hipMemcpyDeviceToHost));
+    return GBRS_OK;
 }
 
 int gbrs_em_destroy(gbrs_em_t *em) {

@@ -70,6 +70,12 @@ int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L, uint32_t H, uint6
                       const uint32_t *ent_row, const uint64_t *col_ptr, const double *count,
                       bool merge_identical_rows, bool interleave, hipStream_t stream);
 
+// `--report-alignment-counts`: aln/uniq are (H x Lout) row-major, locus_uniq is Lout, all DEVICE
+// buffers; locus_group (device, nullable) maps locus -> output column (gene level).
+int alignment_counts_device(uint64_t R, uint32_t L, uint32_t H, uint64_t N, const uint32_t *ent_row,
+                            const uint64_t *col_ptr, const double *count, const int32_t *locus_group,
+                            uint32_t Lout, double *aln, double *uniq, double *locus_uniq, hipStream_t s);
+
 // shared by em.hip and em_layout.hip -----------------------------------------------------------
 __device__ __forceinline__ uint32_t find_column(const uint64_t *__restrict__ col_ptr, uint32_t lo,
                                                 uint32_t hi, uint64_t k) {

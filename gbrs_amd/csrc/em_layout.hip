@@ -454,6 +454,84 @@ __global__ void long_copy_kernel(uint64_t n_long, uint64_t first, const uint32_t
 
 }  // namespace
 
+// ---- `--report-alignment-counts` (AlignmentPropertyMatrix.py:389-459) -------------------------
+__global__ void __launch_bounds__(256)
+count_keys_kernel(uint64_t n, uint32_t ncols, uint32_t L, uint64_t R, const uint64_t *__restrict__ col_ptr,
+                  const uint32_t *__restrict__ ent_row, const int32_t *__restrict__ locus_group,
+                  uint64_t *__restrict__ keys, BuildFlags *flags) {
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k - (threadIdx.x & 63) >= n) return;
+    const bool live = k < n;
+    const uint32_t c = entry_column(col_ptr, ncols, live ? k : n - 1, n);
+    if (!live) return;
+    const uint32_t h = c / L, l = c - h * L;
+    const uint32_t r = ent_row[k];
+    if (r >= R) flags->bad_row = 1;
+    const uint32_t lo = locus_group ? (uint32_t)locus_group[l] : l;
+    keys[k] = ((uint64_t)r << 32) | ((uint64_t)lo << 5) | h;
+}
+
+// per unique (row, locus', hap) entry: bump the row's entry counter; per unique (row, locus')
+// pair: bump the row's locus counter
+__global__ void count_rowstat_kernel(uint64_t n, const uint64_t *__restrict__ keys, uint32_t *__restrict__ nnz_row,
+                                     uint32_t *__restrict__ nloc_row) {
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const uint64_t key = keys[k];
+    const bool new_entry = k == 0 || keys[k - 1] != key;
+    const bool new_pair = k == 0 || (keys[k - 1] >> 5) != (key >> 5);
+    const uint32_t r = (uint32_t)(key >> 32);
+    if (new_entry) atomicAdd(&nnz_row[r], 1u);
+    if (new_pair) atomicAdd(&nloc_row[r], 1u);
+}
+
+__global__ void count_accum_kernel(uint64_t n, uint32_t Lout, const uint64_t *__restrict__ keys,
+                                   const uint32_t *__restrict__ nnz_row, const uint32_t *__restrict__ nloc_row,
+                                   const double *__restrict__ count, double *__restrict__ aln,
+                                   double *__restrict__ uniq, double *__restrict__ locus_uniq) {
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const uint64_t key = keys[k];
+    const bool new_entry = k == 0 || keys[k - 1] != key;
+    if (!new_entry) return;
+    const bool new_pair = k == 0 || (keys[k - 1] >> 5) != (key >> 5);
+    const uint32_t r = (uint32_t)(key >> 32), l = (uint32_t)((key >> 5) & 0x7FFFFFFu), h = (uint32_t)(key & 31);
+    const double w = count ? count[r] : 1.0;
+    atomicAdd(&aln[(size_t)h * Lout + l], w);                       // integer-valued sums: exact
+    if (nnz_row[r] == 1) atomicAdd(&uniq[(size_t)h * Lout + l], w);
+    if (new_pair && nloc_row[r] == 1) atomicAdd(&locus_uniq[l], w);
+}
+
+int alignment_counts_device(uint64_t R, uint32_t L, uint32_t H, uint64_t N, const uint32_t *ent_row,
+                            const uint64_t *col_ptr, const double *count, const int32_t *locus_group,
+                            uint32_t Lout, double *aln, double *uniq, double *locus_uniq, hipStream_t s) {
+    GBRS_HIP_CHECK(hipMemsetAsync(aln, 0, (size_t)H * Lout * 8, s));
+    GBRS_HIP_CHECK(hipMemsetAsync(uniq, 0, (size_t)H * Lout * 8, s));
+    GBRS_HIP_CHECK(hipMemsetAsync(locus_uniq, 0, (size_t)Lout * 8, s));
+    if (N == 0) { GBRS_HIP_CHECK(hipStreamSynchronize(s)); return GBRS_OK; }
+    Scratch sc;
+    DevBuf<BuildFlags> d_flags;
+    GBRS_TRY(d_flags.alloc(1));
+    GBRS_HIP_CHECK(hipMemsetAsync(d_flags.p, 0, sizeof(BuildFlags), s));
+    DevBuf<uint64_t> keys, keys2;
+    DevBuf<uint32_t> nnz_row, nloc_row;
+    GBRS_TRY(keys.alloc(N)); GBRS_TRY(keys2.alloc(N)); GBRS_TRY(nnz_row.alloc(R)); GBRS_TRY(nloc_row.alloc(R));
+    GBRS_HIP_CHECK(hipMemsetAsync(nnz_row.p, 0, nnz_row.bytes(), s));
+    GBRS_HIP_CHECK(hipMemsetAsync(nloc_row.p, 0, nloc_row.bytes(), s));
+    hipLaunchKernelGGL(count_keys_kernel, dim3(grid_for(N)), dim3(256), 0, s, N, H * L, L, R, col_ptr, ent_row,
+                       locus_group, keys.p, d_flags.p);
+    GBRS_TRY(sort_keys64(sc, keys.p, keys2.p, N, 32 + bits_for(R - 1), s));
+    hipLaunchKernelGGL(count_rowstat_kernel, dim3(grid_for(N)), dim3(256), 0, s, N, keys2.p, nnz_row.p, nloc_row.p);
+    hipLaunchKernelGGL(count_accum_kernel, dim3(grid_for(N)), dim3(256), 0, s, N, Lout, keys2.p, nnz_row.p, nloc_row.p,
+                       count, aln, uniq, locus_uniq);
+    BuildFlags hf{};
+    GBRS_HIP_CHECK(hipMemcpyAsync(&hf, d_flags.p, sizeof(hf), hipMemcpyDeviceToHost, s));
+    GBRS_HIP_CHECK(hipStreamSynchronize(s));
+    GBRS_HIP_CHECK(hipGetLastError());
+    if (hf.bad_row) return fail(GBRS_ERR_INVALID, "indices hold a row id >= num_rows");
+    return GBRS_OK;
+}
+
 int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L, uint32_t H, uint64_t N,
                       const uint32_t *ent_row, const uint64_t *col_ptr, const double *count,
                       bool merge, bool interleave, hipStream_t s) {

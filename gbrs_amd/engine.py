@@ -99,12 +99,6 @@ class EmEngine:
         _lib.check(_lib.load().gbrs_em_group_sums(self._h, G, _lib.ptr(gp), _lib.ptr(mem), which, _lib.ptr(out)))
         return out
 
-    def alignment_counts(self):
-        L, H, R = self.shape
-        a = np.empty((H, L)); u = np.empty((H, L)); lu = np.empty(L)
-        _lib.check(_lib.load().gbrs_em_alignment_counts(self._h, _lib.ptr(a), _lib.ptr(u), _lib.ptr(lu)))
-        return a, u, lu
-
     def info(self):
         inf = _lib.EmInfo()
         _lib.check(_lib.load().gbrs_em_info(self._h, C.byref(inf)))

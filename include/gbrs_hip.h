@@ -153,10 +153,16 @@ typedef struct gbrs_em_info {
 } gbrs_em_info_t;
 int gbrs_em_info(gbrs_em_t *em, gbrs_em_info_t *info);
 
-/* `--report-alignment-counts` (emase/AlignmentPropertyMatrix.py:389-459): all (H x L) outputs
- * except locus_unique (L); integer-valued float64, exact.  Any pointer may be NULL. */
-int gbrs_em_alignment_counts(gbrs_em_t *em, double *aln_counts, double *allele_unique,
-                             double *locus_unique);
+/* `--report-alignment-counts` (emase/AlignmentPropertyMatrix.py:389-459), stand-alone (the
+ * reference reloads the alignment file for it, gbrs/emase_utils.py:318-331).  Inputs as for
+ * gbrs_em_create.  locus_group (nullable) int32[L] maps every locus to an output column, which
+ * gives the gene-level report after _bundle_inline(reset=True) (:155-188); num_out_loci = G then,
+ * ignored (= L) otherwise.  Outputs, any nullable: aln_counts and allele_unique (H x Lout)
+ * row-major, locus_unique (Lout).  Sums of EC counts in float64: exact for integer counts. */
+int gbrs_alignment_counts(uint64_t num_rows, uint32_t num_loci, uint32_t num_haps,
+                          const uint32_t *const *indptr, const uint32_t *const *indices,
+                          const double *count, const int32_t *locus_group, uint32_t num_out_loci,
+                          int device, double *aln_counts, double *allele_unique, double *locus_unique);
 
 int gbrs_em_destroy(gbrs_em_t *em);
 

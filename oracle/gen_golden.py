@@ -262,10 +262,57 @@ def hmm_case(name, H, genes_per_chrom, seed, len_minus_one, extra_fai_chrom=True
     np.savez_compressed(os.path.join(GOLD, f"hmm_{name}.npz"), **out)
     print(f"hmm_{name}: H={H} genes={genes_per_chrom} len-1={len_minus_one}")
 
+# ----------------------------------------------------------------------------- alignment counts
+
+def counts_case(name, R, H, L, seed, with_count, drop_rows=0):
+    """`--report-alignment-counts` (AlignmentPropertyMatrix.py:389-459) at isoform level and, after
+    _bundle_inline(reset=True) (:155-188), at gene level, from the reference's own methods."""
+    inc = synth.make_em_problem(R=R, H=H, L=L, seed=seed, with_count=with_count, max_count=7)
+    if drop_rows:
+        rng = np.random.default_rng(seed + 1)
+        dead = rng.choice(R, size=drop_rows, replace=False)
+        for h in range(H):
+            keep = ~np.isin(inc.indices[h], dead)
+            loc = np.repeat(np.arange(L), np.diff(inc.indptr[h].astype(np.int64)))[keep]
+            inc.indices[h] = inc.indices[h][keep]
+            inc.indptr[h] = np.searchsorted(loc, np.arange(L + 1)).astype(np.uint32)
+    case_dir = os.path.join(WORK, name)
+    os.makedirs(case_dir)
+    grpfile = os.path.join(case_dir, "g2t.tsv")
+    with open(grpfile, "w") as fh:
+        for g, members in zip(inc.group_names, inc.groups):
+            fh.write(g + "\t" + "\t".join(inc.locus_names[l] for l in members) + "\n")
+    out = dict(num_rows=R, num_loci=L, num_haps=H, has_count=with_count,
+               count=inc.count if with_count else np.zeros(0),
+               group_ptr=np.concatenate(([0], np.cumsum([len(g) for g in inc.groups]))).astype(np.int64),
+               group_members=np.concatenate([np.asarray(g, dtype=np.int64) for g in inc.groups]))
+    for h in range(H):
+        out[f"indptr{h}"] = inc.indptr[h]
+        out[f"indices{h}"] = inc.indices[h]
+    apm = ref_apm_from(inc, grpfile)
+    for level in ("isoforms", "genes"):
+        if level == "genes":
+            apm._bundle_inline(reset=True)
+        out[f"{level}_aln"] = np.asarray(apm.count_alignments())
+        out[f"{level}_uniq"] = np.asarray(apm.count_unique_reads(ignore_haplotype=False))
+        out[f"{level}_locus_uniq"] = np.asarray(apm.count_unique_reads(ignore_haplotype=True))
+        path = os.path.join(case_dir, level)
+        apm.report_alignment_counts(filename=path)
+        out[f"text_{level}"] = np.array(open(path).read())
+    np.savez_compressed(os.path.join(GOLD, f"counts_{name}.npz"), **out)
+    print(f"counts_{name}: R={R} H={H} L={L} nnz={inc.nnz}")
+
 
 def main():
     os.makedirs(GOLD, exist_ok=True)
+    only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else None
     try:
+        if only in (None, "counts"):
+            counts_case("h8_count", 1500, 8, 80, 41, True)
+            counts_case("h8_plain_emptyrows", 2000, 8, 100, 42, False, drop_rows=100)
+            counts_case("h2_count", 1200, 2, 60, 43, True)
+        if only == "counts":
+            return
         #        name            R     H  L    seed  count  len    pc   mask   tol   max
         em_case("h2_plain",      1500, 2, 60,  11,   False, False, 0.0, False, 1e-4, 999)
         em_case("h2_len",        1500, 2, 60,  12,   False, True,  0.0, False, 1e-4, 999)

@@ -167,3 +167,110 @@ def test_em_errors():
     with pytest.raises(FloatingPointError):
         em.run(model=4, tol=0.0, max_iters=2, verbose=False)
     em.close()
+
+
+def _parse_tsv(text):
+    lines = [l.split("\t") for l in text.strip().split("\n")]
+    return lines[0], {l[0]: l[1:] for l in lines[1:]}
+
+
+@pytest.mark.parametrize("name,use_mask", [("h8_count_len", False), ("h8_mask", True)])
+def test_quantify_cli_files(tmp_path, name, use_mask):
+    """`gbrs quantify` end to end through the CLI: npz alignment file, group/length/genotype files
+    in, the reference's report files out (numbers within 1e-9 of the reference's text)."""
+    from gbrs_amd import cli
+    from gbrs_amd.alignment import AlignmentPropertyMatrix
+    g = load_golden([p for p in golden_files("em") if p.endswith(f"em_{name}.npz")][0])
+    R, L, H, indptr, indices, count, eff_len, groups, gtmask = em_case_inputs(g)
+    hn = [chr(65 + h) for h in range(H)]
+    ln = [f"T{l:07d}" for l in range(L)]
+    apm = AlignmentPropertyMatrix(shape=(L, H, R), indptr=indptr, indices=indices, count=count,
+                                  haplotype_names=hn, locus_names=ln)
+    aln = tmp_path / "aln.npz"
+    apm.save_npz(str(aln))
+    grp = tmp_path / "g2t.tsv"
+    with open(grp, "w") as fh:
+        for i, mem in enumerate(groups):
+            fh.write(f"G{i:07d}\t" + "\t".join(ln[m] for m in mem) + "\n")
+    lens = tmp_path / "len.tsv"
+    with open(lens, "w") as fh:
+        for l in range(L):
+            for h in hn:
+                fh.write(f"{ln[l]}_{h}\t{int(g['raw_length'][l])}\n")
+    argv = ["quantify", "-i", str(aln), "-g", str(grp), "-L", str(lens), "-o", str(tmp_path / "out"),
+            "-p", str(float(g["pseudocount"])), "-a"]
+    suffix = "multiway"
+    if use_mask:
+        gt = tmp_path / "gt.tsv"
+        with open(gt, "w") as fh:
+            fh.write("#Gene_ID\tDiplotype\n")
+            for i, mem in enumerate(groups):
+                hs = np.flatnonzero(gtmask[:, mem[0]])
+                fh.write(f"G{i:07d}\t" + "".join(hn[h] for h in (hs if len(hs) == 2 else [hs[0], hs[0]])) + "\n")
+        argv += ["-G", str(gt)]
+        suffix = "diploid"
+    assert cli.main(argv) == 0
+    for key, fname in (("text_isoforms_tpm", "isoforms.tpm"), ("text_isoforms_counts", "isoforms.expected_read_counts"),
+                       ("text_genes_tpm", "genes.tpm"), ("text_genes_counts", "genes.expected_read_counts")):
+        got_h, got = _parse_tsv(open(tmp_path / f"out.{suffix}.{fname}").read())
+        exp_h, exp = _parse_tsv(str(g[key]))
+        assert got_h[:len(exp_h)] == exp_h and list(got) == list(exp)
+        if use_mask:
+            assert got_h[-1] == "notes"
+        for k in exp:
+            np.testing.assert_allclose([float(x) for x in got[k][:len(exp[k])]], [float(x) for x in exp[k]],
+                                       rtol=1e-9, atol=1e-300)
+    assert (tmp_path / f"out.{suffix}.isoforms.alignment_counts").exists()
+    assert (tmp_path / f"out.{suffix}.genes.alignment_counts").exists()
+
+
+def _sharded_worker(rank, world, port, path, out_dir):
+    import os, sys
+    from conftest import ROOT
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from gbrs_amd.dist import ShardedEM, shard_rows
+    from gbrs_amd.engine import EmEngine
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = load_golden(path)
+    R, L, H, indptr, indices, count, eff_len, groups, gtmask = em_case_inputs(g)
+    r0, r1, ip, ix, cnt = shard_rows(indptr, indices, count, R, rank, world)
+    eng = EmEngine.from_host(r1 - r0, L, H, ip, ix, cnt, eff_len, device=0)
+
+    class Dev:
+        def __init__(self, ptr, n):
+            self.__cuda_array_interface__ = dict(shape=(n,), typestr="<f8", data=(ptr, False), version=2)
+
+    def allreduce(ptr, n):          # gloo on host copies: both ranks share the one GPU of the box
+        eng.sync()
+        t = torch.as_tensor(Dev(ptr, n), device="cuda:0")
+        hcopy = t.cpu()
+        dist.all_reduce(hcopy)
+        t.copy_(hcopy)
+        torch.cuda.synchronize()
+    drv = ShardedEM(eng, allreduce)
+    drv.prepare(float(g["pseudocount"]))
+    n = drv.run(model=4, tol=float(g["tol"]), max_iters=int(g["max_iters"]))
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), theta=eng.theta(), n=n, err=np.array(drv.err_history))
+    eng.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_sharded_hip_engines(tmp_path):
+    """Rows sharded over two processes driving HIP engines (same GPU, gloo all-reduce through host
+    copies): identical on both ranks and equal to the unsharded reference."""
+    import socket
+    import torch.multiprocessing as mp
+    path = [p for p in golden_files("em") if p.endswith("em_h8_count_len.npz")][0]
+    g = load_golden(path)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_sharded_worker, args=(2, port, path, str(tmp_path)), nprocs=2, join=True)
+    a, b = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    np.testing.assert_array_equal(a["theta"], b["theta"])
+    assert int(a["n"]) == int(b["n"]) == int(g["num_iters"])
+    close(a["theta"], g["theta_final"])
+    np.testing.assert_allclose(a["err"], g["err_history"], rtol=1e-7)
