@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--cpu-iters", type=int, default=10)
     ap.add_argument("--hmm-samples", type=int, default=1)
     ap.add_argument("--hmm-reps", type=int, default=5)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo only to rehearse N>1 on one GPU)")
     return ap.parse_args()
 
 
@@ -83,11 +84,12 @@ def em_bench(args, rank, world, torch, dist):
 
     acc_t = None
     if world > 1:
+        # run the library on torch's current stream: E-step -> all-reduce -> M-step are then ordered
+        # on the device and the loop below never synchronises with the host
+        eng.set_stream(torch.cuda.current_stream().cuda_stream)
         p, n = eng.prepare_partial()
         acc_t = torch.as_tensor(DevArray(p, n), device=dev)
-        eng.sync()
         dist.all_reduce(acc_t)
-        torch.cuda.synchronize()
         eng.finish_prepare(0.0)
     else:
         eng.prepare(0.0)
@@ -98,9 +100,7 @@ def em_bench(args, rank, world, torch, dist):
             return
         for _ in range(k):
             eng.estep_partial()
-            eng.sync()
             dist.all_reduce(acc_t)
-            torch.cuda.synchronize()
             eng.finish_step(want_err=False)
         eng.sync()
 
@@ -214,9 +214,13 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: gbrs_amd has no CPU path")
+    local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        else:
+            dist.init_process_group(args.backend)
     import __graft_entry__
     if rank == 0:
         __graft_entry__.build()

@@ -348,6 +348,7 @@ using namespace gbrs;
 struct gbrs_em {
     int device = 0;
     hipStream_t stream = nullptr;
+    bool own_stream = true;
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr;
     uint64_t R = 0, N = 0;
     uint32_t L = 0, H = 0;
@@ -861,6 +862,16 @@ int gbrs_em_group_sums(gbrs_em_t *em, int64_t G, const int64_t *group_ptr, const
 
 void *gbrs_em_stream(gbrs_em_t *em) { return em ? (void *)em->stream : nullptr; }
 
+int gbrs_em_set_stream(gbrs_em_t *em, void *stream) {
+    if (!em) return fail(GBRS_ERR_INVALID, "handle is NULL");
+    GBRS_TRY(select_device(em->device));
+    GBRS_HIP_CHECK(hipStreamSynchronize(em->stream));
+    if (em->own_stream && em->stream) (void)hipStreamDestroy(em->stream);
+    em->stream = (hipStream_t)stream;
+    em->own_stream = false;
+    return GBRS_OK;
+}
+
 int gbrs_em_sync(gbrs_em_t *em) {
     if (!em) return fail(GBRS_ERR_INVALID, "handle is NULL");
     GBRS_HIP_CHECK(hipStreamSynchronize(em->stream));
@@ -950,7 +961,7 @@ int gbrs_em_destroy(gbrs_em_t *em) {
     if (em->ev1) (void)hipEventDestroy(em->ev1);
     if (em->ev2) (void)hipEventDestroy(em->ev2);
     for (auto e : em->ev_pool) (void)hipEventDestroy(e);
-    if (em->stream) (void)hipStreamDestroy(em->stream);
+    if (em->stream && em->own_stream) (void)hipStreamDestroy(em->stream);
     delete em;
     return GBRS_OK;
 }

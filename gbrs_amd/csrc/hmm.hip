@@ -194,9 +194,14 @@ forward_viterbi_kernel(int S, int64_t genes_per_sample, int64_t bp_per_sample,
         if (j == 0) SC[0] = -z;
     }
     int cur = 0;
+    // emission of the next gene is fetched one step ahead (the recursion is latency-bound: no
+    // global load may sit on the step's critical path)
+    double e_next = (active && q == 0 && n > 1) ? E[(int64_t)S + j] : 0.0;
     for (int i = 1; i <= n; ++i) {
         const bool real = i < n_steps;            // produces alpha_i / delta_i
         if (!real && !(i == n && phantom)) break;
+        const double e = e_next;
+        if (active && q == 0 && i + 1 < n) e_next = E[(int64_t)(i + 1) * S + j];
         double tc[KMAX];
 #pragma unroll
         for (int m = 0; m < KMAX; ++m) tc[m] = tn[m];
@@ -227,7 +232,6 @@ forward_viterbi_kernel(int S, int64_t genes_per_sample, int64_t bp_per_sample,
         if (active && q == 0) {
             BP[(int64_t)(i - 1) * S + j] = (uint16_t)best_k;
             if (real) {
-                const double e = E[(int64_t)i * S + j];
                 a_own = log(sum + TINY) + e;
                 d_own = best + e;
                 a_buf[nxt * S + j] = a_own;
@@ -300,10 +304,23 @@ backward_gamma_kernel(int S, int64_t genes_per_sample, const ChromDesc *__restri
         const double norm = wave_sum_lds(g_buf, S);
         if (active && q == 0) GA[(int64_t)(n - 1) * S + j] = g_own / norm;
     }
+    double e_nx = 0.0, al_nx = 0.0, sc_nx = n >= 2 ? SC[n - 2] : 0.0;
+    if (active && q == 0 && n >= 2) {
+        e_nx = E[(int64_t)(n - 2) * S + j];
+        al_nx = AL[(int64_t)(n - 2) * S + j];
+    }
     for (int i = n - 2; i >= 0; --i) {
         double tc[KMAX];
 #pragma unroll
         for (int m = 0; m < KMAX; ++m) tc[m] = tn[m];
+        const double e_i = e_nx, al_i = al_nx, sc = sc_nx;
+        if (i >= 1) {
+            sc_nx = SC[i - 1];
+            if (active && q == 0) {
+                e_nx = E[(int64_t)(i - 1) * S + j];
+                al_nx = AL[(int64_t)(i - 1) * S + j];
+            }
+        }
         if (i >= 1) {
             const double *Tn = Tt + (int64_t)(i - 1) * S * S;
 #pragma unroll
@@ -312,7 +329,6 @@ backward_gamma_kernel(int S, int64_t genes_per_sample, const ChromDesc *__restri
                 if (active && k < S) tn[m] = Tn[(int64_t)j * S + k];
             }
         }
-        const double sc = SC[i];
         const double *b_next = b_buf + cur * S, *e_next = e_buf + cur * S;
         double sum = 0.0;
 #pragma unroll
@@ -327,8 +343,8 @@ backward_gamma_kernel(int S, int64_t genes_per_sample, const ChromDesc *__restri
             const double b = log(sum);
             BE[o] = b;
             b_buf[nxt * S + j] = b;
-            e_buf[nxt * S + j] = E[o];
-            g_own = exp(AL[o] + b);
+            e_buf[nxt * S + j] = e_i;
+            g_own = exp(al_i + b);
             g_buf[nxt * S + j] = g_own;
         }
         __syncthreads();

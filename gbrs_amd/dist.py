@@ -75,7 +75,9 @@ class ShardedEM:
 
 
 def torch_allreduce(dist, torch, device):
-    """all-reduce closure over torch.distributed for a raw device pointer (HIP engine)."""
+    """all-reduce closure over torch.distributed for a raw device pointer (HIP engine).  Call
+    engine.set_stream(torch.cuda.current_stream().cuda_stream) first to drop the two
+    synchronisations below."""
     cache = {}
 
     class _Dev:

@@ -130,3 +130,6 @@ class EmEngine:
 
     def stream(self):
         return _lib.load().gbrs_em_stream(self._h)
+
+    def set_stream(self, stream_ptr):
+        _lib.check(_lib.load().gbrs_em_set_stream(self._h, stream_ptr))

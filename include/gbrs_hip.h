@@ -133,6 +133,10 @@ int gbrs_em_prepare_partial(gbrs_em_t *em, void **partial_dev, uint64_t *n_elems
 int gbrs_em_finish_prepare(gbrs_em_t *em, double pseudocount);
 /* The HIP stream (hipStream_t) the handle launches on, so the caller can order a collective. */
 void *gbrs_em_stream(gbrs_em_t *em);
+/* Launch on the caller's stream instead (e.g. torch's current stream, so that an RCCL all-reduce
+ * issued through torch.distributed is ordered with the E-step without host synchronisation).
+ * The caller keeps ownership of the stream. */
+int gbrs_em_set_stream(gbrs_em_t *em, void *stream);
 int gbrs_em_sync(gbrs_em_t *em);
 
 typedef struct gbrs_em_info {
