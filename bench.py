@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--cpu-rows", type=int, default=2_000_000)
     ap.add_argument("--cpu-iters", type=int, default=10)
     ap.add_argument("--hmm-samples", type=int, default=1)
+    ap.add_argument("--hmm-batch", type=int, default=64, help="second HMM measurement with this many samples in one launch (0 = skip)")
     ap.add_argument("--hmm-reps", type=int, default=5)
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo only to rehearse N>1 on one GPU)")
     return ap.parse_args()
@@ -152,13 +153,13 @@ def em_cpu_baseline(args):
                        f"{args.rows}-row workload; host has {os.cpu_count()} cores, reference is single-threaded")
 
 
-def hmm_bench(args, torch):
+def hmm_bench(args, torch, ns=None, with_cpu=True):
     import numpy as np
     from gbrs_amd import synth
     from gbrs_amd.hmm import DiplotypeHMM
     prob = synth.make_hmm_problem(H=8)
     chroms = prob.chroms
-    ns = args.hmm_samples
+    ns = args.hmm_samples if ns is None else ns
     hmm = DiplotypeHMM(8, chroms, [len(prob.gene_ids[c]) for c in chroms], [prob.tprob[c] for c in chroms],
                        device=torch.cuda.current_device())
     rng = np.random.default_rng(1)
@@ -194,7 +195,10 @@ def hmm_bench(args, torch):
                              frac=inf.algorithmic_bytes * ns / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=None,
                              note="sequential recursion over genes: latency-bound, not bandwidth-bound"))
     hmm.close()
-    if not args.no_cpu_baseline:
+    if with_cpu and args.hmm_batch > 0 and args.hmm_batch != ns:
+        b = hmm_bench(args, torch, ns=args.hmm_batch, with_cpu=False)
+        out["batched"] = {k: b[k] for k in ("value", "unit", "ms_per_pass", "n_samples", "kernels_ms", "roofline")}
+    if with_cpu and not args.no_cpu_baseline:
         from oracle import hmm_oracle
         sub = synth.make_hmm_problem(H=8, genes_per_chrom=[1500, 1500], seed=synth.SEED_HMM)
         t0 = time.perf_counter()

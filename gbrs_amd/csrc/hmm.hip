@@ -117,95 +117,225 @@ struct ChromDesc {
     int32_t n_genes, n_trans;
 };
 
-template <int LPS>
-__device__ __forceinline__ double group_sum(double v) {
-#pragma unroll
-    for (int off = LPS >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
+// ---- cross-lane helpers on DPP (no LDS crossbar on the recursion's critical path) ------------
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+constexpr int DPP_QUAD_XOR1 = 0xB1;      // quad_perm:[1,0,3,2]
+constexpr int DPP_QUAD_XOR2 = 0x4E;      // quad_perm:[2,3,0,1]
+constexpr int DPP_ROW_HALF_MIRROR = 0x141;
+constexpr int DPP_ROW_MIRROR = 0x140;
+
+// sum over the 4 lanes of a quad (LPS = 4 lanes per state); result in every lane of the quad
+__device__ __forceinline__ double quad_sum(double v) {
+    v += dpp_f64<DPP_QUAD_XOR1>(v);
+    v += dpp_f64<DPP_QUAD_XOR2>(v);
     return v;
 }
 
-template <int LPS>
-__device__ __forceinline__ void group_argmax(double &v, int &k) {
-#pragma unroll
-    for (int off = LPS >> 1; off > 0; off >>= 1) {
-        const double ov = __shfl_xor(v, off, WAVE);
-        const int ok = __shfl_xor(k, off, WAVE);
+// (max value, its lowest index) over the quad; ties keep the lower index (np.argmax)
+__device__ __forceinline__ void quad_argmax(double &v, int &k) {
+    {
+        const double ov = dpp_f64<DPP_QUAD_XOR1>(v);
+        const int ok = __builtin_amdgcn_update_dpp(k, k, DPP_QUAD_XOR1, 0xf, 0xf, false);
+        if (ov > v || (ov == v && ok < k)) { v = ov; k = ok; }
+    }
+    {
+        const double ov = dpp_f64<DPP_QUAD_XOR2>(v);
+        const int ok = __builtin_amdgcn_update_dpp(k, k, DPP_QUAD_XOR2, 0xf, 0xf, false);
         if (ov > v || (ov == v && ok < k)) { v = ov; k = ok; }
     }
 }
 
-// log(sum_j exp(x[j])) over the S values in LDS, computed redundantly by every wave (no barrier).
-__device__ __forceinline__ double wave_logsumexp_lds(const double *x, int S) {
-    double s = 0.0;
-    for (int j = threadIdx.x & 63; j < S; j += 64) s += exp(x[j]);
-    return log(wave_sum_all(s));
+// sum over all 64 lanes, same value in every lane: quad, half-row and row steps on DPP, the four
+// row totals through v_readlane
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+    v += dpp_f64<DPP_QUAD_XOR1>(v);
+    v += dpp_f64<DPP_QUAD_XOR2>(v);
+    v += dpp_f64<DPP_ROW_HALF_MIRROR>(v);
+    v += dpp_f64<DPP_ROW_MIRROR>(v);
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    double t = __hiloint2double(__builtin_amdgcn_readlane(hi, 0), __builtin_amdgcn_readlane(lo, 0));
+    t += __hiloint2double(__builtin_amdgcn_readlane(hi, 16), __builtin_amdgcn_readlane(lo, 16));
+    t += __hiloint2double(__builtin_amdgcn_readlane(hi, 32), __builtin_amdgcn_readlane(lo, 32));
+    t += __hiloint2double(__builtin_amdgcn_readlane(hi, 48), __builtin_amdgcn_readlane(lo, 48));
+    return t;
 }
+
+// sum of the S values of an LDS vector, computed redundantly by every wave (no extra barrier)
 __device__ __forceinline__ double wave_sum_lds(const double *x, int S) {
     double s = 0.0;
     for (int j = threadIdx.x & 63; j < S; j += 64) s += x[j];
-    return wave_sum_all(s);
+    return wave_sum_dpp(s);
 }
 
-template <int LPS, int KMAX, int MAXT>
+// P = exp(T) (forward) and its per-block transpose (backward), made once per transition table:
+// the tables are sample independent, so every sample and every later call reuses them.
+__global__ void exp_blocks_kernel(int S, int64_t n_blocks, const double *__restrict__ t,
+                                  double *__restrict__ p, double *__restrict__ pt) {
+    const int64_t total = n_blocks * S * S;
+    for (int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; x < total;
+         x += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = x / ((int64_t)S * S);
+        const int r = (int)(x - b * S * S);
+        const int jj = r / S, kk = r % S;
+        const double v = exp(t[x]);
+        p[x] = v;
+        pt[b * S * S + (int64_t)kk * S + jj] = v;
+    }
+}
+
+__device__ __forceinline__ double fast_recip_pos(double d) {
+    double r = __builtin_amdgcn_rcp(d);
+    double e = fma(-d, r, 1.0);
+    r = fma(r, e, r);
+    e = fma(-d, r, 1.0);
+    return fma(r, e, r);
+}
+
+// pe = exp(eprob): every gene at once, before the sequential sweeps
+__global__ void exp_emission_kernel(int64_t n, const double *__restrict__ e, double *__restrict__ pe) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) pe[i] = exp(e[i]);
+}
+
+// Forward + Viterbi (gbrs_utils.py:500-526, :567-579), one workgroup per (chromosome, sample,
+// role): role 0 runs the alpha recursion, role 1 the delta/backpointer recursion; the two chains
+// only share the transition tables, so they run side by side on different CUs.
+//
+// alpha: the reference's step  alpha_i[j] = log(sum_k exp(alpha_{i-1}[k] + T[j,k]) + tiny) + e_i[j],
+// alpha_i -= log(sum_j exp(alpha_i[j]))  is carried in the probability domain so that no exp/log
+// and no global load sits on the sequential critical path:
+//     x_j = (sum_k y_{i-1}[k] * P[j,k]) / Z_{i-1} + tiny        P = exp(T), precomputed
+//     y_j = x_j * pe_i[j]                Z_i = sum_j y_j         pe = exp(e), precomputed
+// The kernel stores x, alpha-hat = y/Z and 1/Z; hmm_outputs_kernel turns them into the
+// log-domain alpha and scaler of the reference (same quantities up to rounding) in parallel.
+// delta stays in the log domain on T itself: additions and max only, i.e. exact.
+template <int KMAX, int MAXT>
 __global__ void __launch_bounds__(MAXT)
 forward_viterbi_kernel(int S, int64_t genes_per_sample, int64_t bp_per_sample,
                        const ChromDesc *__restrict__ chroms, const double *__restrict__ tprob,
-                       const double *__restrict__ eprob, const double *__restrict__ init_vec,
-                       double *__restrict__ alpha, double *__restrict__ scaler,
+                       const double *__restrict__ pprob, const double *__restrict__ eprob,
+                       const double *__restrict__ peprob, const double *__restrict__ init_vec,
+                       double *__restrict__ xsum, double *__restrict__ ahat, double *__restrict__ invz,
                        double *__restrict__ delta, uint16_t *__restrict__ bp,
                        int32_t *__restrict__ last_state) {
-    extern __shared__ double lds[];           // a[2][S], d[2][S]
+    constexpr int LPS = 4;
+    extern __shared__ double lds[];           // v[2][S]
     const ChromDesc cd = chroms[blockIdx.x];
     const int sample = blockIdx.y;
+    const int role = blockIdx.z;
     const int n = cd.n_genes;
     if (n <= 0) return;
     const int j = threadIdx.x / LPS, q = threadIdx.x % LPS;
     const bool active = j < S;
+    const bool owner = active && q == 0;
     const int64_t g0 = (int64_t)sample * genes_per_sample + cd.gene_off;
+    const int n_steps = min(n, cd.n_trans + 1);   // gene i needs T[i-1]
+    double *buf = lds;
+    int cur = 0;
+
+    if (role == 0) {
+        const double *E = eprob + g0 * S, *PE = peprob + g0 * S;
+        double *XS = xsum + g0 * S, *AH = ahat + g0 * S, *IZ = invz + g0;
+        const double *P = pprob + cd.trans_off * (int64_t)S * S;
+        double y_own = 0.0;
+        if (owner) {
+            const double a0 = init_vec[j] + E[j];
+            y_own = exp(a0);
+            buf[j] = y_own;
+            XS[j] = exp(init_vec[j]);             // so that log(x) + e reproduces init + e
+        }
+        double pn[KMAX];
+#pragma unroll
+        for (int m = 0; m < KMAX; ++m) {
+            const int k = q + LPS * m;
+            pn[m] = (active && k < S && cd.n_trans > 0) ? P[(int64_t)j * S + k] : 0.0;
+        }
+        double pe_next = (owner && n > 1) ? PE[(int64_t)S + j] : 0.0;
+        __syncthreads();
+        double inv_z = fast_recip_pos(wave_sum_lds(buf, S));
+        if (owner) {
+            AH[j] = y_own * inv_z;
+            if (j == 0) IZ[0] = inv_z;
+        }
+        for (int i = 1; i < n_steps; ++i) {
+            const double pe = pe_next;
+            if (owner && i + 1 < n) pe_next = PE[(int64_t)(i + 1) * S + j];
+            double pc[KMAX];
+#pragma unroll
+            for (int m = 0; m < KMAX; ++m) pc[m] = pn[m];
+            if (i < cd.n_trans) {                 // prefetch P[i] for the next step
+                const double *Pn = P + (int64_t)i * S * S;
+#pragma unroll
+                for (int m = 0; m < KMAX; ++m) {
+                    const int k = q + LPS * m;
+                    if (active && k < S) pn[m] = Pn[(int64_t)j * S + k];
+                }
+            }
+            const double *y_prev = buf + cur * S;
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+#pragma unroll
+            for (int m = 0; m < KMAX; ++m) {
+                const int k = q + LPS * m;
+                if (active && k < S) {
+                    const double yp = y_prev[k];
+                    if (m % 3 == 0) s0 = fma(yp, pc[m], s0);
+                    else if (m % 3 == 1) s1 = fma(yp, pc[m], s1);
+                    else s2 = fma(yp, pc[m], s2);
+                }
+            }
+            const double x = quad_sum((s0 + s1) + s2) * inv_z + TINY;
+            const int nxt = cur ^ 1;
+            if (owner) {
+                y_own = x * pe;
+                buf[nxt * S + j] = y_own;
+                XS[(int64_t)i * S + j] = x;
+            }
+            __syncthreads();
+            cur = nxt;
+            inv_z = fast_recip_pos(wave_sum_lds(buf + cur * S, S));
+            if (owner) {
+                AH[(int64_t)i * S + j] = y_own * inv_z;
+                if (j == 0) IZ[i] = inv_z;
+            }
+        }
+        return;
+    }
+
+    // role 1: Viterbi
     const double *E = eprob + g0 * S;
-    double *AL = alpha + g0 * S, *DL = delta + g0 * S, *SC = scaler + g0;
+    double *DL = delta + g0 * S;
     uint16_t *BP = bp + ((int64_t)sample * bp_per_sample + cd.bp_off) * S;
     const double *T = tprob + cd.trans_off * (int64_t)S * S;
-    double *a_buf = lds, *d_buf = lds + 2 * S;
-
-    // step 0
-    double a_own = 0.0, d_own = 0.0;      // unnormalised alpha / delta of state j (q == 0 lanes)
-    if (active && q == 0) {
-        const double v = init_vec[j] + E[j];
-        a_own = v;
-        d_own = v;
-        a_buf[j] = v;
-        d_buf[j] = v;
-        DL[j] = v;
-    }
-    // prefetch transition block 0
-    double tn[KMAX];
-    const int n_steps = min(n, cd.n_trans + 1);   // gene i needs T[i-1]
     const bool phantom = cd.n_trans >= n;         // one more max-step with T[n-1] (backtrace quirk)
+    double d_own = 0.0;
+    if (owner) {
+        d_own = init_vec[j] + E[j];
+        buf[j] = d_own;
+        DL[j] = d_own;
+    }
+    double tn[KMAX];
 #pragma unroll
     for (int m = 0; m < KMAX; ++m) {
         const int k = q + LPS * m;
         tn[m] = (active && k < S && cd.n_trans > 0) ? T[(int64_t)j * S + k] : 0.0;
     }
+    double e_next = (owner && n > 1) ? E[(int64_t)S + j] : 0.0;
     __syncthreads();
-    double z = wave_logsumexp_lds(a_buf, S);
-    if (active && q == 0) {
-        AL[j] = a_own - z;
-        if (j == 0) SC[0] = -z;
-    }
-    int cur = 0;
-    // emission of the next gene is fetched one step ahead (the recursion is latency-bound: no
-    // global load may sit on the step's critical path)
-    double e_next = (active && q == 0 && n > 1) ? E[(int64_t)S + j] : 0.0;
     for (int i = 1; i <= n; ++i) {
-        const bool real = i < n_steps;            // produces alpha_i / delta_i
+        const bool real = i < n_steps;            // produces delta_i
         if (!real && !(i == n && phantom)) break;
         const double e = e_next;
-        if (active && q == 0 && i + 1 < n) e_next = E[(int64_t)(i + 1) * S + j];
+        if (owner && i + 1 < n) e_next = E[(int64_t)(i + 1) * S + j];
         double tc[KMAX];
 #pragma unroll
         for (int m = 0; m < KMAX; ++m) tc[m] = tn[m];
-        if (i < cd.n_trans) {                     // prefetch T[i] for the next step
+        if (i < cd.n_trans) {
             const double *Tn = T + (int64_t)i * S * S;
 #pragma unroll
             for (int m = 0; m < KMAX; ++m) {
@@ -213,40 +343,30 @@ forward_viterbi_kernel(int S, int64_t genes_per_sample, int64_t bp_per_sample,
                 if (active && k < S) tn[m] = Tn[(int64_t)j * S + k];
             }
         }
-        const double *a_prev = a_buf + cur * S, *d_prev = d_buf + cur * S;
-        double sum = 0.0, best = -DBL_MAX;
+        const double *d_prev = buf + cur * S;
+        double best = -DBL_MAX;
         int best_k = 0x7fffffff;
 #pragma unroll
         for (int m = 0; m < KMAX; ++m) {
             const int k = q + LPS * m;
             if (active && k < S) {
-                const double t = tc[m];
-                if (real) sum += exp((a_prev[k] - z) + t);
-                const double dv = d_prev[k] + t;
+                const double dv = d_prev[k] + tc[m];
                 if (dv > best) { best = dv; best_k = k; }   // ascending k: first max kept
             }
         }
-        sum = group_sum<LPS>(sum);
-        group_argmax<LPS>(best, best_k);
+        quad_argmax(best, best_k);
         const int nxt = cur ^ 1;
-        if (active && q == 0) {
+        if (owner) {
             BP[(int64_t)(i - 1) * S + j] = (uint16_t)best_k;
             if (real) {
-                a_own = log(sum + TINY) + e;
                 d_own = best + e;
-                a_buf[nxt * S + j] = a_own;
-                d_buf[nxt * S + j] = d_own;
+                buf[nxt * S + j] = d_own;
                 DL[(int64_t)i * S + j] = d_own;
             }
         }
         if (!real) break;
         __syncthreads();
         cur = nxt;
-        z = wave_logsumexp_lds(a_buf + cur * S, S);
-        if (active && q == 0) {
-            AL[(int64_t)i * S + j] = a_own - z;
-            if (j == 0) SC[i] = -z;
-        }
     }
     // sid = argmax delta[:, n-1] (first max)
     __syncthreads();
@@ -260,97 +380,104 @@ forward_viterbi_kernel(int S, int64_t genes_per_sample, int64_t bp_per_sample,
     }
 }
 
-// Backward + posterior.  tprob_t holds the transposed blocks: Tt[i][j][k] = T[i][k][j].
-template <int LPS, int KMAX, int MAXT>
+// Backward (gbrs_utils.py:530-550) in the probability domain:
+//     bhat_i[j] = (sum_k P_i[k,j] * bhat_{i+1}[k] * pe_{i+1}[k]) / Z_i          bhat_{n-1} = 1/Z_{n-1}
+// pprob_t holds the transposed blocks Pt[i][j][k] = exp(T[i][k][j]) so that a thread reads a row.
+// beta = log(bhat) and the posterior are produced by hmm_outputs_kernel.
+template <int KMAX, int MAXT>
 __global__ void __launch_bounds__(MAXT)
-backward_gamma_kernel(int S, int64_t genes_per_sample, const ChromDesc *__restrict__ chroms,
-                      const double *__restrict__ tprob_t, const double *__restrict__ eprob,
-                      const double *__restrict__ alpha, const double *__restrict__ scaler,
-                      double *__restrict__ beta, double *__restrict__ gamma) {
-    extern __shared__ double lds[];           // b[2][S], e[2][S], g[2][S]
+backward_kernel(int S, int64_t genes_per_sample, const ChromDesc *__restrict__ chroms,
+                const double *__restrict__ pprob_t, const double *__restrict__ peprob,
+                const double *__restrict__ invz, double *__restrict__ bhat) {
+    constexpr int LPS = 4;
+    extern __shared__ double lds[];           // w[2][S]
     const ChromDesc cd = chroms[blockIdx.x];
     const int sample = blockIdx.y;
     const int n = cd.n_genes;
     if (n <= 0) return;
     const int j = threadIdx.x / LPS, q = threadIdx.x % LPS;
     const bool active = j < S;
+    const bool owner = active && q == 0;
     const int64_t g0 = (int64_t)sample * genes_per_sample + cd.gene_off;
-    const double *E = eprob + g0 * S, *AL = alpha + g0 * S, *SC = scaler + g0;
-    double *BE = beta + g0 * S, *GA = gamma + g0 * S;
-    const double *Tt = tprob_t + cd.trans_off * (int64_t)S * S;
-    double *b_buf = lds, *e_buf = lds + 2 * S, *g_buf = lds + 4 * S;
+    const double *PE = peprob + g0 * S, *IZ = invz + g0;
+    double *BH = bhat + g0 * S;
+    const double *Pt = pprob_t + cd.trans_off * (int64_t)S * S;
+    double *w_buf = lds;
 
-    // The reference indexes tprob[c][i] for i = n-2 .. 0, so it needs n_trans >= n-1
-    // (checked on the host).
+    // The reference indexes tprob[c][i] for i = n-2 .. 0, so it needs n_trans >= n-1 (host check).
     int cur = 0;
-    double g_own = 0.0;
-    if (active && q == 0) {
+    if (owner) {
         const int64_t o = (int64_t)(n - 1) * S + j;
-        const double b = SC[n - 1];
-        BE[o] = b;
-        b_buf[j] = b;
-        e_buf[j] = E[o];
-        g_own = exp(AL[o] + b);
-        g_buf[j] = g_own;
+        const double bh = IZ[n - 1];                       // exp(scaler[n-1])
+        BH[o] = bh;
+        w_buf[j] = bh * PE[o];
     }
     double tn[KMAX];
 #pragma unroll
     for (int m = 0; m < KMAX; ++m) {
         const int k = q + LPS * m;
-        tn[m] = (active && k < S && n >= 2) ? Tt[((int64_t)(n - 2) * S + j) * S + k] : 0.0;
+        tn[m] = (active && k < S && n >= 2) ? Pt[((int64_t)(n - 2) * S + j) * S + k] : 0.0;
     }
+    double pe_nx = (owner && n >= 2) ? PE[(int64_t)(n - 2) * S + j] : 0.0;
+    double iz_nx = n >= 2 ? IZ[n - 2] : 0.0;
     __syncthreads();
-    {
-        const double norm = wave_sum_lds(g_buf, S);
-        if (active && q == 0) GA[(int64_t)(n - 1) * S + j] = g_own / norm;
-    }
-    double e_nx = 0.0, al_nx = 0.0, sc_nx = n >= 2 ? SC[n - 2] : 0.0;
-    if (active && q == 0 && n >= 2) {
-        e_nx = E[(int64_t)(n - 2) * S + j];
-        al_nx = AL[(int64_t)(n - 2) * S + j];
-    }
     for (int i = n - 2; i >= 0; --i) {
         double tc[KMAX];
 #pragma unroll
         for (int m = 0; m < KMAX; ++m) tc[m] = tn[m];
-        const double e_i = e_nx, al_i = al_nx, sc = sc_nx;
+        const double pe = pe_nx, iz = iz_nx;
         if (i >= 1) {
-            sc_nx = SC[i - 1];
-            if (active && q == 0) {
-                e_nx = E[(int64_t)(i - 1) * S + j];
-                al_nx = AL[(int64_t)(i - 1) * S + j];
-            }
-        }
-        if (i >= 1) {
-            const double *Tn = Tt + (int64_t)(i - 1) * S * S;
+            iz_nx = IZ[i - 1];
+            if (owner) pe_nx = PE[(int64_t)(i - 1) * S + j];
+            const double *Tn = Pt + (int64_t)(i - 1) * S * S;
 #pragma unroll
             for (int m = 0; m < KMAX; ++m) {
                 const int k = q + LPS * m;
                 if (active && k < S) tn[m] = Tn[(int64_t)j * S + k];
             }
         }
-        const double *b_next = b_buf + cur * S, *e_next = e_buf + cur * S;
-        double sum = 0.0;
+        const double *w_next = w_buf + cur * S;
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0;
 #pragma unroll
         for (int m = 0; m < KMAX; ++m) {
             const int k = q + LPS * m;
-            if (active && k < S) sum += exp(((tc[m] + b_next[k]) + e_next[k]) + sc);
+            if (active && k < S) {
+                const double wv = w_next[k];
+                if (m % 3 == 0) s0 = fma(wv, tc[m], s0);
+                else if (m % 3 == 1) s1 = fma(wv, tc[m], s1);
+                else s2 = fma(wv, tc[m], s2);
+            }
         }
-        sum = group_sum<LPS>(sum);
+        const double bh = quad_sum((s0 + s1) + s2) * iz;
         const int nxt = cur ^ 1;
-        if (active && q == 0) {
-            const int64_t o = (int64_t)i * S + j;
-            const double b = log(sum);
-            BE[o] = b;
-            b_buf[nxt * S + j] = b;
-            e_buf[nxt * S + j] = e_i;
-            g_own = exp(al_i + b);
-            g_buf[nxt * S + j] = g_own;
+        if (owner) {
+            w_buf[nxt * S + j] = bh * pe;
+            BH[(int64_t)i * S + j] = bh;
         }
         __syncthreads();
         cur = nxt;
-        const double norm = wave_sum_lds(g_buf + cur * S, S);
-        if (active && q == 0) GA[(int64_t)i * S + j] = g_own / norm;
+    }
+}
+
+// Log-domain outputs of the reference from the probability-domain sweeps, one thread per
+// (sample, gene):  alpha = log(x) + e - log(Z), scaler = -log(Z), beta = log(bhat),
+// gamma = ahat*bhat / sum_j(ahat*bhat)  (gbrs_utils.py:515-524, :542-549, :558-560).
+__global__ void __launch_bounds__(64)
+hmm_outputs_kernel(int S, int64_t n_rows, const double *__restrict__ eprob, const double *__restrict__ xsum,
+                   const double *__restrict__ ahat, const double *__restrict__ invz,
+                   const double *__restrict__ bhat, double *__restrict__ alpha, double *__restrict__ scaler,
+                   double *__restrict__ beta, double *__restrict__ gamma) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    const double lz = -log(invz[r]);
+    scaler[r] = -lz;
+    const int64_t o = r * S;
+    double norm = 0.0;
+    for (int s = 0; s < S; ++s) norm += ahat[o + s] * bhat[o + s];
+    for (int s = 0; s < S; ++s) {
+        alpha[o + s] = (log(xsum[o + s]) + eprob[o + s]) - lz;
+        beta[o + s] = log(bhat[o + s]);
+        gamma[o + s] = ahat[o + s] * bhat[o + s] / norm;
     }
 }
 
@@ -396,18 +523,6 @@ backtrace_kernel(int S, int BT_CHUNK, int64_t genes_per_sample, int64_t bp_per_s
     }
 }
 
-__global__ void transpose_blocks_kernel(int S, int64_t n_blocks, const double *__restrict__ src,
-                                        double *__restrict__ dst) {
-    const int64_t total = n_blocks * S * S;
-    for (int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; x < total;
-         x += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t b = x / ((int64_t)S * S);
-        const int r = (int)(x - b * S * S);
-        const int jj = r / S, kk = r % S;
-        dst[x] = src[b * S * S + (int64_t)kk * S + jj];
-    }
-}
-
 }  // namespace gbrs
 
 using namespace gbrs;
@@ -421,8 +536,8 @@ struct gbrs_hmm {
     int64_t total_genes = 0, total_trans = 0, total_bp = 0;
     bool have_eprob = false, ran = false;
     DevBuf<ChromDesc> d_chroms;
-    DevBuf<double> tprob, tprob_t, init_vec;
-    DevBuf<double> expr, avecs, eprob, alpha, beta, gamma, delta, scaler;
+    DevBuf<double> tprob, pprob, pprob_t, init_vec;   // log T, exp(T), exp(T) transposed per block
+    DevBuf<double> expr, avecs, eprob, peprob, xsum, bhat, alpha, ahat, beta, gamma, delta, scaler, invz;
     DevBuf<uint8_t> has_avec;
     DevBuf<uint16_t> bp;
     DevBuf<int32_t> last_state, states, calls;
@@ -436,6 +551,11 @@ int hmm_alloc_samples(gbrs_hmm *h, int n_samples) {
     const size_t gs = (size_t)h->total_genes * n_samples;
     GBRS_TRY(h->eprob.alloc(gs * h->S));
     GBRS_TRY(h->alpha.alloc(gs * h->S));
+    GBRS_TRY(h->ahat.alloc(gs * h->S));
+    GBRS_TRY(h->peprob.alloc(gs * h->S));
+    GBRS_TRY(h->xsum.alloc(gs * h->S));
+    GBRS_TRY(h->bhat.alloc(gs * h->S));
+    GBRS_TRY(h->invz.alloc(gs));
     GBRS_TRY(h->beta.alloc(gs * h->S));
     GBRS_TRY(h->gamma.alloc(gs * h->S));
     GBRS_TRY(h->delta.alloc(gs * h->S));
@@ -448,22 +568,28 @@ int hmm_alloc_samples(gbrs_hmm *h, int n_samples) {
     return GBRS_OK;
 }
 
-template <int LPS, int KMAX, int MAXT>
+template <int KMAX, int MAXT>
 int hmm_launch(gbrs_hmm *h) {
     const int S = h->S;
-    const int threads = ((S * LPS + 63) / 64) * 64;
-    dim3 grid(h->n_chrom, h->n_samples);
+    const int threads = ((S * 4 + 63) / 64) * 64;
+    const int64_t rows = h->total_genes * h->n_samples;
     GBRS_HIP_CHECK(hipEventRecord(h->ev[1], h->stream));
-    hipLaunchKernelGGL((forward_viterbi_kernel<LPS, KMAX, MAXT>), grid, dim3(threads), 4 * S * sizeof(double),
-                       h->stream, S, h->total_genes, h->total_bp, h->d_chroms.p, h->tprob.p, h->eprob.p,
-                       h->init_vec.p, h->alpha.p, h->scaler.p, h->delta.p, h->bp.p, h->last_state.p);
+    hipLaunchKernelGGL(exp_emission_kernel, dim3((unsigned)((rows * S + 255) / 256)), dim3(256), 0, h->stream,
+                       rows * S, h->eprob.p, h->peprob.p);
+    hipLaunchKernelGGL((forward_viterbi_kernel<KMAX, MAXT>), dim3(h->n_chrom, h->n_samples, 2), dim3(threads),
+                       2 * S * sizeof(double), h->stream, S, h->total_genes, h->total_bp, h->d_chroms.p,
+                       h->tprob.p, h->pprob.p, h->eprob.p, h->peprob.p, h->init_vec.p, h->xsum.p, h->ahat.p,
+                       h->invz.p, h->delta.p, h->bp.p, h->last_state.p);
     GBRS_HIP_CHECK(hipEventRecord(h->ev[2], h->stream));
-    hipLaunchKernelGGL((backward_gamma_kernel<LPS, KMAX, MAXT>), grid, dim3(threads), 6 * S * sizeof(double),
-                       h->stream, S, h->total_genes, h->d_chroms.p, h->tprob_t.p, h->eprob.p, h->alpha.p,
-                       h->scaler.p, h->beta.p, h->gamma.p);
+    hipLaunchKernelGGL((backward_kernel<KMAX, MAXT>), dim3(h->n_chrom, h->n_samples), dim3(threads),
+                       2 * S * sizeof(double), h->stream, S, h->total_genes, h->d_chroms.p, h->pprob_t.p,
+                       h->peprob.p, h->invz.p, h->bhat.p);
+    hipLaunchKernelGGL(hmm_outputs_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, h->stream, S, rows,
+                       h->eprob.p, h->xsum.p, h->ahat.p, h->invz.p, h->bhat.p, h->alpha.p, h->scaler.p, h->beta.p,
+                       h->gamma.p);
     GBRS_HIP_CHECK(hipEventRecord(h->ev[3], h->stream));
     const int bt_chunk = std::max(1, std::min(512, 32768 / S));   // <= 64 KiB of staged backpointers
-    hipLaunchKernelGGL(backtrace_kernel, grid, dim3(256), (size_t)bt_chunk * S * sizeof(uint16_t), h->stream,
+    hipLaunchKernelGGL(backtrace_kernel, dim3(h->n_chrom, h->n_samples), dim3(256), (size_t)bt_chunk * S * sizeof(uint16_t), h->stream,
                        S, bt_chunk, h->total_genes, h->total_bp, h->total_genes + h->n_chrom, h->n_chrom,
                        h->d_chroms.p, h->bp.p, h->last_state.p, h->states.p, h->calls.p);
     GBRS_HIP_CHECK(hipEventRecord(h->ev[4], h->stream));
@@ -518,14 +644,15 @@ int gbrs_hmm_create(int num_haps, int n_chrom, const int32_t *n_genes, const int
     GBRS_HIP_CHECK(hipMemcpy(h->d_chroms.p, h->chroms.data(), n_chrom * sizeof(ChromDesc), hipMemcpyHostToDevice));
     const size_t blk = (size_t)S * S;
     GBRS_TRY(h->tprob.alloc(std::max<size_t>(h->total_trans * blk, 1)));
-    GBRS_TRY(h->tprob_t.alloc(std::max<size_t>(h->total_trans * blk, 1)));
+    GBRS_TRY(h->pprob.alloc(std::max<size_t>(h->total_trans * blk, 1)));
+    GBRS_TRY(h->pprob_t.alloc(std::max<size_t>(h->total_trans * blk, 1)));
     for (int c = 0; c < n_chrom; ++c)
         if (n_trans[c] > 0)
             GBRS_HIP_CHECK(hipMemcpy(h->tprob.p + h->chroms[c].trans_off * blk, tprob[c],
                                      (size_t)n_trans[c] * blk * sizeof(double), hipMemcpyHostToDevice));
     if (h->total_trans > 0)
-        hipLaunchKernelGGL(transpose_blocks_kernel, dim3(2048), dim3(256), 0, h->stream, S, h->total_trans,
-                           h->tprob.p, h->tprob_t.p);
+        hipLaunchKernelGGL(exp_blocks_kernel, dim3(2048), dim3(256), 0, h->stream, S, h->total_trans,
+                           h->tprob.p, h->pprob.p, h->pprob_t.p);
     // init_vec (gbrs_utils.py:465-471): log(1/H^2) homozygous, log(2/H^2) heterozygous
     std::vector<double> iv;
     for (int a = 0; a < num_haps; ++a)
@@ -599,9 +726,9 @@ int gbrs_hmm_run(gbrs_hmm_t *h) {
     GBRS_TRY(select_device(h->device));
     const int S = h->S;
     int rc;
-    if (S <= 48) rc = hmm_launch<16, 3, 768>(h);
-    else if (S <= 64) rc = hmm_launch<16, 4, 1024>(h);
-    else rc = hmm_launch<4, 34, 576>(h);      // S <= 136 (MAX_H = 16)
+    if (S <= 48) rc = hmm_launch<12, 192>(h);          // 4 lanes per state, KMAX = ceil(S / 4)
+    else if (S <= 64) rc = hmm_launch<16, 256>(h);
+    else rc = hmm_launch<34, 576>(h);                   // S <= 136 (MAX_H = 16)
     if (rc == GBRS_OK) h->ran = true;
     return rc;
 }
