@@ -32,7 +32,7 @@ struct EmScalars {          // lives in device memory, one per handle
     int pad;
 };
 
-constexpr int RED_BLOCKS = 4096;  // partial slots of the two-level deterministic reductions
+constexpr int RED_BLOCKS = 1024;  // partial slots of the two-level deterministic reductions
 constexpr int RED_THREADS = 256;
 
 // theta' = theta * A / len, counts = theta * A, per-locus totals before and after, block partials.
