@@ -398,12 +398,11 @@ int em_estep_tiles_h(gbrs_em *em) {
         const dim3 grid((unsigned)tl.n_tiles), block(TILE_THREADS);
         if (tl.weighted)
             hipLaunchKernelGGL((tile_estep_kernel<HT, true, ONES>), grid, block, 0, em->stream, em->H, tl.tiles.p,
-                               tl.words.p, tl.dict.p, tl.batch_row.p, tl.row_weight.p, em->theta.p, tl.partials.p,
-                               em->scalars.p);
+                               tl.words.p, tl.dict.p, tl.word_weight.p, em->theta.p, tl.partials.p, em->scalars.p);
         else
             hipLaunchKernelGGL((tile_estep_kernel<HT, false, ONES>), grid, block, 0, em->stream, em->H, tl.tiles.p,
-                               tl.words.p, tl.dict.p, (const uint32_t *)nullptr, (const double *)nullptr, em->theta.p,
-                               tl.partials.p, em->scalars.p);
+                               tl.words.p, tl.dict.p, (const double *)nullptr, em->theta.p, tl.partials.p,
+                               em->scalars.p);
     }
     return GBRS_OK;
 }
@@ -901,7 +900,7 @@ int gbrs_em_info(gbrs_em_t *em, gbrs_em_info_t *info) {
         // [row weights]; gather: slot index + partials read back + acc store; M-step etc.: 5 H*L vectors
         info->bytes_per_iter = 4 * tl.n_batches * 64 + 16 * tl.n_tiles + 4 * tl.n_slots +
                                8 * tl.n_slots * em->H * 3 + 4 * tl.n_slots + 4 * ((uint64_t)em->L + 1) +
-                               (tl.weighted ? 4 * tl.n_batches + 8 * tl.n_rows : 0) + 8 * HL * 6;
+                               (tl.weighted ? 8 * tl.n_batches * 64 : 0) + 8 * HL * 6;
     }
     info->last_estep_ms = em->last_estep_ms;
     info->last_step_ms = em->last_step_ms;

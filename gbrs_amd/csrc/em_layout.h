@@ -51,8 +51,8 @@ struct TileLayout {
     DevBuf<uint32_t> words;          // n_batches * 64
     DevBuf<TileHdr> tiles;           // n_tiles
     DevBuf<uint32_t> dict;           // n_slots: global locus of each slot
-    DevBuf<uint32_t> batch_row;      // n_batches: ordinal of the first row of each batch (weighted)
-    DevBuf<double> row_weight;       // n_rows (weighted)
+    DevBuf<double> word_weight;      // n_batches * 64 (weighted): the row's weight on each of its words
+    DevBuf<double> row_weight;       // n_rows (weighted; build-time only)
     DevBuf<uint32_t> slot_ptr;       // L + 1
     DevBuf<uint32_t> slot_list;      // n_slots, grouped by locus, ascending slot inside a locus
     DevBuf<uint32_t> heavy_loci;     // loci with more than HEAVY_SLOTS slots

@@ -389,7 +389,7 @@ __global__ void emit_words_kernel(uint64_t m_rows, uint32_t H, const uint32_t *_
                                   const uint32_t *__restrict__ hrow, const uint32_t *__restrict__ rowstart,
                                   const uint32_t *__restrict__ ploc, const uint32_t *__restrict__ pmask,
                                   const uint32_t *__restrict__ rowpad, uint32_t *__restrict__ words,
-                                  uint32_t *__restrict__ batch_row) {
+                                  const double *__restrict__ row_weight, double *__restrict__ word_weight) {
     const uint64_t m = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (m >= m_rows) return;
     const TileHdr th = hdr[tincl[m] - 1];
@@ -406,8 +406,8 @@ __global__ void emit_words_kernel(uint64_t m_rows, uint32_t H, const uint32_t *_
             if (d[mid] < l) lo = mid + 1; else hi = mid;
         }
         words[base + j] = pmask[p0 + j] | (j << H) | ((cnt - 1 - j) << (H + PB)) | (lo << (H + 2 * PB));
+        if (word_weight) word_weight[base + j] = row_weight[m];
     }
-    if (batch_row && (off & 63u) == 0) batch_row[th.batch_base + (off >> 6)] = (uint32_t)m;
 }
 
 __global__ void iota_kernel(uint64_t n, uint32_t *__restrict__ v) {
@@ -741,14 +741,19 @@ int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L, uint32_t H, uint6
     // 10. words
     GBRS_TRY(out.words.alloc((size_t)NB * 64));
     GBRS_HIP_CHECK(hipMemsetAsync(out.words.p, 0, out.words.bytes(), s));
-    if (out.weighted) GBRS_TRY(out.batch_row.alloc(NB));
+    if (out.weighted) {
+        GBRS_TRY(out.word_weight.alloc((size_t)NB * 64));
+        GBRS_HIP_CHECK(hipMemsetAsync(out.word_weight.p, 0, out.word_weight.bytes(), s));
+    }
     hipLaunchKernelGGL(emit_words_kernel, dim3(grid_for(M)), dim3(256), 0, s, M, H, tincl.p, out.tiles.p, out.dict.p,
                        hrow.p, rowstart.p, ploc.p, pmask.p, rowpad.p, out.words.p,
-                       out.weighted ? out.batch_row.p : nullptr);
+                       out.weighted ? out.row_weight.p : (const double *)nullptr,
+                       out.weighted ? out.word_weight.p : (double *)nullptr);
     GBRS_HIP_CHECK(hipStreamSynchronize(s));
     tmpdict.release(); dcount.release(); dict_base.release(); batch_base.release(); nbatch.release();
     rowpad.release(); tincl.release(); npm.release(); wordoff.release(); tile_row.release();
     hrow.release(); rowstart.release(); ploc.release(); pmask.release();
+    out.row_weight.release();
     // 11. inverted index locus -> slots (ascending slot inside a locus: radix sort is stable)
     GBRS_TRY(out.slot_list.alloc(std::max<uint32_t>(NS, 1)));
     if (NS) {
