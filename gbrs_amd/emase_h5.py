@@ -1,0 +1,345 @@
+"""EMASE alignment files in the PyTables/HDF5 layout, read and written through libhdf5 (ctypes).
+
+Layout, as written by the reference (emase/Sparse3DMatrix.py:400-444,
+emase/AlignmentPropertyMatrix.py:478-525; second writer emase/AlignmentMatrixFactory.py:84-142):
+
+    /                attrs  incidence_only (bool)  mtype = 'csc_matrix'  shape = (L, H, R)  hname = [..]
+    /h0 .. /h{H-1}   groups with CArrays  indptr uint32[L+1], indices uint32[nnz] (row ids), [data]
+    /count           float64[R]  (EC multiplicities, optional)
+    /lname           fixed-length byte strings [L];   /rname optional
+    all arrays chunked + zlib level 1
+
+PyTables stores tuple/list attributes as pickled byte strings and scalars natively.  Neither
+PyTables nor h5py exists in this image, so the reader accepts every encoding HDF5 allows for
+these fields (pickled string, integer array, string array, bool/enum/int scalar) and the writer
+emits the PyTables conventions as documented; a file written by real PyTables could not be
+produced here to confirm - the round trip and `h5dump` structure are tested.
+Files without an `mtype` attribute (legacy COO form, Sparse3DMatrix.py:76-78) are rejected.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import ctypes.util
+import os
+import pickle
+
+import numpy as np
+
+hid_t = C.c_int64
+_lib = None
+
+H5F_ACC_RDONLY, H5F_ACC_TRUNC = 0, 2
+H5P_DEFAULT = 0
+H5S_ALL = 0
+H5T_INTEGER, H5T_FLOAT, H5T_STRING, H5T_ENUM = 0, 1, 3, 8
+H5S_SCALAR = 0
+
+
+def _load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    cands = [os.environ.get('GBRS_LIBHDF5'), '/opt/conda/lib/libhdf5.so', ctypes.util.find_library('hdf5')]
+    err = None
+    for c in cands:
+        if not c:
+            continue
+        try:
+            lib = C.CDLL(c)
+            break
+        except OSError as e:     # noqa: PERF203
+            err = e
+    else:
+        raise ImportError(f'libhdf5 not found (set GBRS_LIBHDF5=/path/to/libhdf5.so): {err}; '
+                          'use the .npz mirror format instead (AlignmentPropertyMatrix.save_npz)')
+    lib.H5open()
+    lib.H5Eset_auto2.argtypes = [hid_t, C.c_void_p, C.c_void_p]
+    lib.H5Eset_auto2(0, None, None)          # we raise Python errors ourselves
+    for name in ('H5Fopen', 'H5Fcreate', 'H5Gopen2', 'H5Gcreate2', 'H5Dopen2', 'H5Dcreate2', 'H5Dget_space',
+                 'H5Dget_type', 'H5Aopen', 'H5Aget_type', 'H5Aget_space', 'H5Acreate2', 'H5Tcopy',
+                 'H5Screate_simple', 'H5Screate', 'H5Pcreate'):
+        getattr(lib, name).restype = hid_t
+    lib.H5Tget_size.restype = C.c_size_t
+    lib.H5Sget_simple_extent_npoints.restype = C.c_int64
+    H, VP, CP, U, I, SZ = hid_t, C.c_void_p, C.c_char_p, C.c_uint, C.c_int, C.c_size_t
+    sig = dict(
+        H5Fopen=[CP, U, H], H5Fcreate=[CP, U, H, H], H5Fclose=[H],
+        H5Gopen2=[H, CP, H], H5Gcreate2=[H, CP, H, H, H], H5Gclose=[H],
+        H5Dopen2=[H, CP, H], H5Dcreate2=[H, CP, H, H, H, H, H], H5Dget_space=[H], H5Dget_type=[H],
+        H5Dread=[H, H, H, H, H, VP], H5Dwrite=[H, H, H, H, H, VP], H5Dclose=[H],
+        H5Aexists=[H, CP], H5Aopen=[H, CP, H], H5Aget_type=[H], H5Aget_space=[H], H5Aread=[H, H, VP],
+        H5Acreate2=[H, CP, H, H, H, H], H5Awrite=[H, H, VP], H5Aclose=[H], H5Adelete=[H, CP],
+        H5Tcopy=[H], H5Tset_size=[H, SZ], H5Tget_class=[H], H5Tget_size=[H], H5Tget_sign=[H],
+        H5Tis_variable_str=[H], H5Tclose=[H],
+        H5Screate_simple=[I, VP, VP], H5Screate=[I], H5Sclose=[H], H5Sget_simple_extent_ndims=[H],
+        H5Sget_simple_extent_dims=[H, VP, VP],
+        H5Pcreate=[H], H5Pset_chunk=[H, I, VP], H5Pset_deflate=[H, U], H5Pclose=[H],
+        H5Lexists=[H, CP, H],
+    )
+    for name, args in sig.items():
+        getattr(lib, name).argtypes = args
+    _lib = lib
+    return lib
+
+
+def _g(name):
+    return C.c_int64.in_dll(_load(), name).value
+
+
+def _native(dtype):
+    dtype = np.dtype(dtype)
+    table = {'uint32': 'H5T_NATIVE_UINT32_g', 'int32': 'H5T_NATIVE_INT32_g', 'uint64': 'H5T_NATIVE_UINT64_g',
+             'int64': 'H5T_NATIVE_INT64_g', 'float64': 'H5T_NATIVE_DOUBLE_g', 'float32': 'H5T_NATIVE_FLOAT_g',
+             'int8': 'H5T_NATIVE_INT8_g', 'uint8': 'H5T_NATIVE_UINT8_g', 'uint16': 'H5T_NATIVE_UINT16_g',
+             'int16': 'H5T_NATIVE_INT16_g'}
+    return _g(table[dtype.name])
+
+
+def _check(v, what):
+    if (v.value if isinstance(v, hid_t) else v) < 0:
+        raise RuntimeError(f'HDF5 error in {what}')
+    return v
+
+
+def _id(v):
+    return v.value if isinstance(v, hid_t) else int(v)
+
+
+def _dims(space):
+    lib = _load()
+    nd = lib.H5Sget_simple_extent_ndims(space)
+    dims = (C.c_uint64 * max(nd, 1))()
+    if nd > 0:
+        lib.H5Sget_simple_extent_dims(space, dims, None)
+    return tuple(int(dims[i]) for i in range(nd))
+
+
+def _read_typed(read, obj, ftype, space):
+    """Read a dataset/attribute into a numpy array given its file type and dataspace."""
+    lib = _load()
+    shape = _dims(space)
+    cls = lib.H5Tget_class(ftype)
+    size = int(lib.H5Tget_size(ftype))
+    if cls in (H5T_INTEGER, H5T_ENUM):
+        signed = lib.H5Tget_sign(ftype) == 1 if cls == H5T_INTEGER else True
+        dt = np.dtype(f"{'i' if signed else 'u'}{size}")
+        out = np.empty(shape, dtype=dt)
+        mem = _native(dt) if cls == H5T_INTEGER else ftype
+        _check(read(obj, mem, out.ctypes.data_as(C.c_void_p)), 'read')
+        return out
+    if cls == H5T_FLOAT:
+        dt = np.dtype(f'f{size}')
+        out = np.empty(shape, dtype=dt)
+        _check(read(obj, _native(dt), out.ctypes.data_as(C.c_void_p)), 'read')
+        return out
+    if cls == H5T_STRING:
+        if lib.H5Tis_variable_str(ftype) > 0:
+            n = int(np.prod(shape)) if shape else 1
+            ptrs = (C.c_char_p * n)()
+            _check(read(obj, ftype, ptrs), 'read')
+            vals = [ptrs[i] or b'' for i in range(n)]
+            return np.array(vals, dtype=object).reshape(shape) if shape else np.array(vals[0], dtype=object)
+        out = np.empty(shape, dtype=f'S{size}')
+        _check(read(obj, ftype, out.ctypes.data_as(C.c_void_p)), 'read')
+        return out
+    raise RuntimeError(f'unsupported HDF5 type class {cls}')
+
+
+def _read_dataset(loc, name):
+    lib = _load()
+    d = _check(lib.H5Dopen2(loc, name.encode(), H5P_DEFAULT), f'open dataset {name}')
+    try:
+        ftype, space = lib.H5Dget_type(d), lib.H5Dget_space(d)
+        try:
+            return _read_typed(lambda o, t, p: lib.H5Dread(o, t, H5S_ALL, H5S_ALL, H5P_DEFAULT, p),
+                               d, ftype, space)
+        finally:
+            lib.H5Tclose(ftype)
+            lib.H5Sclose(space)
+    finally:
+        lib.H5Dclose(d)
+
+
+def _read_attr(loc, name):
+    lib = _load()
+    if lib.H5Aexists(loc, name.encode()) <= 0:
+        raise AttributeError(name)
+    a = _check(lib.H5Aopen(loc, name.encode(), H5P_DEFAULT), f'open attribute {name}')
+    try:
+        ftype, space = lib.H5Aget_type(a), lib.H5Aget_space(a)
+        try:
+            return _read_typed(lambda o, t, p: lib.H5Aread(o, t, p), a, ftype, space)
+        finally:
+            lib.H5Tclose(ftype)
+            lib.H5Sclose(space)
+    finally:
+        lib.H5Aclose(a)
+
+
+class _AttrUnpickler(pickle.Unpickler):
+    """Only what a shape tuple / name list needs: builtins plus numpy scalars.  An EMASE file is
+    input data, not code."""
+    _ALLOWED = {('numpy.core.multiarray', 'scalar'), ('numpy._core.multiarray', 'scalar'), ('numpy', 'dtype')}
+
+    def find_class(self, module, name):
+        if (module, name) in self._ALLOWED:
+            return super().find_class(module, name)
+        raise pickle.UnpicklingError(f'{module}.{name} is not allowed in an EMASE attribute')
+
+
+def _unpickle_maybe(v):
+    """PyTables keeps non-scalar Python attributes as pickled byte strings."""
+    if isinstance(v, np.ndarray) and v.dtype.kind == 'S' and v.shape == ():
+        v = v.item()
+    if isinstance(v, np.ndarray) and v.dtype == object and v.shape == ():
+        v = v.item()
+    if isinstance(v, (bytes, np.bytes_)):
+        raw = bytes(v)
+        try:
+            import io
+            return _AttrUnpickler(io.BytesIO(raw)).load()
+        except Exception:
+            return raw
+    return v
+
+
+def load_into(apm, path):
+    """Fill an AlignmentPropertyMatrix from an EMASE h5 file (Sparse3DMatrix.py:42-102,
+    AlignmentPropertyMatrix.py:70-83)."""
+    lib = _load()
+    f = lib.H5Fopen(os.fsencode(path), H5F_ACC_RDONLY, H5P_DEFAULT)
+    if f < 0:
+        raise OSError(f'cannot open {path} as HDF5')
+    try:
+        root = _check(lib.H5Gopen2(f, b'/', H5P_DEFAULT), 'open /')
+        try:
+            try:
+                mtype = _unpickle_maybe(_read_attr(root, 'mtype'))
+            except AttributeError:
+                raise RuntimeError('Only csc matrices are supported (legacy COO EMASE file without an '
+                                   '`mtype` attribute).')
+            if isinstance(mtype, (bytes, np.bytes_)):
+                mtype = bytes(mtype).decode()
+            mtype = str(mtype).rstrip('\x00')
+            if mtype != 'csc_matrix':
+                raise RuntimeError('Only csc or coo matrices are supported.')
+            shape = _unpickle_maybe(_read_attr(root, 'shape'))
+            apm.shape = tuple(int(x) for x in np.asarray(shape).ravel())
+            L, H, R = apm.shape
+            try:
+                hname = _unpickle_maybe(_read_attr(root, 'hname'))
+                apm.hname = [x.decode() if isinstance(x, (bytes, np.bytes_)) else str(x)
+                             for x in (hname.ravel() if isinstance(hname, np.ndarray) else hname)]
+            except AttributeError:
+                apm.hname = None
+            apm.indptr, apm.indices = [], []
+            for h in range(H):
+                g = _check(lib.H5Gopen2(f, f'/h{h}'.encode(), H5P_DEFAULT), f'open /h{h}')
+                try:
+                    apm.indptr.append(np.ascontiguousarray(_read_dataset(g, 'indptr'), dtype=np.uint32))
+                    apm.indices.append(np.ascontiguousarray(_read_dataset(g, 'indices'), dtype=np.uint32))
+                finally:
+                    lib.H5Gclose(g)
+            if lib.H5Lexists(root, b'count', H5P_DEFAULT) > 0:
+                apm.count = np.ascontiguousarray(_read_dataset(root, 'count'), dtype=np.float64)
+            if lib.H5Lexists(root, b'lname', H5P_DEFAULT) > 0:
+                ln = _read_dataset(root, 'lname')
+                apm.lname = [x.decode() if isinstance(x, (bytes, np.bytes_)) else str(x) for x in ln.ravel()]
+        finally:
+            lib.H5Gclose(root)
+    finally:
+        lib.H5Fclose(f)
+
+
+# ------------------------------------------------------------------------------------------ writer
+
+def _write_str_attr(loc, name, value: bytes):
+    lib = _load()
+    t = lib.H5Tcopy(_g('H5T_C_S1_g'))
+    lib.H5Tset_size(t, max(len(value), 1))
+    s = lib.H5Screate(H5S_SCALAR)
+    a = _check(lib.H5Acreate2(loc, name.encode(), t, s, H5P_DEFAULT, H5P_DEFAULT), f'attr {name}')
+    buf = C.create_string_buffer(value, max(len(value), 1))
+    lib.H5Awrite(a, t, buf)
+    lib.H5Aclose(a); lib.H5Sclose(s); lib.H5Tclose(t)
+
+
+def _write_scalar_attr(loc, name, value, dtype):
+    lib = _load()
+    arr = np.array(value, dtype=dtype)
+    s = lib.H5Screate(H5S_SCALAR)
+    a = _check(lib.H5Acreate2(loc, name.encode(), _native(dtype), s, H5P_DEFAULT, H5P_DEFAULT),
+               f'attr {name}')
+    lib.H5Awrite(a, _native(dtype), arr.ctypes.data_as(C.c_void_p))
+    lib.H5Aclose(a); lib.H5Sclose(s)
+
+
+def _write_carray(loc, name, arr, title='', complevel=1):
+    lib = _load()
+    arr = np.ascontiguousarray(arr)
+    n = int(arr.shape[0])
+    dims = (C.c_uint64 * 1)(n)
+    space = lib.H5Screate_simple(1, dims, None)
+    plist = lib.H5Pcreate(_g('H5P_CLS_DATASET_CREATE_ID_g'))
+    if n > 0:
+        chunk = (C.c_uint64 * 1)(min(n, 1 << 16))
+        lib.H5Pset_chunk(plist, 1, chunk)
+        lib.H5Pset_deflate(plist, complevel)
+    if arr.dtype.kind == 'S':
+        t = lib.H5Tcopy(_g('H5T_C_S1_g'))
+        lib.H5Tset_size(t, arr.dtype.itemsize)
+        ftype = mtype = t
+    else:
+        t = None
+        ftype = mtype = _native(arr.dtype)
+    d = _check(lib.H5Dcreate2(loc, name.encode(), ftype, space, H5P_DEFAULT, plist, H5P_DEFAULT),
+               f'create {name}')
+    if n > 0:
+        _check(lib.H5Dwrite(d, mtype, H5S_ALL, H5S_ALL, H5P_DEFAULT,
+                            arr.ctypes.data_as(C.c_void_p)), f'write {name}')
+    _write_str_attr(d, 'CLASS', b'CARRAY')
+    _write_str_attr(d, 'VERSION', b'1.1')
+    _write_str_attr(d, 'TITLE', title.encode())
+    lib.H5Dclose(d); lib.H5Pclose(plist); lib.H5Sclose(space)
+    if t is not None:
+        lib.H5Tclose(t)
+
+
+def _group_attrs(g, title=''):
+    _write_str_attr(g, 'CLASS', b'GROUP')
+    _write_str_attr(g, 'VERSION', b'1.0')
+    _write_str_attr(g, 'TITLE', title.encode())
+
+
+def save(apm, path, title=None, complib='zlib', incidence_only=True, shallow=False, **_ignored):
+    """Write the EMASE h5 layout (Sparse3DMatrix.save :400-444 + AlignmentPropertyMatrix.save :478-525).
+    Only incidence matrices are written (`incidence_only=True`, the reference's default)."""
+    lib = _load()
+    f = lib.H5Fcreate(os.fsencode(path), H5F_ACC_TRUNC, H5P_DEFAULT, H5P_DEFAULT)
+    if f < 0:
+        raise OSError(f'cannot create {path}')
+    try:
+        root = lib.H5Gopen2(f, b'/', H5P_DEFAULT)
+        _group_attrs(root, title or '')
+        _write_str_attr(root, 'PYTABLES_FORMAT_VERSION', b'2.1')
+        _write_scalar_attr(root, 'incidence_only', 1, np.int8)
+        _write_str_attr(root, 'mtype', b'csc_matrix')
+        _write_str_attr(root, 'shape', pickle.dumps(tuple(int(x) for x in apm.shape), 0))
+        L, H, R = apm.shape
+        for h in range(H):
+            g = _check(lib.H5Gcreate2(f, f'/h{h}'.encode(), H5P_DEFAULT, H5P_DEFAULT, H5P_DEFAULT),
+                       f'group h{h}')
+            _group_attrs(g, f'Sparse matrix components for Haplotype {h}')
+            _write_carray(g, 'indptr', apm.indptr[h].astype(np.uint32))
+            _write_carray(g, 'indices', apm.indices[h].astype(np.uint32))
+            lib.H5Gclose(g)
+        if apm.count is not None:
+            _write_carray(root, 'count', np.asarray(apm.count, dtype=np.float64), 'Equivalence Class Counts')
+        if not shallow:
+            if apm.hname is not None:
+                _write_str_attr(root, 'hname', pickle.dumps(list(apm.hname), 0))
+            if apm.lname is not None:
+                _write_carray(root, 'lname', np.array(apm.lname, dtype='S'), 'Locus Names')
+        lib.H5Gclose(root)
+    finally:
+        lib.H5Fclose(f)
