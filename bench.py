@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--flags", type=int, default=0, help="extra gbrs_em_create flags (tuning)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hmm", action="store_true")
+    ap.add_argument("--no-merged-line", action="store_true")
     ap.add_argument("--cpu-rows", type=int, default=2_000_000)
     ap.add_argument("--cpu-iters", type=int, default=10)
     ap.add_argument("--hmm-samples", type=int, default=1)
@@ -117,6 +118,14 @@ def em_bench(args, rank, world, torch, dist):
         dt = float(tt.item())
     inf = eng.info()
     res = dict(dt=dt, t_gen=t_gen, t_create=t_create, N=n_entries, info=inf)
+    if world == 1 and not args.merge:
+        # time to solution with the reference's default stopping rule (tol = 1e-4 TPM units)
+        eng.prepare(0.0)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        n_it, hist = eng.run(model=4, tol=1e-4, max_iters=999)
+        res["solve"] = dict(iterations=n_it, ms=(time.perf_counter() - t1) * 1e3,
+                            final_err_sum=float(hist[-1]) if n_it else None)
     if world == 1:
         res["estep_ms"] = inf.last_estep_ms
         res["step_ms"] = inf.last_step_ms
@@ -259,10 +268,35 @@ def main():
                      "priced_bytes": priced},
         "setup_s": {"generate": em["t_gen"], "create_layout": em["t_create"]},
     }
+    if "solve" in em:
+        line["time_to_solution"] = dict(em["solve"], rule="err_sum <= 1e6*tol, tol=1e-4 (gbrs quantify default)")
+    # HBM traffic of the E-step kernel from the committed rocprofv3 PMC passes (separate runs of this
+    # same command, scripts/profile_estep.sh): FETCH_SIZE x2 (gfx950 correction, MI355X_MICROARCH.md)
+    # + WRITE_SIZE, per launch.  Only quoted for the exact workload it was measured on.
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+            pt = json.load(fh)
+        key = f"R{args.rows}_H{args.haps}_L{args.loci}_merge{int(args.merge)}"
+        if key in pt:
+            line["roofline"]["traffic"] = pt[key]["bytes_per_launch"]
+            line["roofline"]["traffic_source"] = pt[key]["source"]
+    except (OSError, ValueError):
+        pass
     if rank == 0:
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = em_cpu_baseline(args)
             line["speedup_vs_cpu"] = (value / world) / line["cpu_baseline"]["value"]
+        if not args.merge and not args.no_merged_line and world == 1:
+            import copy
+            a2 = copy.copy(args)
+            a2.merge = True
+            m = em_bench(a2, rank, world, torch, dist)
+            line["merged_rows_variant"] = {
+                "note": "same sample with identical reads merged into weighted rows while building the device "
+                        "layout (GBRS_EM_MERGE_IDENTICAL_ROWS, what `gbrs compress` does first); not the headline",
+                "value": args.steps / m["dt"], "unit": "iters/s", "ms_per_step": m["dt"] / args.steps * 1e3,
+                "estep_kernel_ms": m["estep_ms"], "device_rows": int(m["info"].num_device_rows),
+                "device_words": int(m["info"].num_device_words), "layout_bytes": int(m["info"].bytes_per_iter)}
         if not args.no_hmm:
             line["hmm"] = hmm_bench(args, torch)
         print(json.dumps(line), flush=True)

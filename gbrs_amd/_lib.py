@@ -21,7 +21,7 @@ EXPORTS = [
     "gbrs_em_set_stream",
     "gbrs_em_sync", "gbrs_em_info", "gbrs_alignment_counts", "gbrs_em_destroy",
     "gbrs_hmm_create", "gbrs_hmm_set_expression", "gbrs_hmm_set_eprob", "gbrs_hmm_run",
-    "gbrs_hmm_get", "gbrs_hmm_info", "gbrs_hmm_destroy",
+    "gbrs_hmm_get", "gbrs_hmm_info", "gbrs_hmm_destroy", "gbrs_interpolate", "gbrs_genoprob_dosage",
 ]
 
 GBRS_OK = 0
@@ -108,6 +108,8 @@ def load():
         "gbrs_hmm_get": [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp],
         "gbrs_hmm_info": [vp, C.POINTER(HmmInfo)],
         "gbrs_hmm_destroy": [vp],
+        "gbrs_interpolate": [i32, i32, vp, vp, i32, vp, vp, i32],
+        "gbrs_genoprob_dosage": [i32, i64, vp, vp, i32],
     }
     for name, args in sigs.items():
         fn = getattr(lib, name)

@@ -56,6 +56,20 @@ def build_parser():
     r.add_argument('-o', '--outbase', default=None)
     r.add_argument('-v', '--verbose', action='count', default=0)
     r.add_argument('--device', type=int, default=0, help='HIP device ordinal (extension)')
+    it = sub.add_parser('interpolate', help='interpolate probability on a decently-spaced grid')
+    it.add_argument('-i', '--genoprob-file', required=True, type=_existing)
+    it.add_argument('-g', '--grid-file', type=_existing, default=None)
+    it.add_argument('-p', '--gpos-file', type=_existing, default=None)
+    it.add_argument('-o', '--output', dest='output_file', default=None)
+    it.add_argument('-v', '--verbose', action='count', default=0)
+    it.add_argument('--device', type=int, default=0)
+    ex = sub.add_parser('export', help='export to GBRS quant format')
+    ex.add_argument('-i', '--genoprob-file', required=True, type=_existing)
+    ex.add_argument('-s', '--strains', action='append', required=True)
+    ex.add_argument('-g', '--grid-file', type=_existing, default=None)
+    ex.add_argument('-o', '--output', dest='output_file', default=None)
+    ex.add_argument('-v', '--verbose', action='count', default=0)
+    ex.add_argument('--device', type=int, default=0)
     return ap
 
 
@@ -76,6 +90,15 @@ def main(argv=None) -> int:
                      report_alignment_counts=args.report_alignment_counts,
                      report_posterior=args.report_posterior, device=args.device,
                      merge_identical_rows=args.merge_identical_rows)
+        elif args.command == 'interpolate':
+            from .postproc import interpolate
+            interpolate(genoprob_file=args.genoprob_file, grid_file=args.grid_file, gpos_file=args.gpos_file,
+                        output_file=args.output_file, device=args.device)
+        elif args.command == 'export':
+            from .postproc import export
+            strains = [s for x in args.strains for s in x.split(',')]
+            export(genoprob_file=args.genoprob_file, strains=strains, grid_file=args.grid_file,
+                   output_file=args.output_file, device=args.device)
         else:
             from .hmm import reconstruct
             reconstruct(expression_file=args.expression_file, tprob_file=args.tprob_file,

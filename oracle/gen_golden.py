@@ -302,6 +302,62 @@ def counts_case(name, R, H, L, seed, with_count, drop_rows=0):
     np.savez_compressed(os.path.join(GOLD, f"counts_{name}.npz"), **out)
     print(f"counts_{name}: R={R} H={H} L={L} nnz={inc.nnz}")
 
+# ----------------------------------------------------------------------------- interpolate / export
+
+def postproc_case(name, hmm_name, n_grid):
+    """gbrs_utils.interpolate and gbrs_utils.export run unmodified on a genoprobs file taken from
+    an HMM golden; the oracle restatement must reproduce them bit for bit."""
+    from oracle import postproc_oracle
+    g = np.load(os.path.join(GOLD, f"hmm_{hmm_name}.npz"))
+    chroms = [str(c) for c in g["chroms"]]
+    H = int(g["num_haps"])
+    strains = [chr(65 + h) for h in range(H)]
+    case_dir = os.path.join(WORK, name)
+    os.makedirs(case_dir)
+    with open(os.path.join(WORK, "ref.fa.fai"), "w") as fh:
+        for c in chroms:
+            fh.write(f"{c}\t1000000\t0\t60\t61\n")
+    rng = np.random.default_rng(77)
+    gpos, gamma, xg, grid = {}, {}, {}, {}
+    for c in chroms:
+        n = g[f"gamma_{c}"].shape[1]
+        pos = np.sort(rng.uniform(0.5, 90.0, size=n))
+        arr = np.zeros(n, dtype=[("f0", "U24"), ("f1", "f8")])
+        arr["f0"] = g[f"genes_{c}"]
+        arr["f1"] = pos
+        gpos[c], gamma[c], xg[c] = arr, g[f"gamma_{c}"], pos
+        grid[c] = np.sort(np.concatenate(([0.0, pos[0], pos[-1]], rng.uniform(0.0, pos[-1] + 5.0, size=n_grid - 3))))
+    gpos_file = os.path.join(case_dir, "gpos.npz"); np.savez(gpos_file, **gpos)
+    gp_file = os.path.join(case_dir, "genoprobs.npz"); np.savez(gp_file, **gamma)
+    grid_file = os.path.join(case_dir, "grid.txt")
+    with open(grid_file, "w") as fh:
+        fh.write("marker\tchr\tbp\tcM\n")
+        k = 0
+        for c in chroms:
+            for x in grid[c]:
+                fh.write(f"m{k}\t{c}\t{int(x * 1e6)}\t{repr(float(x))}\n")
+                k += 1
+    out_i = os.path.join(case_dir, "interp.npz")
+    ref_gbrs_utils.interpolate(gp_file, grid_file=grid_file, gpos_file=gpos_file, output_file=out_i)
+    ref_i = np.load(out_i)
+    out_e = os.path.join(case_dir, "export.tsv")
+    ref_gbrs_utils.export(out_i, strains, grid_file=grid_file, output_file=out_e)
+    out = dict(num_haps=H, chroms=np.array(chroms), export_text=np.array(open(out_e).read()))
+    rows = []
+    for c in chroms:
+        mine = postproc_oracle.interpolate(xg[c], gamma[c], grid[c])
+        beq(ref_i[c], mine, f"{name} interpolate {c}")
+        out[f"xgene_{c}"] = xg[c]; out[f"gamma_{c}"] = gamma[c]; out[f"grid_{c}"] = grid[c]
+        out[f"interp_{c}"] = ref_i[c]
+        rows.append(ref_i[c].transpose())
+    dos = postproc_oracle.dosage(np.vstack(rows), H)
+    ref_dos = np.loadtxt(out_e, skiprows=1, delimiter="\t")
+    if np.max(np.abs(ref_dos - dos)) > 5.1e-7:
+        raise AssertionError(f"{name}: export restatement differs")
+    out["dosage"] = dos
+    np.savez_compressed(os.path.join(GOLD, f"postproc_{name}.npz"), **out)
+    print(f"postproc_{name}: from hmm_{hmm_name}, {n_grid} grid points per chromosome")
+
 
 def main():
     os.makedirs(GOLD, exist_ok=True)
@@ -312,6 +368,10 @@ def main():
             counts_case("h8_plain_emptyrows", 2000, 8, 100, 42, False, drop_rows=100)
             counts_case("h2_count", 1200, 2, 60, 43, True)
         if only == "counts":
+            return
+        if only == "postproc":
+            postproc_case("h8", "h8_full", 25)
+            postproc_case("h4", "h4_full", 12)
             return
         #        name            R     H  L    seed  count  len    pc   mask   tol   max
         em_case("h2_plain",      1500, 2, 60,  11,   False, False, 0.0, False, 1e-4, 999)
@@ -330,6 +390,8 @@ def main():
         hmm_case("h8_short", 8, [40, 25, 33], 32, True)
         hmm_case("h4_full", 4, [30, 12], 33, False)
         hmm_case("h2_short", 2, [20, 1 + 1], 34, True)
+        postproc_case("h8", "h8_full", 25)
+        postproc_case("h4", "h4_full", 12)
     finally:
         shutil.rmtree(WORK, ignore_errors=True)
 
