@@ -525,29 +525,22 @@ backtrace_kernel(int S, int BT_CHUNK, int64_t genes_per_sample, int64_t bp_per_s
 
 // ---- post-processing of the posteriors (gbrs_utils.py:612-697 interpolate, :863-938 export) ---
 
-// Linear interpolation of gamma (S x n genes, positions xg extended by one point at each end, the
-// end columns duplicated) onto the marker grid, operation order of scipy interp1d(kind='linear'):
-//     slope = (y_hi - y_lo) / (x_hi - x_lo);  y = slope * (x - x_lo) + y_lo
-__global__ void interpolate_kernel(int S, int n, const double *__restrict__ xg /* n+2 */,
-                                   const double *__restrict__ gamma, int m, const double *__restrict__ xq,
-                                   double *__restrict__ out) {
+// Linear interpolation of the rows of y (S x n points at ascending x) onto xq, operation order of
+// scipy interp1d(kind='linear'):  slope = (y_hi - y_lo) / (x_hi - x_lo);  y = slope * (x - x_lo) + y_lo
+__global__ void interpolate_kernel(int S, int n, const double *__restrict__ xs, const double *__restrict__ y,
+                                   int m, const double *__restrict__ xq, double *__restrict__ out) {
     const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (id >= (int64_t)S * m) return;
     const int s = (int)(id / m), g = (int)(id - (int64_t)s * m);
     const double x = xq[g];
-    const int nx = n + 2;
-    int lo = 0, hi = nx;                       // searchsorted(xg, x, side='left')
+    int lo = 0, hi = n;                        // searchsorted(xs, x, side='left')
     while (lo < hi) {
         const int mid = (lo + hi) >> 1;
-        if (xg[mid] < x) lo = mid + 1; else hi = mid;
+        if (xs[mid] < x) lo = mid + 1; else hi = mid;
     }
-    int idx = min(max(lo, 1), nx - 1);
-    const int i_lo = idx - 1, i_hi = idx;
-    auto y = [&](int i) -> double {            // column i of the extended matrix
-        const int c = min(max(i - 1, 0), n - 1);
-        return gamma[(int64_t)s * n + c];
-    };
-    const double x_lo = xg[i_lo], x_hi = xg[i_hi], y_lo = y(i_lo), y_hi = y(i_hi);
+    const int idx = min(max(lo, 1), n - 1);
+    const double x_lo = xs[idx - 1], x_hi = xs[idx];
+    const double y_lo = y[(int64_t)s * n + idx - 1], y_hi = y[(int64_t)s * n + idx];
     const double slope = (y_hi - y_lo) / (x_hi - x_lo);
     out[(int64_t)s * m + g] = slope * (x - x_lo) + y_lo;
 }
@@ -827,33 +820,33 @@ int gbrs_hmm_info(gbrs_hmm_t *h, gbrs_hmm_info_t *info) {
     return GBRS_OK;
 }
 
-int gbrs_interpolate(int S, int n_genes, const double *x_gene_ext, const double *gamma, int n_grid,
+int gbrs_interpolate(int S, int n_points, const double *x, const double *y, int n_grid,
                      const double *x_grid, double *out, int device) {
-    if (S < 1 || n_genes < 1 || n_grid < 0 || !x_gene_ext || !gamma || (n_grid && (!x_grid || !out)))
+    if (S < 1 || n_points < 2 || n_grid < 0 || !x || !y || (n_grid && (!x_grid || !out)))
         return fail(GBRS_ERR_INVALID, "bad argument");
-    for (int i = 0; i + 1 < n_genes + 2; ++i)
-        if (!(x_gene_ext[i] <= x_gene_ext[i + 1])) return fail(GBRS_ERR_INVALID, "x_gene_ext must be ascending");
+    for (int i = 0; i + 1 < n_points; ++i)
+        if (!(x[i] <= x[i + 1])) return fail(GBRS_ERR_INVALID, "x must be ascending");
     for (int g = 0; g < n_grid; ++g) {
-        if (x_grid[g] < x_gene_ext[0])
+        if (x_grid[g] < x[0])
             return fail(GBRS_ERR_INVALID, "A value (%.17g) in x_new is below the interpolation range's minimum value (%.17g).",
-                        x_grid[g], x_gene_ext[0]);
-        if (x_grid[g] > x_gene_ext[n_genes + 1])
+                        x_grid[g], x[0]);
+        if (x_grid[g] > x[n_points - 1])
             return fail(GBRS_ERR_INVALID, "A value (%.17g) in x_new is above the interpolation range's maximum value (%.17g).",
-                        x_grid[g], x_gene_ext[n_genes + 1]);
+                        x_grid[g], x[n_points - 1]);
     }
     if (n_grid == 0) return GBRS_OK;
     GBRS_TRY(select_device(device));
-    DevBuf<double> d_x, d_g, d_q, d_o;
-    GBRS_TRY(d_x.alloc(n_genes + 2));
-    GBRS_TRY(d_g.alloc((size_t)S * n_genes));
+    DevBuf<double> d_x, d_y, d_q, d_o;
+    GBRS_TRY(d_x.alloc(n_points));
+    GBRS_TRY(d_y.alloc((size_t)S * n_points));
     GBRS_TRY(d_q.alloc(n_grid));
     GBRS_TRY(d_o.alloc((size_t)S * n_grid));
-    GBRS_HIP_CHECK(hipMemcpy(d_x.p, x_gene_ext, d_x.bytes(), hipMemcpyHostToDevice));
-    GBRS_HIP_CHECK(hipMemcpy(d_g.p, gamma, d_g.bytes(), hipMemcpyHostToDevice));
+    GBRS_HIP_CHECK(hipMemcpy(d_x.p, x, d_x.bytes(), hipMemcpyHostToDevice));
+    GBRS_HIP_CHECK(hipMemcpy(d_y.p, y, d_y.bytes(), hipMemcpyHostToDevice));
     GBRS_HIP_CHECK(hipMemcpy(d_q.p, x_grid, d_q.bytes(), hipMemcpyHostToDevice));
     const int64_t total = (int64_t)S * n_grid;
-    hipLaunchKernelGGL(interpolate_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, nullptr, S, n_genes,
-                       d_x.p, d_g.p, n_grid, d_q.p, d_o.p);
+    hipLaunchKernelGGL(interpolate_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, nullptr, S, n_points,
+                       d_x.p, d_y.p, n_grid, d_q.p, d_o.p);
     GBRS_HIP_CHECK(hipGetLastError());
     GBRS_HIP_CHECK(hipMemcpy(out, d_o.p, d_o.bytes(), hipMemcpyDeviceToHost));
     return GBRS_OK;

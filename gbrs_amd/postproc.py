@@ -19,22 +19,19 @@ logger = logging.getLogger('gbrs')
 def interpolate_arrays(x_gene, gamma, x_grid, device=0):
     """gamma (S x n) at gene positions x_gene (n) -> (S x len(x_grid)), end points padded as the
     reference does (:664-676, :684-688)."""
-    gamma = np.ascontiguousarray(gamma, dtype=np.float64)
-    S, n = gamma.shape
+    gamma = np.asarray(gamma, dtype=np.float64)
+    S = gamma.shape[0]
     x = np.append([0.0], np.asarray(x_gene, dtype=np.float64))
     x = np.append(x, [x_grid[-1] + 1.0])
+    y = np.hstack((gamma[:, 0][:, np.newaxis], gamma))
+    y = np.hstack((y, y[:, -1][:, np.newaxis]))
     order = np.argsort(x, kind='mergesort')            # interp1d(assume_sorted=False)
-    if not np.array_equal(order, np.arange(len(x))):
-        x = x[order]
-        y = np.hstack((gamma[:, :1], gamma, gamma[:, -1:]))[:, order]
-        # fold the permuted extended matrix back into "interior + duplicated ends" form
-        gamma = np.ascontiguousarray(y[:, 1:-1])
-        if not (np.array_equal(y[:, 0], gamma[:, 0]) and np.array_equal(y[:, -1], gamma[:, -1])):
-            raise ValueError('gene positions must lie between 0 and the last grid point')
+    x = np.ascontiguousarray(x[order])
+    y = np.ascontiguousarray(np.take(y, order, axis=1))
     xq = np.ascontiguousarray(x_grid, dtype=np.float64)
     out = np.empty((S, len(xq)), dtype=np.float64)
-    st = _lib.load().gbrs_interpolate(S, n, _lib.ptr(np.ascontiguousarray(x)), _lib.ptr(gamma), len(xq),
-                                      _lib.ptr(xq), _lib.ptr(out), device)
+    st = _lib.load().gbrs_interpolate(S, len(x), _lib.ptr(x), _lib.ptr(y), len(xq), _lib.ptr(xq), _lib.ptr(out),
+                                      device)
     if st == _lib.GBRS_ERR_INVALID and b'interpolation range' in _lib.load().gbrs_last_error():
         raise ValueError(_lib.load().gbrs_last_error().decode())
     _lib.check(st)

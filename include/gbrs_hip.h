@@ -222,12 +222,12 @@ int gbrs_hmm_info(gbrs_hmm_t *hmm, gbrs_hmm_info_t *info);
 
 int gbrs_hmm_destroy(gbrs_hmm_t *hmm);
 
-/* `gbrs interpolate` numeric body (gbrs/gbrs_utils.py:664-692): gamma (S x n_genes, C order) at gene
- * positions x_gene_ext (n_genes + 2 ascending values: the gene positions with one extra point at
- * each end, whose columns are copies of the first / last gene) linearly interpolated onto x_grid
- * (scipy interp1d(kind='linear') operation order).  out is (S x n_grid).  Grid points outside
- * [x_gene_ext[0], x_gene_ext[n+1]] fail with scipy's ValueError text. */
-int gbrs_interpolate(int num_states, int n_genes, const double *x_gene_ext, const double *gamma,
+/* `gbrs interpolate` numeric body (gbrs/gbrs_utils.py:684-688): the rows of y (S x n_points, C
+ * order) given at ascending positions x are linearly interpolated onto x_grid with scipy
+ * interp1d(kind='linear')'s operation order; out is (S x n_grid).  The caller pads the gene
+ * positions / posterior columns with the reference's two end points (:664-676, :684-685).  Grid
+ * points outside [x[0], x[n_points-1]] fail with scipy's ValueError text. */
+int gbrs_interpolate(int num_states, int n_points, const double *x, const double *y,
                      int n_grid, const double *x_grid, double *out, int device);
 
 /* `gbrs export` numeric body (gbrs_utils.py:888-927): n_rows x S diplotype probabilities times the
