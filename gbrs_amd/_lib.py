@@ -22,6 +22,7 @@ EXPORTS = [
     "gbrs_em_sync", "gbrs_em_info", "gbrs_alignment_counts", "gbrs_em_destroy",
     "gbrs_hmm_create", "gbrs_hmm_set_expression", "gbrs_hmm_set_eprob", "gbrs_hmm_run",
     "gbrs_hmm_get", "gbrs_hmm_info", "gbrs_hmm_destroy", "gbrs_interpolate", "gbrs_genoprob_dosage",
+    "gbrs_compress_create", "gbrs_compress_get", "gbrs_compress_destroy",
 ]
 
 GBRS_OK = 0
@@ -110,6 +111,9 @@ def load():
         "gbrs_hmm_destroy": [vp],
         "gbrs_interpolate": [i32, i32, vp, vp, i32, vp, vp, i32],
         "gbrs_genoprob_dosage": [i32, i64, vp, vp, i32],
+        "gbrs_compress_create": [u64, u32, u32, pp, pp, vp, i32, pp, C.POINTER(u64), vp],
+        "gbrs_compress_get": [vp, pp, pp, vp],
+        "gbrs_compress_destroy": [vp],
     }
     for name, args in sigs.items():
         fn = getattr(lib, name)

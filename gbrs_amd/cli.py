@@ -70,6 +70,12 @@ def build_parser():
     ex.add_argument('-o', '--output', dest='output_file', default=None)
     ex.add_argument('-v', '--verbose', action='count', default=0)
     ex.add_argument('--device', type=int, default=0)
+    cp = sub.add_parser('compress', help='compress EMASE format alignment incidence matrix')
+    cp.add_argument('-i', '--emase-file', dest='emase_files', action='append', required=True)
+    cp.add_argument('-o', '--output', dest='output_file', required=True)
+    cp.add_argument('-c', '--comp-lib', default='zlib')
+    cp.add_argument('-v', '--verbose', action='count', default=0)
+    cp.add_argument('--device', type=int, default=0)
     return ap
 
 
@@ -90,6 +96,10 @@ def main(argv=None) -> int:
                      report_alignment_counts=args.report_alignment_counts,
                      report_posterior=args.report_posterior, device=args.device,
                      merge_identical_rows=args.merge_identical_rows)
+        elif args.command == 'compress':
+            from .compress import compress
+            files = [f for x in args.emase_files for f in x.split(',')]
+            compress(emase_files=files, output_file=args.output_file, comp_lib=args.comp_lib, device=args.device)
         elif args.command == 'interpolate':
             from .postproc import interpolate
             interpolate(genoprob_file=args.genoprob_file, grid_file=args.grid_file, gpos_file=args.gpos_file,

@@ -677,6 +677,72 @@ int em_create_impl(uint64_t R, uint32_t L, uint32_t H, const uint32_t *const *in
 
 }  // namespace
 
+struct gbrs_compress {
+    int device = 0;
+    uint32_t L = 0, H = 0;
+    CompressResult res;
+};
+
+extern "C" {
+
+int gbrs_compress_create(uint64_t R, uint32_t L, uint32_t H, const uint32_t *const *indptr,
+                         const uint32_t *const *indices, const double *count, int device,
+                         gbrs_compress_t **out, uint64_t *num_ecs, uint64_t *nnz_per_hap) {
+    if (!out) return fail(GBRS_ERR_INVALID, "out is NULL");
+    *out = nullptr;
+    if (H < 1 || H > 16 || L < 1 || R < 1 || R > 0xFFFFFFFFull || !indptr || !indices)
+        return fail(GBRS_ERR_INVALID, "The shape must be a tuple of three positive integers (H <= 16, R < 2^32).");
+    GBRS_TRY(select_device(device));
+    hipStream_t s = nullptr;
+    GBRS_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamDefault));
+    struct SG { hipStream_t s; ~SG() { (void)hipStreamDestroy(s); } } sg{s};
+    DevBuf<uint32_t> ent_row;
+    DevBuf<uint64_t> col_ptr;
+    DevBuf<double> d_count;
+    uint64_t n = 0;
+    GBRS_TRY(upload_csc(R, L, H, indptr, indices, false, ent_row, col_ptr, n));
+    if (count) {
+        GBRS_TRY(d_count.alloc(R));
+        GBRS_HIP_CHECK(hipMemcpy(d_count.p, count, R * sizeof(double), hipMemcpyHostToDevice));
+    }
+    GBRS_HIP_CHECK(hipDeviceSynchronize());
+    gbrs_compress *c = new gbrs_compress();
+    c->device = device; c->L = L; c->H = H;
+    const int st = compress_device(c->res, R, L, H, n, ent_row.p, col_ptr.p, count ? d_count.p : nullptr, s);
+    if (st != GBRS_OK) { delete c; return st; }
+    if (num_ecs) *num_ecs = c->res.num_ecs;
+    if (nnz_per_hap) {
+        std::vector<uint64_t> cp((size_t)H * L + 1);
+        GBRS_HIP_CHECK(hipMemcpy(cp.data(), c->res.col_ptr.p, cp.size() * 8, hipMemcpyDeviceToHost));
+        for (uint32_t h = 0; h < H; ++h) nnz_per_hap[h] = cp[(size_t)(h + 1) * L] - cp[(size_t)h * L];
+    }
+    *out = c;
+    return GBRS_OK;
+}
+
+int gbrs_compress_get(gbrs_compress_t *c, uint32_t *const *indptr_out, uint32_t *const *indices_out, double *count_out) {
+    if (!c || !indptr_out || !indices_out) return fail(GBRS_ERR_INVALID, "NULL argument");
+    GBRS_TRY(select_device(c->device));
+    const uint32_t L = c->L, H = c->H;
+    std::vector<uint64_t> cp((size_t)H * L + 1);
+    GBRS_HIP_CHECK(hipMemcpy(cp.data(), c->res.col_ptr.p, cp.size() * 8, hipMemcpyDeviceToHost));
+    for (uint32_t h = 0; h < H; ++h) {
+        const uint64_t base = cp[(size_t)h * L], cnt = cp[(size_t)(h + 1) * L] - base;
+        for (uint32_t l = 0; l <= L; ++l) indptr_out[h][l] = (uint32_t)(cp[(size_t)h * L + l] - base);
+        if (cnt) GBRS_HIP_CHECK(hipMemcpy(indices_out[h], c->res.indices.p + base, cnt * 4, hipMemcpyDeviceToHost));
+    }
+    if (count_out && c->res.num_ecs)
+        GBRS_HIP_CHECK(hipMemcpy(count_out, c->res.count.p, c->res.num_ecs * 8, hipMemcpyDeviceToHost));
+    return GBRS_OK;
+}
+
+int gbrs_compress_destroy(gbrs_compress_t *c) {
+    if (c) { (void)hipSetDevice(c->device); delete c; }
+    return GBRS_OK;
+}
+
+}  // extern "C"
+
 extern "C" {
 
 int gbrs_em_create(uint64_t R, uint32_t L, uint32_t H, const uint32_t *const *indptr,

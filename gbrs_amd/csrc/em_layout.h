@@ -70,6 +70,16 @@ int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L, uint32_t H, uint6
                       const uint32_t *ent_row, const uint64_t *col_ptr, const double *count,
                       bool merge_identical_rows, bool interleave, hipStream_t stream);
 
+// `gbrs compress`: equivalence classes of identical rows, in first-seen order.
+struct CompressResult {
+    uint64_t num_ecs = 0, n_entries = 0;
+    DevBuf<uint64_t> col_ptr;     // H*L + 1 offsets into indices (column c = h*L + l)
+    DevBuf<uint32_t> indices;     // class ids, ascending inside a column
+    DevBuf<double> count;         // num_ecs
+};
+int compress_device(CompressResult &out, uint64_t R, uint32_t L, uint32_t H, uint64_t N, const uint32_t *ent_row,
+                    const uint64_t *col_ptr, const double *count, hipStream_t s);
+
 // `--report-alignment-counts`: aln/uniq are (H x Lout) row-major, locus_uniq is Lout, all DEVICE
 // buffers; locus_group (device, nullable) maps locus -> output column (gene level).
 int alignment_counts_device(uint64_t R, uint32_t L, uint32_t H, uint64_t N, const uint32_t *ent_row,

@@ -532,6 +532,223 @@ int alignment_counts_device(uint64_t R, uint32_t L, uint32_t H, uint64_t N, cons
     return GBRS_OK;
 }
 
+// ---- `gbrs compress` (gbrs/emase_utils.py:60-103): identical rows -> equivalence classes -------
+__global__ void ec_min_row_kernel(uint64_t n, const uint32_t *__restrict__ hincl, const uint32_t *__restrict__ srow,
+                                  const uint32_t *__restrict__ row_orig, const double *__restrict__ count,
+                                  uint32_t *__restrict__ minrow, double *__restrict__ weight) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t g = hincl[i] - 1;
+    const uint32_t r = row_orig[srow[i]];
+    atomicMin(&minrow[g], r);
+    atomicAdd(&weight[g], count ? count[r] : 1.0);
+}
+
+// rows without any alignment all share the empty key: one more class, at its first row's rank
+__global__ void ec_empty_rows_kernel(uint64_t R, const uint32_t *__restrict__ nnz_row, const double *__restrict__ count,
+                                     uint32_t *__restrict__ minrow_slot, double *__restrict__ weight_slot) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R || nnz_row[r] != 0) return;
+    atomicMin(minrow_slot, (uint32_t)r);
+    atomicAdd(weight_slot, count ? count[r] : 1.0);
+}
+
+__global__ void ec_row_nnz_kernel(uint64_t n, const uint32_t *__restrict__ ent_row, uint32_t *__restrict__ nnz_row) {
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) atomicAdd(&nnz_row[ent_row[k]], 1u);
+}
+
+__global__ void ec_rank_scatter_kernel(uint64_t n, const uint32_t *__restrict__ sorted_group, uint32_t *__restrict__ newid) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) newid[sorted_group[i]] = (uint32_t)i;
+}
+
+__global__ void ec_permute_count_kernel(uint64_t n, const uint32_t *__restrict__ newid, const double *__restrict__ w,
+                                        double *__restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[newid[i]] = w[i];
+}
+
+__global__ void ec_count_entries_kernel(uint64_t n_short, const uint32_t *__restrict__ head, const uint32_t *__restrict__ srow,
+                                        const uint32_t *__restrict__ rowstart, const uint32_t *__restrict__ pmask,
+                                        uint32_t *__restrict__ nent) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_short) return;
+    uint32_t c = 0;
+    if (head[i]) {
+        const uint32_t r = srow[i];
+        for (uint32_t p = rowstart[r]; p < rowstart[r + 1]; ++p) c += __popc(pmask[p]);
+    }
+    nent[i] = c;
+}
+
+__global__ void ec_emit_entries_kernel(uint64_t n_short, const uint32_t *__restrict__ head, const uint32_t *__restrict__ hincl,
+                                       const uint32_t *__restrict__ srow, const uint32_t *__restrict__ rowstart,
+                                       const uint32_t *__restrict__ ploc, const uint32_t *__restrict__ pmask,
+                                       const uint32_t *__restrict__ eoff, const uint32_t *__restrict__ newid,
+                                       uint64_t *__restrict__ keys) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_short || !head[i]) return;
+    const uint32_t r = srow[i];
+    const uint64_t id = newid[hincl[i] - 1];
+    uint32_t o = eoff[i];
+    for (uint32_t p = rowstart[r]; p < rowstart[r + 1]; ++p) {
+        uint32_t m = pmask[p];
+        while (m) {
+            const uint32_t h = __ffs(m) - 1;
+            m &= m - 1;
+            keys[o++] = ((uint64_t)h << 59) | ((uint64_t)ploc[p] << 32) | id;     // sort by (hap, locus, class)
+        }
+    }
+}
+
+__global__ void ec_split_kernel(uint64_t n, const uint64_t *__restrict__ keys, uint32_t *__restrict__ indices) {
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) indices[k] = (uint32_t)(keys[k] & 0xFFFFFFFFu);
+}
+
+__global__ void ec_indptr_kernel(uint32_t L, uint32_t H, uint64_t n, const uint64_t *__restrict__ keys,
+                                 uint64_t *__restrict__ colptr) {
+    const uint64_t c = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;   // column id h*L + l, plus the end
+    if (c > (uint64_t)H * L) return;
+    const uint64_t h = c / L, l = c - h * L;
+    const uint64_t target = c == (uint64_t)H * L ? ~0ull : ((h << 59) | (l << 32));
+    uint64_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (keys[mid] < target) lo = mid + 1; else hi = mid;
+    }
+    colptr[c] = lo;
+}
+
+int compress_device(CompressResult &out, uint64_t R, uint32_t L, uint32_t H, uint64_t N, const uint32_t *ent_row,
+                    const uint64_t *col_ptr, const double *count, hipStream_t s) {
+    if (H > 16 || N >= 0xFFFFFFFFull || L >= (1u << 27))
+        return fail(GBRS_ERR_INVALID, "compress needs H <= 16, N < 2^32 entries and L < 2^27 loci");
+    Scratch sc;
+    DevBuf<BuildFlags> d_flags;
+    GBRS_TRY(d_flags.alloc(1));
+    GBRS_HIP_CHECK(hipMemsetAsync(d_flags.p, 0, sizeof(BuildFlags), s));
+    BuildFlags hf{};
+    out.num_ecs = 0;
+    out.n_entries = 0;
+    GBRS_TRY(out.col_ptr.alloc((size_t)H * L + 1));
+    GBRS_HIP_CHECK(hipMemsetAsync(out.col_ptr.p, 0, out.col_ptr.bytes(), s));
+    // rows without alignments
+    DevBuf<uint32_t> nnz_row;
+    GBRS_TRY(nnz_row.alloc(R));
+    GBRS_HIP_CHECK(hipMemsetAsync(nnz_row.p, 0, nnz_row.bytes(), s));
+    if (N) hipLaunchKernelGGL(ec_row_nnz_kernel, dim3(grid_for(N)), dim3(256), 0, s, N, ent_row, nnz_row.p);
+    uint64_t P = 0, R1 = 0, M = 0;
+    DevBuf<uint32_t> prow, ploc, pmask, rowstart, row_orig, srow, head, hincl;
+    if (N) {
+        DevBuf<uint64_t> keys, keys2;
+        GBRS_TRY(keys.alloc(N)); GBRS_TRY(keys2.alloc(N));
+        hipLaunchKernelGGL(make_keys_kernel, dim3(grid_for(N)), dim3(256), 0, s, N, H * L, L, R, col_ptr, ent_row, keys.p,
+                           d_flags.p);
+        GBRS_TRY(sort_keys64(sc, keys.p, keys2.p, N, 32 + bits_for(R - 1), s));
+        keys.release();
+        DevBuf<uint32_t> pflag, pidx;
+        GBRS_TRY(pflag.alloc(N)); GBRS_TRY(pidx.alloc(N));
+        hipLaunchKernelGGL(pair_flag_kernel, dim3(grid_for(N)), dim3(256), 0, s, N, keys2.p, pflag.p, d_flags.p);
+        GBRS_TRY(exclusive_scan(sc, pflag.p, pidx.p, N, s));
+        uint32_t P32 = 0;
+        GBRS_TRY(fetch_last_plus(pidx.p, pflag.p, N, P32, s));
+        GBRS_HIP_CHECK(hipMemcpyAsync(&hf, d_flags.p, sizeof(hf), hipMemcpyDeviceToHost, s));
+        GBRS_HIP_CHECK(hipStreamSynchronize(s));
+        if (hf.bad_row) return fail(GBRS_ERR_INVALID, "indices hold a row id >= num_rows");
+        if (hf.duplicate) return fail(GBRS_ERR_INVALID, "duplicate (row, locus, haplotype) entry: the CSC arrays must be canonical");
+        P = P32;
+        GBRS_TRY(prow.alloc(P)); GBRS_TRY(ploc.alloc(P)); GBRS_TRY(pmask.alloc(P));
+        hipLaunchKernelGGL(emit_pairs_kernel, dim3(grid_for(N)), dim3(256), 0, s, N, keys2.p, pflag.p, pidx.p, prow.p, ploc.p,
+                           pmask.p);
+        GBRS_HIP_CHECK(hipStreamSynchronize(s));
+        keys2.release(); pflag.release(); pidx.release();
+        DevBuf<uint32_t> rflag, ridx;
+        GBRS_TRY(rflag.alloc(P)); GBRS_TRY(ridx.alloc(P));
+        hipLaunchKernelGGL(row_flag_kernel, dim3(grid_for(P)), dim3(256), 0, s, P, prow.p, rflag.p);
+        GBRS_TRY(exclusive_scan(sc, rflag.p, ridx.p, P, s));
+        uint32_t R32 = 0;
+        GBRS_TRY(fetch_last_plus(ridx.p, rflag.p, P, R32, s));
+        R1 = R32;
+        GBRS_TRY(rowstart.alloc(R1 + 1)); GBRS_TRY(row_orig.alloc(R1));
+        hipLaunchKernelGGL(row_start_kernel, dim3(grid_for(P)), dim3(256), 0, s, P, R1, rflag.p, ridx.p, prow.p, rowstart.p,
+                           row_orig.p);
+        GBRS_HIP_CHECK(hipStreamSynchronize(s));
+        rflag.release(); ridx.release(); prow.release();
+        DevBuf<uint64_t> rkey, skey;
+        DevBuf<uint32_t> ident;
+        GBRS_TRY(rkey.alloc(R1)); GBRS_TRY(skey.alloc(R1)); GBRS_TRY(ident.alloc(R1)); GBRS_TRY(srow.alloc(R1));
+        const unsigned lbits = bits_for(L - 1);
+        hipLaunchKernelGGL(row_key_kernel, dim3(grid_for(R1)), dim3(256), 0, s, R1, 0xFFFFFFFFu, lbits > 24 ? lbits - 24 : 0u,
+                           rowstart.p, ploc.p, pmask.p, rkey.p, ident.p, d_flags.p);
+        GBRS_TRY(sort_pairs<uint64_t>(sc, rkey.p, skey.p, ident.p, srow.p, R1, 64, s));
+        GBRS_TRY(head.alloc(R1)); GBRS_TRY(hincl.alloc(R1));
+        hipLaunchKernelGGL(merge_flag_kernel, dim3(grid_for(R1)), dim3(256), 0, s, R1, 1, skey.p, srow.p, rowstart.p, ploc.p,
+                           pmask.p, head.p);
+        GBRS_TRY(inclusive_scan(sc, head.p, hincl.p, R1, s));
+        uint32_t m32 = 0;
+        GBRS_HIP_CHECK(hipMemcpyAsync(&m32, hincl.p + R1 - 1, 4, hipMemcpyDeviceToHost, s));
+        GBRS_HIP_CHECK(hipStreamSynchronize(s));
+        M = m32;
+    }
+    // classes: M from rows with alignments (+1 for the empty key if any row is empty)
+    DevBuf<uint32_t> minrow;
+    DevBuf<double> weight;
+    GBRS_TRY(minrow.alloc(M + 1));
+    GBRS_TRY(weight.alloc(M + 1));
+    GBRS_HIP_CHECK(hipMemsetAsync(minrow.p, 0xFF, minrow.bytes(), s));
+    GBRS_HIP_CHECK(hipMemsetAsync(weight.p, 0, weight.bytes(), s));
+    if (R1) hipLaunchKernelGGL(ec_min_row_kernel, dim3(grid_for(R1)), dim3(256), 0, s, R1, hincl.p, srow.p, row_orig.p, count,
+                               minrow.p, weight.p);
+    hipLaunchKernelGGL(ec_empty_rows_kernel, dim3(grid_for(R)), dim3(256), 0, s, R, nnz_row.p, count, minrow.p + M,
+                       weight.p + M);
+    uint32_t empty_first = 0xFFFFFFFFu;
+    GBRS_HIP_CHECK(hipMemcpyAsync(&empty_first, minrow.p + M, 4, hipMemcpyDeviceToHost, s));
+    GBRS_HIP_CHECK(hipStreamSynchronize(s));
+    const uint64_t G = M + (empty_first != 0xFFFFFFFFu ? 1 : 0);
+    out.num_ecs = G;
+    if (G == 0) return GBRS_OK;
+    // first-seen order (dict insertion order of the reference, :77, :95): rank classes by first row
+    DevBuf<uint32_t> gid, gsorted, msorted, newid;
+    GBRS_TRY(gid.alloc(G)); GBRS_TRY(gsorted.alloc(G)); GBRS_TRY(msorted.alloc(G)); GBRS_TRY(newid.alloc(G));
+    hipLaunchKernelGGL(iota_kernel, dim3(grid_for(G)), dim3(256), 0, s, G, gid.p);
+    GBRS_TRY(sort_pairs<uint32_t>(sc, minrow.p, msorted.p, gid.p, gsorted.p, G, 32, s));
+    hipLaunchKernelGGL(ec_rank_scatter_kernel, dim3(grid_for(G)), dim3(256), 0, s, G, gsorted.p, newid.p);
+    GBRS_TRY(out.count.alloc(G));
+    {   // counts in the new order
+        DevBuf<double> tmpw;
+        GBRS_TRY(tmpw.alloc(G));
+        GBRS_HIP_CHECK(hipMemcpyAsync(tmpw.p, weight.p, G * 8, hipMemcpyDeviceToDevice, s));
+        // out.count[newid[g]] = weight[g]
+        hipLaunchKernelGGL(ec_permute_count_kernel, dim3(grid_for(G)), dim3(256), 0, s, G, newid.p, tmpw.p, out.count.p);
+        GBRS_HIP_CHECK(hipStreamSynchronize(s));
+    }
+    if (R1 == 0) return GBRS_OK;
+    // entries of the representative rows, relabelled and ordered by (hap, locus, class)
+    DevBuf<uint32_t> nent, eoff;
+    GBRS_TRY(nent.alloc(R1)); GBRS_TRY(eoff.alloc(R1));
+    hipLaunchKernelGGL(ec_count_entries_kernel, dim3(grid_for(R1)), dim3(256), 0, s, R1, head.p, srow.p, rowstart.p, pmask.p,
+                       nent.p);
+    GBRS_TRY(exclusive_scan(sc, nent.p, eoff.p, R1, s));
+    uint32_t E32 = 0;
+    GBRS_TRY(fetch_last_plus(eoff.p, nent.p, R1, E32, s));
+    const uint64_t E = E32;
+    out.n_entries = E;
+    DevBuf<uint64_t> ekeys, ekeys2;
+    GBRS_TRY(ekeys.alloc(E)); GBRS_TRY(ekeys2.alloc(E));
+    hipLaunchKernelGGL(ec_emit_entries_kernel, dim3(grid_for(R1)), dim3(256), 0, s, R1, head.p, hincl.p, srow.p, rowstart.p,
+                       ploc.p, pmask.p, eoff.p, newid.p, ekeys.p);
+    GBRS_TRY(sort_keys64(sc, ekeys.p, ekeys2.p, E, 64, s));
+    GBRS_TRY(out.indices.alloc(E));
+    hipLaunchKernelGGL(ec_split_kernel, dim3(grid_for(E)), dim3(256), 0, s, E, ekeys2.p, out.indices.p);
+    hipLaunchKernelGGL(ec_indptr_kernel, dim3(grid_for((uint64_t)H * L + 1)), dim3(256), 0, s, L, H, E, ekeys2.p,
+                       out.col_ptr.p);
+    GBRS_HIP_CHECK(hipStreamSynchronize(s));
+    GBRS_HIP_CHECK(hipGetLastError());
+    return GBRS_OK;
+}
+
 int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L, uint32_t H, uint64_t N,
                       const uint32_t *ent_row, const uint64_t *col_ptr, const double *count,
                       bool merge, bool interleave, hipStream_t s) {

@@ -170,6 +170,23 @@ int gbrs_alignment_counts(uint64_t num_rows, uint32_t num_loci, uint32_t num_hap
 
 int gbrs_em_destroy(gbrs_em_t *em);
 
+/* `gbrs compress` numeric body (gbrs/emase_utils.py:60-103): rows with identical alignment patterns
+ * collapse into equivalence classes (ECs) whose count is the sum of the member counts; classes are
+ * numbered in order of first appearance (the reference's dict insertion order, :77/:95); rows
+ * without any alignment form one class with the empty key, as they do there.  Inputs as for
+ * gbrs_em_create (several files = their rows concatenated by the caller).  create returns the
+ * number of classes and the entries per haplotype so that the caller can size the outputs of get:
+ * indptr_out[h] uint32[L+1], indices_out[h] uint32[nnz_per_hap[h]] (class ids ascending inside a
+ * column), count_out double[num_ecs]. */
+typedef struct gbrs_compress gbrs_compress_t;
+int gbrs_compress_create(uint64_t num_rows, uint32_t num_loci, uint32_t num_haps,
+                         const uint32_t *const *indptr, const uint32_t *const *indices,
+                         const double *count, int device, gbrs_compress_t **out,
+                         uint64_t *num_ecs, uint64_t *nnz_per_hap);
+int gbrs_compress_get(gbrs_compress_t *c, uint32_t *const *indptr_out, uint32_t *const *indices_out,
+                      double *count_out);
+int gbrs_compress_destroy(gbrs_compress_t *c);
+
 /* ------------------------------------------------------------------------------------------
  * HMM: per-chromosome forward-backward + Viterbi over the S = H(H+1)/2 diplotype states.
  * ---------------------------------------------------------------------------------------- */
