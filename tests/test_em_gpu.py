@@ -274,3 +274,47 @@ def test_two_rank_sharded_hip_engines(tmp_path):
     assert int(a["n"]) == int(b["n"]) == int(g["num_iters"])
     close(a["theta"], g["theta_final"])
     np.testing.assert_allclose(a["err"], g["err_history"], rtol=1e-7)
+
+
+def _random_rows_problem(R, H, L, seed, min_loci, max_loci, with_count):
+    """Rows with many loci each and no repetition structure: exercises cold tiles (dictionary cuts),
+    multi-word row sums and, above 32 loci (16 for H > 8), the long-row kernel."""
+    rng = np.random.default_rng(seed)
+    nl = rng.integers(min_loci, max_loci + 1, size=R)
+    rows = np.repeat(np.arange(R, dtype=np.int64), nl)
+    loci = np.concatenate([rng.choice(L, size=k, replace=False) for k in nl]).astype(np.int64)
+    masks = rng.integers(1, 1 << H, size=len(rows), dtype=np.int64)
+    indptr, indices = [], []
+    for h in range(H):
+        sel = (masks >> h) & 1 == 1
+        order = np.lexsort((rows[sel], loci[sel]))
+        indices.append(rows[sel][order].astype(np.uint32))
+        indptr.append(np.searchsorted(loci[sel][order], np.arange(L + 1)).astype(np.uint32))
+    count = rng.integers(1, 5, size=R).astype(np.float64) if with_count else None
+    eff = np.tile(np.maximum(np.round(rng.lognormal(7.3, 0.6, size=L)) - 99.0, 1.0), (H, 1))
+    return indptr, indices, count, np.ascontiguousarray(eff)
+
+
+@pytest.mark.parametrize("R,H,L,lo,hi,cnt", [(4000, 8, 3000, 1, 12, False),      # cold tiles, rows up to 12 words
+                                             (600, 8, 400, 20, 70, True),        # long rows (> 32 loci), weighted
+                                             (500, 16, 300, 10, 40, False),      # H = 16: long above 16 loci
+                                             (20000, 8, 20000, 1, 3, False)])    # many distinct lists: dictionary cuts
+def test_em_unstructured_rows_vs_oracle(R, H, L, lo, hi, cnt):
+    from gbrs_amd.engine import EmEngine
+    from oracle.em_oracle import EMOracle
+    indptr, indices, count, eff = _random_rows_problem(R, H, L, 123 + R, lo, hi, cnt)
+    o = EMOracle(R, L, H, indptr, indices, count)
+    o.prepare(0.0, eff)
+    theta0 = o.theta.copy()
+    o.run(tol=0.0, max_iters=4)
+    for flags in (0, 1, 2):                                      # tiles, tiles + merge, csc
+        eng = EmEngine.from_host(R, L, H, indptr, indices, count, eff, flags=flags)
+        eng.prepare(0.0)
+        close(eng.theta(), theta0)
+        eng.run(model=4, tol=0.0, max_iters=4)
+        close(eng.theta(), o.theta)
+        close(eng.expected_counts(), o.expected_read_counts())
+        inf = eng.info()
+        if flags != 2 and hi > (32 if H <= 8 else 16):
+            assert inf.num_long_rows > 0
+        eng.close()
