@@ -29,10 +29,10 @@ struct EmScalars {          // lives in device memory, one per handle
     int stop;               // set once err_sum <= target (EMfactory.py:267)
     int iters_done;         // EM steps applied to theta
     int float_error;        // a referenced row had den == 0 (FloatingPointError in the reference)
-    int pad;
+    int ticket;             // arrival counter of err_finish_kernel (reset by its last block)
 };
 
-constexpr int RED_BLOCKS = 1024;  // partial slots of the two-level deterministic reductions
+constexpr int RED_BLOCKS = 256;   // partial slots of the two-level deterministic reductions
 constexpr int RED_THREADS = 256;
 
 // theta' = theta * A / len, counts = theta * A, per-locus totals before and after, block partials.
@@ -80,38 +80,26 @@ __device__ __forceinline__ double reduce_partials(const double *__restrict__ p, 
 
 // Element-parallel M-step for H a power of two: one thread per (locus, haplotype), the H lanes of
 // a locus are adjacent, so every access is a coalesced 8-byte stream; per-locus totals by shuffles.
-// FUSED: the slot gather of the tiled layout is done here (loci with few slots); loci with more
-// than HEAVY_SLOTS slots were summed into `acc` by gather_kernel's wavefront-per-locus path.
-template <int MODE, bool FUSED>
+// A comes from `acc` (tile epilogues for single-tile loci, gather_kernel for the rest; loci without
+// any read stay 0).  Block sums of theta before/after go to RED_BLOCKS accumulator slots.
+template <int MODE>
 __global__ void __launch_bounds__(RED_THREADS)
 mstep_elem_kernel(uint32_t L, uint32_t H, double *__restrict__ theta, const double *__restrict__ acc,
-                  const double *__restrict__ eff_len, double *__restrict__ counts,
-                  double *__restrict__ tot_prev, double *__restrict__ tot_new,
-                  double *__restrict__ partials, const EmScalars *__restrict__ sc,
-                  const uint32_t *__restrict__ slot_ptr, const uint32_t *__restrict__ slot_list,
-                  const double *__restrict__ slot_partials, const double *__restrict__ acc_extra) {
+                  const double *__restrict__ acc_extra, const double *__restrict__ eff_len,
+                  double *__restrict__ counts, double *__restrict__ tot_prev, double *__restrict__ tot_new,
+                  double *__restrict__ partials, const EmScalars *__restrict__ sc) {
     __shared__ double lds[16];
     if (MODE == 0 && sc->stop) return;
     const uint64_t n = (uint64_t)L * H;
-    double p_prev = 0.0, p_new = 0.0;
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-         i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    double t = 0.0, tn = 0.0;
+    if (i < n) {
         const uint32_t l = (uint32_t)(i / H), h = (uint32_t)(i & (H - 1));
-        double a;
-        if (FUSED) {
-            const uint32_t k0 = slot_ptr[l], k1 = slot_ptr[l + 1];
-            if (k1 - k0 > (uint32_t)HEAVY_SLOTS) {
-                a = acc[i];
-            } else {
-                a = acc_extra ? acc_extra[i] : 0.0;
-                for (uint32_t k = k0; k < k1; ++k) a += slot_partials[(size_t)slot_list[k] * H + h];
-            }
-        } else {
-            a = acc[i];
-        }
-        const double t = MODE == 0 ? theta[i] : 1.0;
+        double a = acc[i];
+        if (acc_extra) a += acc_extra[i];
+        t = MODE == 0 ? theta[i] : 1.0;
         const double c = t * a;
-        const double tn = eff_len ? c / eff_len[i] : c;
+        tn = eff_len ? c / eff_len[i] : c;
         counts[i] = c;
         theta[i] = tn;
         double tp = t, tq = tn;
@@ -123,25 +111,29 @@ mstep_elem_kernel(uint32_t L, uint32_t H, double *__restrict__ theta, const doub
             tot_prev[l] = tp;
             tot_new[l] = tq;
         }
-        p_prev += t;
-        p_new += tn;
     }
-    double a = block_sum(p_prev, lds);
-    double b = block_sum(p_new, lds);
+    double a = block_sum(t, lds);
+    double b = block_sum(tn, lds);
     if (threadIdx.x == 0) {
-        partials[blockIdx.x] = a;
-        partials[RED_BLOCKS + blockIdx.x] = b;
+        atomicAdd(&partials[blockIdx.x % RED_BLOCKS], a);
+        atomicAdd(&partials[RED_BLOCKS + blockIdx.x % RED_BLOCKS], b);
     }
 }
 
-// err partials: sum_l | tot_new[l]*1e6/S_new - tot_prev[l]*1e6/S_prev |   (EMfactory.py:268-278)
 constexpr int ERR_BLOCKS = 64;
+// err_sum = sum_l | tot_new[l]*1e6/S_new - tot_prev[l]*1e6/S_prev |  (EMfactory.py:268-278), then the
+// bookkeeping of the step (err history, iteration counter, stop flag; :266-267).  Every block
+// reduces the M-step's block partials to S_prev / S_new itself (fixed order), writes its partial
+// of err_sum and takes a ticket; the block that draws the last ticket sums the partials in fixed
+// order, so the result does not depend on the order in which blocks finish.
 __global__ void __launch_bounds__(RED_THREADS)
-err_kernel(uint32_t L, int nblocks, const double *__restrict__ tot_prev,
-           const double *__restrict__ tot_new, double *__restrict__ partials,
-           const EmScalars *__restrict__ sc) {
+err_finish_kernel(uint32_t L, int nblocks, const double *__restrict__ tot_prev,
+                  const double *__restrict__ tot_new, double *__restrict__ partials,
+                  EmScalars *__restrict__ sc, double target_err, double *__restrict__ err_hist,
+                  int err_hist_cap) {
     __shared__ double lds[16];
     __shared__ double s_sums[2];
+    __shared__ int s_last;
     if (sc->stop) return;
     double a = reduce_partials(partials, nblocks, lds);
     double b = reduce_partials(partials + RED_BLOCKS, nblocks, lds);
@@ -155,26 +147,31 @@ err_kernel(uint32_t L, int nblocks, const double *__restrict__ tot_prev,
     for (uint32_t l = blockIdx.x * blockDim.x + threadIdx.x; l < L; l += gridDim.x * blockDim.x)
         e += fabs(tot_new[l] * cn - tot_prev[l] * cp);
     e = block_sum(e, lds);
-    if (threadIdx.x == 0) partials[2 * RED_BLOCKS + blockIdx.x] = e;
-}
-
-__global__ void __launch_bounds__(RED_THREADS)
-finish_kernel(int nblocks, int nerr, const double *__restrict__ partials, EmScalars *__restrict__ sc,
-              double target_err, double *__restrict__ err_hist, int err_hist_cap) {
-    __shared__ double lds[16];
-    if (sc->stop) return;
-    double a = reduce_partials(partials, nblocks, lds);
-    double b = reduce_partials(partials + RED_BLOCKS, nblocks, lds);
-    double e = reduce_partials(partials + 2 * RED_BLOCKS, nerr, lds);
     if (threadIdx.x == 0) {
-        sc->s_prev = a;
-        sc->s_new = b;
-        sc->err_sum = e;
+        partials[2 * RED_BLOCKS + blockIdx.x] = e;
+        __threadfence();                                        // publish before the ticket
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the compiler may drop the fence's own wait)
+        const int ticket = atomicAdd(&sc->ticket, 1);
+        s_last = ticket == (int)gridDim.x - 1;
+        if (s_last) __threadfence();                            // acquire the other blocks' partials
+    }
+    __syncthreads();
+    if (!s_last) return;
+    double tot = 0.0;
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += blockDim.x)
+        tot += __hip_atomic_load(&partials[2 * RED_BLOCKS + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    tot = block_sum(tot, lds);
+    for (int i = threadIdx.x; i < 2 * RED_BLOCKS; i += blockDim.x) partials[i] = 0.0;   // for the next M-step
+    if (threadIdx.x == 0) {
+        sc->ticket = 0;
+        sc->s_prev = s_sums[0];
+        sc->s_new = s_sums[1];
+        sc->err_sum = tot;
         const int it = sc->iters_done;
-        if (err_hist && it < err_hist_cap) err_hist[it] = e;
+        if (err_hist && it < err_hist_cap) err_hist[it] = tot;
         sc->iters_done = it + 1;
-        if (!(e > target_err)) sc->stop = 1;
-        if (!(a > 0.0) || !(b > 0.0) || e != e) sc->float_error = 1;
+        if (!(tot > target_err)) sc->stop = 1;
+        if (!(s_sums[0] > 0.0) || !(s_sums[1] > 0.0) || tot != tot) sc->float_error = 1;
     }
 }
 
@@ -356,7 +353,8 @@ struct gbrs_em {
     uint32_t flags = 0;
 
     int layout = 0;               // 0 = csc-direct, 1 = packed row tiles
-    bool acc_in_slots = false;    // last E-step left A in the tile slots (fused gather in the M-step)
+    bool acc_needs_extra = false; // last E-step left the long-row sums in tl.acc_extra for the M-step to add
+    bool acc_external = false;    // the caller all-reduces acc (sharded): always materialise all of it
     TileLayout tl;
 
     // layout 0
@@ -398,11 +396,12 @@ int em_estep_tiles_h(gbrs_em *em) {
         const dim3 grid((unsigned)tl.n_tiles), block(TILE_THREADS);
         if (tl.weighted)
             hipLaunchKernelGGL((tile_estep_kernel<HT, true, ONES>), grid, block, 0, em->stream, em->H, tl.tiles.p,
-                               tl.words.p, tl.dict.p, tl.word_weight.p, em->theta.p, tl.partials.p, em->scalars.p);
+                               tl.words.p, tl.dict.p, tl.word_weight.p, em->theta.p, tl.partials.p, tl.slot_dest.p,
+                               em->acc.p, em->scalars.p);
         else
             hipLaunchKernelGGL((tile_estep_kernel<HT, false, ONES>), grid, block, 0, em->stream, em->H, tl.tiles.p,
                                tl.words.p, tl.dict.p, (const double *)nullptr, em->theta.p, tl.partials.p,
-                               em->scalars.p);
+                               tl.slot_dest.p, em->acc.p, em->scalars.p);
     }
     return GBRS_OK;
 }
@@ -428,16 +427,18 @@ int em_estep_tiles(gbrs_em *em, bool materialize) {
     }
     uint32_t HP = 1;
     while (HP < em->H) HP <<= 1;
-    const uint64_t elems = (uint64_t)em->L * em->H;
     const bool pow2 = (em->H & (em->H - 1)) == 0;
-    const bool fuse = !materialize && pow2;
-    em->acc_in_slots = fuse;
-    const unsigned light = fuse ? 0u : (unsigned)((elems + 255) / 256);
+    const bool all = materialize || em->acc_external || !pow2;     // write every element of acc
+    const uint64_t elems = all ? (uint64_t)em->L * em->H : (uint64_t)tl.n_light * em->H;
+    const unsigned light = (unsigned)((elems + 255) / 256);
     const unsigned heavy = (unsigned)((tl.n_heavy + 3) / 4);
+    em->acc_needs_extra = !all && tl.n_long > 0;
     if (light + heavy > 0)
-    hipLaunchKernelGGL(gather_kernel, dim3(light + heavy), dim3(256), 0, em->stream, em->L, em->H, HP, light,
-                       (uint32_t)tl.n_heavy, tl.slot_ptr.p, tl.slot_list.p, tl.heavy_loci.p, tl.partials.p,
-                       tl.n_long ? tl.acc_extra.p : (const double *)nullptr, em->acc.p, em->scalars.p, ONES ? 0 : 1);
+        hipLaunchKernelGGL(gather_kernel, dim3(light + heavy), dim3(256), 0, em->stream, em->L, em->H, HP, light,
+                           (uint32_t)tl.n_heavy, all ? 1 : 0, (uint32_t)tl.n_light, tl.light_loci.p, tl.slot_ptr.p,
+                           tl.slot_list.p, tl.heavy_loci.p, tl.locus_class.p, tl.partials.p,
+                           (tl.n_long && all) ? tl.acc_extra.p : (const double *)nullptr, em->acc.p, em->scalars.p,
+                           ONES ? 0 : 1);
     GBRS_HIP_CHECK(hipGetLastError());
     return GBRS_OK;
 }
@@ -446,7 +447,7 @@ int em_estep_tiles(gbrs_em *em, bool materialize) {
 template <bool ONES>
 int em_estep(gbrs_em *em, bool materialize = false) {
     if (em->layout == 1) return em_estep_tiles<ONES>(em, materialize);
-    em->acc_in_slots = false;
+    em->acc_needs_extra = false;
     const uint64_t n = em->N;
     const uint32_t ncols = em->H * em->L;
     GBRS_HIP_CHECK(hipMemsetAsync(em->acc.p, 0, em->acc.bytes(), em->stream));
@@ -463,9 +464,8 @@ int em_estep(gbrs_em *em, bool materialize = false) {
 }
 
 // M-step launch: element-parallel when H is a power of two, thread-per-locus otherwise.
-// fused: take A straight from the tile slots (single-GPU path) instead of em->acc.
 template <int MODE>
-int em_launch_mstep(gbrs_em *em, bool fused, int *nb_out) {
+int em_launch_mstep(gbrs_em *em) {
     const bool pow2 = (em->H & (em->H - 1)) == 0;
     const double *len = em->has_len ? em->eff_len.p : nullptr;
     if (!pow2) {
@@ -473,35 +473,22 @@ int em_launch_mstep(gbrs_em *em, bool fused, int *nb_out) {
         hipLaunchKernelGGL(mstep_kernel<MODE>, dim3(nb), dim3(RED_THREADS), 0, em->stream, em->L, em->H,
                            em->theta.p, em->acc.p, len, em->counts.p, em->tot_prev.p, em->tot_new.p,
                            em->partials.p, em->scalars.p);
-        *nb_out = nb;
         return GBRS_OK;
     }
     const uint64_t n = (uint64_t)em->L * em->H;
-    const int nb = (int)std::min<uint64_t>(RED_BLOCKS, (n + RED_THREADS - 1) / RED_THREADS);
-    const TileLayout &tl = em->tl;
-    if (fused)
-        hipLaunchKernelGGL((mstep_elem_kernel<MODE, true>), dim3(nb), dim3(RED_THREADS), 0, em->stream, em->L, em->H,
-                           em->theta.p, em->acc.p, len, em->counts.p, em->tot_prev.p, em->tot_new.p, em->partials.p,
-                           em->scalars.p, tl.slot_ptr.p, tl.slot_list.p, tl.partials.p,
-                           tl.n_long ? tl.acc_extra.p : (const double *)nullptr);
-    else
-        hipLaunchKernelGGL((mstep_elem_kernel<MODE, false>), dim3(nb), dim3(RED_THREADS), 0, em->stream, em->L, em->H,
-                           em->theta.p, em->acc.p, len, em->counts.p, em->tot_prev.p, em->tot_new.p, em->partials.p,
-                           em->scalars.p, (const uint32_t *)nullptr, (const uint32_t *)nullptr,
-                           (const double *)nullptr, (const double *)nullptr);
-    *nb_out = nb;
+    const unsigned nb = (unsigned)((n + RED_THREADS - 1) / RED_THREADS);
+    hipLaunchKernelGGL(mstep_elem_kernel<MODE>, dim3(nb), dim3(RED_THREADS), 0, em->stream, em->L, em->H, em->theta.p,
+                       em->acc.p, em->acc_needs_extra ? em->tl.acc_extra.p : (const double *)nullptr, len,
+                       em->counts.p, em->tot_prev.p, em->tot_new.p, em->partials.p, em->scalars.p);
     return GBRS_OK;
 }
 
 // Everything after the E-step of one EM iteration.
 int em_finish_step(gbrs_em *em, double target_err) {
-    int nb = 0;
-    GBRS_TRY(em_launch_mstep<0>(em, em->acc_in_slots, &nb));
+    GBRS_TRY(em_launch_mstep<0>(em));
     const int ne = (int)std::min<uint64_t>(ERR_BLOCKS, (em->L + RED_THREADS - 1) / RED_THREADS);
-    hipLaunchKernelGGL(err_kernel, dim3(ne), dim3(RED_THREADS), 0, em->stream, em->L, nb,
-                       em->tot_prev.p, em->tot_new.p, em->partials.p, em->scalars.p);
-    hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(RED_THREADS), 0, em->stream, nb, ne, em->partials.p,
-                       em->scalars.p, target_err, em->err_hist.p, em->err_hist_cap);
+    hipLaunchKernelGGL(err_finish_kernel, dim3(ne), dim3(RED_THREADS), 0, em->stream, em->L, RED_BLOCKS, em->tot_prev.p,
+                       em->tot_new.p, em->partials.p, em->scalars.p, target_err, em->err_hist.p, em->err_hist_cap);
     GBRS_HIP_CHECK(hipGetLastError());
     return GBRS_OK;
 }
@@ -525,15 +512,15 @@ int em_read_times(gbrs_em *em) {
 }
 
 int em_finish_prepare(gbrs_em *em, double pseudocount) {
-    int nb = 0;
-    GBRS_TRY(em_launch_mstep<1>(em, em->acc_in_slots, &nb));
-    nb = em->red_blocks();
+    GBRS_TRY(em_launch_mstep<1>(em));
+    const int nb = em->red_blocks();
     if (pseudocount > 0.0) {
         hipLaunchKernelGGL(pseudo_add_kernel, dim3(nb), dim3(RED_THREADS), 0, em->stream, em->L,
                            em->H, pseudocount, em->theta.p, em->partials.p);
         hipLaunchKernelGGL(pseudo_scale_kernel, dim3(nb), dim3(RED_THREADS), 0, em->stream,
                            (uint64_t)em->L * em->H, nb, em->theta.p, em->partials.p, em->scalars.p);
     }
+    GBRS_HIP_CHECK(hipMemsetAsync(em->partials.p, 0, em->partials.bytes(), em->stream));
     GBRS_HIP_CHECK(hipGetLastError());
     em->prepared = true;
     return GBRS_OK;
@@ -642,6 +629,8 @@ int em_create_impl(uint64_t R, uint32_t L, uint32_t H, const uint32_t *const *in
     GBRS_TRY(em->scalars.alloc(1));
     GBRS_HIP_CHECK(hipMemset(em->scalars.p, 0, sizeof(EmScalars)));
     GBRS_HIP_CHECK(hipMemset(em->theta.p, 0, em->theta.bytes()));
+    GBRS_HIP_CHECK(hipMemset(em->acc.p, 0, em->acc.bytes()));
+    GBRS_HIP_CHECK(hipMemset(em->partials.p, 0, em->partials.bytes()));
     GBRS_HIP_CHECK(hipMemset(em->counts.p, 0, em->counts.bytes()));
     if (count) {
         GBRS_TRY(em->count.alloc(R));
@@ -761,8 +750,8 @@ int gbrs_em_prepare_partial(gbrs_em_t *em, void **partial_dev, uint64_t *n_elems
     if (!em) return fail(GBRS_ERR_INVALID, "handle is NULL");
     GBRS_TRY(select_device(em->device));
     GBRS_TRY(em_reset_scalars(em, false));
+    em->acc_external = true;
     GBRS_TRY(em_estep<true>(em, true));
-    em->acc_in_slots = false;
     if (partial_dev) *partial_dev = em->acc.p;
     if (n_elems) *n_elems = (uint64_t)em->L * em->H;
     return GBRS_OK;
@@ -785,8 +774,8 @@ int gbrs_em_estep_partial(gbrs_em_t *em, void **partial_dev, uint64_t *n_elems) 
     if (!em) return fail(GBRS_ERR_INVALID, "handle is NULL");
     if (!em->prepared) return fail(GBRS_ERR_STATE, "prepare() has not been called");
     GBRS_TRY(select_device(em->device));
+    em->acc_external = true;
     GBRS_TRY(em_estep<false>(em, true));
-    em->acc_in_slots = false;
     if (partial_dev) *partial_dev = em->acc.p;
     if (n_elems) *n_elems = (uint64_t)em->L * em->H;
     return GBRS_OK;

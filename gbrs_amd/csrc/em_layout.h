@@ -29,7 +29,8 @@ __host__ __device__ constexpr int max_row_words(int H) { return 1 << pos_bits(H)
 #endif
 constexpr int LDS_THETA_DOUBLES = GBRS_LDS_DOUBLES;        // theta of the tile: D_MAX * H doubles
 constexpr int LDS_ACC_DOUBLES = GBRS_LDS_DOUBLES + 64;     // privatised partial sums
-constexpr int HEAVY_SLOTS = 32;                // loci with more slots get a whole wave in the gather
+constexpr uint32_t SLOT_DIRECT = 0x80000000u;
+constexpr int HEAVY_SLOTS = 1;                 // loci with more slots get a whole wave in the gather
 
 struct TileHdr {
     uint32_t batch_base;   // first batch of the tile in `words`
@@ -44,7 +45,7 @@ struct TileLayout {
     uint64_t n_rows_in = 0;      // rows with at least one alignment
     uint64_t n_rows = 0;         // rows in the layout (after optional merging), short rows only
     uint64_t n_long = 0;         // rows with more than MAX_ROW_WORDS loci
-    uint64_t n_tiles = 0, n_batches = 0, n_slots = 0, n_heavy = 0;
+    uint64_t n_tiles = 0, n_batches = 0, n_slots = 0, n_heavy = 0, n_light = 0;
     uint32_t d_max = 0;          // dictionary capacity used when cutting tiles
     bool weighted = false;       // per-row weights present (count given or rows merged)
 
@@ -56,6 +57,10 @@ struct TileLayout {
     DevBuf<uint32_t> slot_ptr;       // L + 1
     DevBuf<uint32_t> slot_list;      // n_slots, grouped by locus, ascending slot inside a locus
     DevBuf<uint32_t> heavy_loci;     // loci with more than HEAVY_SLOTS slots
+    DevBuf<uint32_t> light_loci;     // loci with 2..HEAVY_SLOTS slots
+    DevBuf<uint32_t> slot_dest;      // n_slots: where the tile epilogue stores a slot: its own index in
+                                     // `partials`, or SLOT_DIRECT | locus when the locus has this one slot only
+    DevBuf<uint8_t> locus_class;     // L: 0 no slot, 1 one slot (sum goes straight to acc), 2 few, 3 heavy
     DevBuf<double> partials;         // n_slots * H
     // long rows (kept in pair form)
     DevBuf<uint64_t> long_ptr;       // n_long + 1 offsets into long_loc / long_mask

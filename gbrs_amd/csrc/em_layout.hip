@@ -427,6 +427,15 @@ __global__ void slot_ptr_kernel(uint32_t L, uint64_t n_slots, const uint32_t *__
     slot_ptr[l] = (uint32_t)lo;
 }
 
+__global__ void locus_class_kernel(uint32_t L, const uint32_t *__restrict__ slot_ptr, const uint32_t *__restrict__ slot_list,
+                                   uint8_t *__restrict__ cls, uint32_t *__restrict__ slot_dest) {
+    const uint32_t l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= L) return;
+    const uint32_t k0 = slot_ptr[l], cnt = slot_ptr[l + 1] - k0;
+    cls[l] = cnt == 0 ? 0 : (cnt == 1 ? 1 : (cnt <= (uint32_t)HEAVY_SLOTS ? 2 : 3));
+    if (cnt == 1) slot_dest[slot_list[k0]] = SLOT_DIRECT | l;
+}
+
 __global__ void long_rows_kernel(uint64_t n_long, uint64_t first, const uint32_t *__restrict__ srow,
                                  const uint32_t *__restrict__ rowstart, const uint32_t *__restrict__ row_orig,
                                  const double *__restrict__ count, uint64_t *__restrict__ len,
@@ -771,6 +780,8 @@ int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L, uint32_t H, uint6
     out.n_pairs = out.n_rows = out.n_rows_in = out.n_long = out.n_tiles = out.n_batches = out.n_slots = 0;
     GBRS_TRY(out.slot_ptr.alloc((size_t)L + 1));
     GBRS_HIP_CHECK(hipMemsetAsync(out.slot_ptr.p, 0, out.slot_ptr.bytes(), s));
+    GBRS_TRY(out.locus_class.alloc(L));
+    GBRS_HIP_CHECK(hipMemsetAsync(out.locus_class.p, 0, out.locus_class.bytes(), s));
     if (N == 0) { GBRS_HIP_CHECK(hipStreamSynchronize(s)); return GBRS_OK; }
 
     // 1. entries -> sorted (row, locus, hap) keys
@@ -983,14 +994,23 @@ int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L, uint32_t H, uint6
         GBRS_HIP_CHECK(hipStreamSynchronize(s));
     }
     GBRS_TRY(out.partials.alloc(std::max<size_t>((size_t)NS * H, 1)));
+    GBRS_TRY(out.slot_dest.alloc(std::max<uint32_t>(NS, 1)));
+    if (NS) hipLaunchKernelGGL(iota_kernel, dim3(grid_for(NS)), dim3(256), 0, s, (uint64_t)NS, out.slot_dest.p);
+    hipLaunchKernelGGL(locus_class_kernel, dim3(grid_for(L)), dim3(256), 0, s, L, out.slot_ptr.p, out.slot_list.p,
+                       out.locus_class.p, out.slot_dest.p);
     // 12. loci with many slots get a whole wave in the gather kernel
     {
-        std::vector<uint32_t> sp((size_t)L + 1), heavy;
+        std::vector<uint32_t> sp((size_t)L + 1), heavy, lightv;
         GBRS_HIP_CHECK(hipMemcpyAsync(sp.data(), out.slot_ptr.p, sp.size() * 4, hipMemcpyDeviceToHost, s));
         GBRS_HIP_CHECK(hipStreamSynchronize(s));
         for (uint32_t l = 0; l < L; ++l)
             if (sp[l + 1] - sp[l] > (uint32_t)HEAVY_SLOTS) heavy.push_back(l);
+            else if (sp[l + 1] - sp[l] >= 2) lightv.push_back(l);
         out.n_heavy = heavy.size();
+        out.n_light = lightv.size();
+        GBRS_TRY(out.light_loci.alloc(std::max<size_t>(lightv.size(), 1)));
+        if (!lightv.empty())
+            GBRS_HIP_CHECK(hipMemcpyAsync(out.light_loci.p, lightv.data(), lightv.size() * 4, hipMemcpyHostToDevice, s));
         GBRS_TRY(out.heavy_loci.alloc(std::max<size_t>(heavy.size(), 1)));
         if (!heavy.empty())
             GBRS_HIP_CHECK(hipMemcpyAsync(out.heavy_loci.p, heavy.data(), heavy.size() * 4, hipMemcpyHostToDevice, s));
