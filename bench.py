@@ -44,6 +44,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hmm", action="store_true")
     ap.add_argument("--no-merged-line", action="store_true")
+    ap.add_argument("--from-host", action="store_true", help="also time gbrs_em_create from host (numpy) arrays: PCIe copy + layout build")
     ap.add_argument("--cpu-rows", type=int, default=2_000_000)
     ap.add_argument("--cpu-iters", type=int, default=10)
     ap.add_argument("--hmm-samples", type=int, default=1)
@@ -76,6 +77,18 @@ def em_bench(args, rank, world, torch, dist):
         flags=(_lib.GBRS_EM_MERGE_IDENTICAL_ROWS if args.merge else 0) | args.flags)
     t_create = time.perf_counter() - t0
     n_entries = prob["N"]
+    t_host = None
+    if args.from_host and world == 1:
+        import numpy as np
+        ip = [t.cpu().numpy().view(np.uint32) for t in prob["indptr"]]
+        ix = [t.cpu().numpy().view(np.uint32) for t in prob["indices"]]
+        ef = prob["eff_len"].cpu().numpy()
+        t1 = time.perf_counter()
+        e2 = EmEngine.from_host(prob["R"], prob["L"], prob["H"], ip, ix, None, ef,
+                                device=torch.cuda.current_device())
+        t_host = time.perf_counter() - t1
+        e2.close()
+        del ip, ix
     del prob
     torch.cuda.empty_cache()
 
@@ -117,7 +130,7 @@ def em_bench(args, rank, world, torch, dist):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     inf = eng.info()
-    res = dict(dt=dt, t_gen=t_gen, t_create=t_create, N=n_entries, info=inf)
+    res = dict(dt=dt, t_gen=t_gen, t_create=t_create, t_create_host=t_host, N=n_entries, info=inf)
     if world == 1 and not args.merge:
         # time to solution with the reference's default stopping rule (tol = 1e-4 TPM units)
         eng.prepare(0.0)
@@ -266,7 +279,8 @@ def main():
                      "traffic": None, "kernel": "E-step", "kernel_ms": em["estep_ms"],
                      "step_ms_events": em["step_ms"], "algorithmic_bytes": algo, "layout_bytes": moved,
                      "priced_bytes": priced},
-        "setup_s": {"generate": em["t_gen"], "create_layout": em["t_create"]},
+        "setup_s": {"generate": em["t_gen"], "create_layout": em["t_create"],
+                    "create_from_host_arrays": em["t_create_host"]},
     }
     if "solve" in em:
         line["time_to_solution"] = dict(em["solve"], rule="err_sum <= 1e6*tol, tol=1e-4 (gbrs quantify default)")
