@@ -322,6 +322,17 @@ csc_acc_kernel(uint64_t n, uint32_t ncols, uint32_t L, uint32_t H,
     }
 }
 
+// largest row id of the uploaded arrays (inputs that arrive as device pointers cannot be checked on
+// the host, and an out-of-range id would make the scatter kernels fault)
+__global__ void __launch_bounds__(256)
+max_row_kernel(uint64_t n, const uint32_t *__restrict__ ent_row, unsigned int *__restrict__ out) {
+    unsigned int m = 0;
+    for (uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (uint64_t)gridDim.x * blockDim.x)
+        m = max(m, ent_row[k]);
+    for (int off = 32; off > 0; off >>= 1) m = max(m, (unsigned int)__shfl_down((int)m, off, WAVE));
+    if ((threadIdx.x & 63) == 0) atomicMax(out, m);
+}
+
 // `--report-alignment-counts` on the CSC arrays (AlignmentPropertyMatrix.py:389-459).
 //   nnz_row[r]   number of stored entries of row r   (sum LOCUS then HAPLOTYPE)
 //   nloc_row[r]  number of distinct loci of row r    (nnz of the HAPLOTYPE-summed matrix)
@@ -644,6 +655,16 @@ int em_create_impl(uint64_t R, uint32_t L, uint32_t H, const uint32_t *const *in
         GBRS_HIP_CHECK(hipStreamSynchronize(em->stream));
     }
     GBRS_HIP_CHECK(hipDeviceSynchronize());
+    if (on_device && n > 0) {
+        DevBuf<unsigned int> d_max;
+        GBRS_TRY(d_max.alloc(1));
+        GBRS_HIP_CHECK(hipMemsetAsync(d_max.p, 0, sizeof(unsigned int), em->stream));
+        hipLaunchKernelGGL(max_row_kernel, dim3(1024), dim3(256), 0, em->stream, n, em->ent_row.p, d_max.p);
+        unsigned int mx = 0;
+        GBRS_HIP_CHECK(hipMemcpyAsync(&mx, d_max.p, sizeof(mx), hipMemcpyDeviceToHost, em->stream));
+        GBRS_HIP_CHECK(hipStreamSynchronize(em->stream));
+        if (mx >= R) return fail(GBRS_ERR_INVALID, "indices hold row id %u >= num_rows", mx);
+    }
     if (!(flags & GBRS_EM_LAYOUT_CSC) && H <= 16 && n < 0xFFFFFFFFull) {
         GBRS_TRY(build_tile_layout(em->tl, R, L, H, n, em->ent_row.p, em->col_ptr.p,
                                    count ? em->count.p : nullptr, (flags & GBRS_EM_MERGE_IDENTICAL_ROWS) != 0,

@@ -318,3 +318,25 @@ def test_em_unstructured_rows_vs_oracle(R, H, L, lo, hi, cnt):
         if flags != 2 and hi > (32 if H <= 8 else 16):
             assert inf.num_long_rows > 0
         eng.close()
+
+
+def test_create_rejects_bad_inputs():
+    """Malformed inputs must come back as errors, never reach a kernel (host and device inputs)."""
+    import torch
+    from gbrs_amd import _lib
+    from gbrs_amd.engine import EmEngine
+    ip = [np.array([0, 2, 3], dtype=np.uint32)]
+    with pytest.raises(_lib.GbrsHipError, match="row id"):
+        EmEngine.from_host(3, 2, 1, ip, [np.array([0, 7, 1], dtype=np.uint32)])
+    with pytest.raises(_lib.GbrsHipError, match="non-decreasing"):
+        EmEngine.from_host(3, 2, 1, [np.array([0, 3, 2], dtype=np.uint32)], [np.array([0, 1], dtype=np.uint32)])
+    with pytest.raises(_lib.GbrsHipError, match="duplicate"):
+        EmEngine.from_host(3, 2, 1, ip, [np.array([1, 1, 0], dtype=np.uint32)])
+    d_ip = torch.tensor([0, 2, 3], dtype=torch.int32, device="cuda")
+    d_ix = torch.tensor([0, 9, 1], dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    for flags in (0, _lib.GBRS_EM_LAYOUT_CSC):
+        with pytest.raises(_lib.GbrsHipError, match="row id"):
+            EmEngine.from_device(3, 2, 1, [d_ip.data_ptr()], [d_ix.data_ptr()], flags=flags)
+    with pytest.raises(_lib.GbrsHipError):
+        EmEngine.from_host(3, 2, 40, ip * 40, [np.array([0, 1, 2], dtype=np.uint32)] * 40)     # H > 32
