@@ -166,6 +166,16 @@ __device__ __forceinline__ double wave_sum_dpp(double v) {
     return t;
 }
 
+// Workgroup barrier for the recursion loops: waits for this wave's LDS traffic only.  A plain
+// __syncthreads() also drains vmcnt, i.e. it would wait every step for the step's global stores
+// and for the transition block prefetched for the NEXT step (1-2 us each) - the whole point of
+// the prefetch is that those stay in flight across the barrier.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+
 // sum of the S values of an LDS vector, computed redundantly by every wave (no extra barrier)
 __device__ __forceinline__ double wave_sum_lds(const double *x, int S) {
     double s = 0.0;
@@ -215,7 +225,7 @@ __global__ void exp_emission_kernel(int64_t n, const double *__restrict__ e, dou
 // The kernel stores x, alpha-hat = y/Z and 1/Z; hmm_outputs_kernel turns them into the
 // log-domain alpha and scaler of the reference (same quantities up to rounding) in parallel.
 // delta stays in the log domain on T itself: additions and max only, i.e. exact.
-template <int KMAX, int MAXT>
+template <int KMAX, int MAXT, bool EXACT>
 __global__ void __launch_bounds__(MAXT)
 forward_viterbi_kernel(int S, int64_t genes_per_sample, int64_t bp_per_sample,
                        const ChromDesc *__restrict__ chroms, const double *__restrict__ tprob,
@@ -234,11 +244,20 @@ forward_viterbi_kernel(int S, int64_t genes_per_sample, int64_t bp_per_sample,
     const int j = threadIdx.x / LPS, q = threadIdx.x % LPS;
     const bool active = j < S;
     const bool owner = active && q == 0;
+    const int KPT = EXACT ? KMAX : (S + LPS - 1) / LPS;   // columns per lane (<= KMAX)
+    // EXACT: S == LPS * KMAX, so every (lane, m) is a real column and no access needs a predicate;
+    // the padding threads (j >= S) then simply shadow the last state and never store
+    const int jr = EXACT ? min(j, S - 1) : j;
     const int64_t g0 = (int64_t)sample * genes_per_sample + cd.gene_off;
     const int n_steps = min(n, cd.n_trans + 1);   // gene i needs T[i-1]
     double *buf = lds;
     int cur = 0;
 
+#if defined(HMM_ONLY_DELTA)
+    if (role == 0) return;
+#elif defined(HMM_ONLY_ALPHA)
+    if (role == 1) return;
+#endif
     if (role == 0) {
         const double *E = eprob + g0 * S, *PE = peprob + g0 * S;
         double *XS = xsum + g0 * S, *AH = ahat + g0 * S, *IZ = invz + g0;
@@ -253,8 +272,8 @@ forward_viterbi_kernel(int S, int64_t genes_per_sample, int64_t bp_per_sample,
         double pn[KMAX];
 #pragma unroll
         for (int m = 0; m < KMAX; ++m) {
-            const int k = q + LPS * m;
-            pn[m] = (active && k < S && cd.n_trans > 0) ? P[(int64_t)j * S + k] : 0.0;
+            const int k = q * KPT + m;          // contiguous chunk per lane: wide loads
+            pn[m] = ((EXACT || (active && m < KPT && k < S)) && cd.n_trans > 0) ? P[(int64_t)jr * S + k] : 0.0;
         }
         double pe_next = (owner && n > 1) ? PE[(int64_t)S + j] : 0.0;
         __syncthreads();
@@ -273,16 +292,16 @@ forward_viterbi_kernel(int S, int64_t genes_per_sample, int64_t bp_per_sample,
                 const double *Pn = P + (int64_t)i * S * S;
 #pragma unroll
                 for (int m = 0; m < KMAX; ++m) {
-                    const int k = q + LPS * m;
-                    if (active && k < S) pn[m] = Pn[(int64_t)j * S + k];
+                    const int k = q * KPT + m;          // contiguous chunk per lane: wide loads
+                    if (EXACT || (active && m < KPT && k < S)) pn[m] = Pn[(int64_t)jr * S + k];
                 }
             }
             const double *y_prev = buf + cur * S;
             double s0 = 0.0, s1 = 0.0, s2 = 0.0;
 #pragma unroll
             for (int m = 0; m < KMAX; ++m) {
-                const int k = q + LPS * m;
-                if (active && k < S) {
+                const int k = q * KPT + m;          // contiguous chunk per lane: wide loads
+                if (EXACT || (active && m < KPT && k < S)) {
                     const double yp = y_prev[k];
                     if (m % 3 == 0) s0 = fma(yp, pc[m], s0);
                     else if (m % 3 == 1) s1 = fma(yp, pc[m], s1);
@@ -296,7 +315,7 @@ forward_viterbi_kernel(int S, int64_t genes_per_sample, int64_t bp_per_sample,
                 buf[nxt * S + j] = y_own;
                 XS[(int64_t)i * S + j] = x;
             }
-            __syncthreads();
+            lds_barrier();
             cur = nxt;
             inv_z = fast_recip_pos(wave_sum_lds(buf + cur * S, S));
             if (owner) {
@@ -322,8 +341,8 @@ forward_viterbi_kernel(int S, int64_t genes_per_sample, int64_t bp_per_sample,
     double tn[KMAX];
 #pragma unroll
     for (int m = 0; m < KMAX; ++m) {
-        const int k = q + LPS * m;
-        tn[m] = (active && k < S && cd.n_trans > 0) ? T[(int64_t)j * S + k] : 0.0;
+        const int k = q * KPT + m;          // contiguous chunk per lane: wide loads
+        tn[m] = ((EXACT || (active && m < KPT && k < S)) && cd.n_trans > 0) ? T[(int64_t)jr * S + k] : 0.0;
     }
     double e_next = (owner && n > 1) ? E[(int64_t)S + j] : 0.0;
     __syncthreads();
@@ -339,8 +358,8 @@ forward_viterbi_kernel(int S, int64_t genes_per_sample, int64_t bp_per_sample,
             const double *Tn = T + (int64_t)i * S * S;
 #pragma unroll
             for (int m = 0; m < KMAX; ++m) {
-                const int k = q + LPS * m;
-                if (active && k < S) tn[m] = Tn[(int64_t)j * S + k];
+                const int k = q * KPT + m;          // contiguous chunk per lane: wide loads
+                if (EXACT || (active && m < KPT && k < S)) tn[m] = Tn[(int64_t)jr * S + k];
             }
         }
         const double *d_prev = buf + cur * S;
@@ -348,8 +367,8 @@ forward_viterbi_kernel(int S, int64_t genes_per_sample, int64_t bp_per_sample,
         int best_k = 0x7fffffff;
 #pragma unroll
         for (int m = 0; m < KMAX; ++m) {
-            const int k = q + LPS * m;
-            if (active && k < S) {
+            const int k = q * KPT + m;          // contiguous chunk per lane: wide loads
+            if (EXACT || (active && m < KPT && k < S)) {
                 const double dv = d_prev[k] + tc[m];
                 if (dv > best) { best = dv; best_k = k; }   // ascending k: first max kept
             }
@@ -365,7 +384,7 @@ forward_viterbi_kernel(int S, int64_t genes_per_sample, int64_t bp_per_sample,
             }
         }
         if (!real) break;
-        __syncthreads();
+        lds_barrier();
         cur = nxt;
     }
     // sid = argmax delta[:, n-1] (first max)
@@ -384,7 +403,7 @@ forward_viterbi_kernel(int S, int64_t genes_per_sample, int64_t bp_per_sample,
 //     bhat_i[j] = (sum_k P_i[k,j] * bhat_{i+1}[k] * pe_{i+1}[k]) / Z_i          bhat_{n-1} = 1/Z_{n-1}
 // pprob_t holds the transposed blocks Pt[i][j][k] = exp(T[i][k][j]) so that a thread reads a row.
 // beta = log(bhat) and the posterior are produced by hmm_outputs_kernel.
-template <int KMAX, int MAXT>
+template <int KMAX, int MAXT, bool EXACT>
 __global__ void __launch_bounds__(MAXT)
 backward_kernel(int S, int64_t genes_per_sample, const ChromDesc *__restrict__ chroms,
                 const double *__restrict__ pprob_t, const double *__restrict__ peprob,
@@ -398,6 +417,10 @@ backward_kernel(int S, int64_t genes_per_sample, const ChromDesc *__restrict__ c
     const int j = threadIdx.x / LPS, q = threadIdx.x % LPS;
     const bool active = j < S;
     const bool owner = active && q == 0;
+    const int KPT = EXACT ? KMAX : (S + LPS - 1) / LPS;   // columns per lane (<= KMAX)
+    // EXACT: S == LPS * KMAX, so every (lane, m) is a real column and no access needs a predicate;
+    // the padding threads (j >= S) then simply shadow the last state and never store
+    const int jr = EXACT ? min(j, S - 1) : j;
     const int64_t g0 = (int64_t)sample * genes_per_sample + cd.gene_off;
     const double *PE = peprob + g0 * S, *IZ = invz + g0;
     double *BH = bhat + g0 * S;
@@ -415,8 +438,8 @@ backward_kernel(int S, int64_t genes_per_sample, const ChromDesc *__restrict__ c
     double tn[KMAX];
 #pragma unroll
     for (int m = 0; m < KMAX; ++m) {
-        const int k = q + LPS * m;
-        tn[m] = (active && k < S && n >= 2) ? Pt[((int64_t)(n - 2) * S + j) * S + k] : 0.0;
+        const int k = q * KPT + m;          // contiguous chunk per lane: wide loads
+        tn[m] = ((EXACT || (active && m < KPT && k < S)) && n >= 2) ? Pt[((int64_t)(n - 2) * S + jr) * S + k] : 0.0;
     }
     double pe_nx = (owner && n >= 2) ? PE[(int64_t)(n - 2) * S + j] : 0.0;
     double iz_nx = n >= 2 ? IZ[n - 2] : 0.0;
@@ -432,16 +455,16 @@ backward_kernel(int S, int64_t genes_per_sample, const ChromDesc *__restrict__ c
             const double *Tn = Pt + (int64_t)(i - 1) * S * S;
 #pragma unroll
             for (int m = 0; m < KMAX; ++m) {
-                const int k = q + LPS * m;
-                if (active && k < S) tn[m] = Tn[(int64_t)j * S + k];
+                const int k = q * KPT + m;          // contiguous chunk per lane: wide loads
+                if (EXACT || (active && m < KPT && k < S)) tn[m] = Tn[(int64_t)jr * S + k];
             }
         }
         const double *w_next = w_buf + cur * S;
         double s0 = 0.0, s1 = 0.0, s2 = 0.0;
 #pragma unroll
         for (int m = 0; m < KMAX; ++m) {
-            const int k = q + LPS * m;
-            if (active && k < S) {
+            const int k = q * KPT + m;          // contiguous chunk per lane: wide loads
+            if (EXACT || (active && m < KPT && k < S)) {
                 const double wv = w_next[k];
                 if (m % 3 == 0) s0 = fma(wv, tc[m], s0);
                 else if (m % 3 == 1) s1 = fma(wv, tc[m], s1);
@@ -454,7 +477,7 @@ backward_kernel(int S, int64_t genes_per_sample, const ChromDesc *__restrict__ c
             w_buf[nxt * S + j] = bh * pe;
             BH[(int64_t)i * S + j] = bh;
         }
-        __syncthreads();
+        lds_barrier();
         cur = nxt;
     }
 }
@@ -608,7 +631,7 @@ int hmm_alloc_samples(gbrs_hmm *h, int n_samples) {
     return GBRS_OK;
 }
 
-template <int KMAX, int MAXT>
+template <int KMAX, int MAXT, bool EXACT>
 int hmm_launch(gbrs_hmm *h) {
     const int S = h->S;
     const int threads = ((S * 4 + 63) / 64) * 64;
@@ -616,12 +639,12 @@ int hmm_launch(gbrs_hmm *h) {
     GBRS_HIP_CHECK(hipEventRecord(h->ev[1], h->stream));
     hipLaunchKernelGGL(exp_emission_kernel, dim3((unsigned)((rows * S + 255) / 256)), dim3(256), 0, h->stream,
                        rows * S, h->eprob.p, h->peprob.p);
-    hipLaunchKernelGGL((forward_viterbi_kernel<KMAX, MAXT>), dim3(h->n_chrom, h->n_samples, 2), dim3(threads),
+    hipLaunchKernelGGL((forward_viterbi_kernel<KMAX, MAXT, EXACT>), dim3(h->n_chrom, h->n_samples, 2), dim3(threads),
                        2 * S * sizeof(double), h->stream, S, h->total_genes, h->total_bp, h->d_chroms.p,
                        h->tprob.p, h->pprob.p, h->eprob.p, h->peprob.p, h->init_vec.p, h->xsum.p, h->ahat.p,
                        h->invz.p, h->delta.p, h->bp.p, h->last_state.p);
     GBRS_HIP_CHECK(hipEventRecord(h->ev[2], h->stream));
-    hipLaunchKernelGGL((backward_kernel<KMAX, MAXT>), dim3(h->n_chrom, h->n_samples), dim3(threads),
+    hipLaunchKernelGGL((backward_kernel<KMAX, MAXT, EXACT>), dim3(h->n_chrom, h->n_samples), dim3(threads),
                        2 * S * sizeof(double), h->stream, S, h->total_genes, h->d_chroms.p, h->pprob_t.p,
                        h->peprob.p, h->invz.p, h->bhat.p);
     hipLaunchKernelGGL(hmm_outputs_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, h->stream, S, rows,
@@ -766,9 +789,13 @@ int gbrs_hmm_run(gbrs_hmm_t *h) {
     GBRS_TRY(select_device(h->device));
     const int S = h->S;
     int rc;
-    if (S <= 48) rc = hmm_launch<12, 192>(h);          // 4 lanes per state, KMAX = ceil(S / 4)
-    else if (S <= 64) rc = hmm_launch<16, 256>(h);
-    else rc = hmm_launch<34, 576>(h);                   // S <= 136 (MAX_H = 16)
+    // 4 lanes per state, KMAX = ceil(S / 4); the two production shapes (DO: H = 8, CC-style:
+    // H = 16) divide evenly and get predicate-free instantiations
+    if (S == 36) rc = hmm_launch<9, 192, true>(h);
+    else if (S == 136) rc = hmm_launch<34, 576, true>(h);
+    else if (S <= 48) rc = hmm_launch<12, 192, false>(h);
+    else if (S <= 64) rc = hmm_launch<16, 256, false>(h);
+    else rc = hmm_launch<34, 576, false>(h);            // S <= 136 (MAX_H = 16)
     if (rc == GBRS_OK) h->ran = true;
     return rc;
 }
