@@ -30,79 +30,99 @@ __device__ __forceinline__ double seq_norm(const double *v, int H, int stride) {
     return sqrt(s);
 }
 
+// 64 consecutive genes of one sample per workgroup; the genes' specificity matrices, expression
+// vectors and results pass through LDS so that every global access is a coalesced stream (a thread
+// reading its own 512-byte matrix straight from HBM touches 64 different lines per instruction).
 __global__ void __launch_bounds__(64)
 emission_kernel(int H, int S, int64_t n_genes, int n_samples, const double *__restrict__ expr,
                 const double *__restrict__ avecs, const uint8_t *__restrict__ has_avec,
                 const double *__restrict__ init_vec, double expr_threshold, double sigma,
                 double *__restrict__ eprob) {
-    const int64_t id = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (id >= n_genes * n_samples) return;
-    const int64_t g = id % n_genes;
-    const double *e = expr + id * H;
-    double *out = eprob + id * S;
-    double esum = 0.0;
-    for (int x = 0; x < H; ++x) esum += e[x];
-    if (esum < expr_threshold) {
-        for (int s = 0; s < S; ++s) out[s] = init_vec[s];
-        return;
-    }
-    const bool naive = !has_avec[g];
-    const double sg = naive ? 0.450 : sigma;
-    const double denom = -2 * sg * sg;
-    const double *A = avecs + g * H * H;
-    // profile unit vector
-    double u[MAX_H];
-    {
-        const bool norm = esum > 1e-6;
-        const double nrm = norm ? seq_norm(e, H, 1) : 1.0;
-        for (int x = 0; x < H; ++x) u[x] = norm ? e[x] / nrm : e[x];
-    }
-    // per-haplotype specificity row: value accessor, sum and norm
-    double rn[MAX_H];       // norm to divide by, or 0 when the row is left as is
-    for (int i = 0; i < H; ++i) {
-        double s = 0.0, q = 0.0;
-        for (int x = 0; x < H; ++x) {
-            const double a = naive ? (x == i ? 1.0 : 0.0001) : A[i * H + x];
-            s += a;
-            q += a * a;
-        }
-        rn[i] = s > 1e-6 ? sqrt(q) : 0.0;
-    }
-    auto unit_row = [&](int i, int x) -> double {
-        const double a = naive ? (x == i ? 1.0 : 0.0001) : A[i * H + x];
-        return rn[i] != 0.0 ? a / rn[i] : a;
-    };
-    int s_idx = 0;
-    double psum = 0.0;
-    for (int i = 0; i < H; ++i) {
-        for (int j = i; j < H; ++j) {
-            double d = 0.0;
-            if (j == i) {
+    extern __shared__ double lds[];
+    const int HH = H * H, av_stride = HH + 1, ex_stride = H + 1, out_stride = S + 1;
+    double *l_av = lds, *l_ex = l_av + 64 * av_stride, *l_out = l_ex + 64 * ex_stride;
+    const int64_t blocks_per_sample = (n_genes + 63) / 64;
+    const int sample = (int)(blockIdx.x / blocks_per_sample);
+    const int64_t g0 = (blockIdx.x % blocks_per_sample) * 64;
+    const int ng = (int)min((int64_t)64, n_genes - g0);
+    const int tid = threadIdx.x;
+    for (int x = tid; x < ng * HH; x += 64) l_av[(x / HH) * av_stride + x % HH] = avecs[g0 * HH + x];
+    const double *ex_src = expr + ((int64_t)sample * n_genes + g0) * H;
+    for (int x = tid; x < ng * H; x += 64) l_ex[(x / H) * ex_stride + x % H] = ex_src[x];
+    __syncthreads();
+    if (tid < ng) {
+        const int64_t g = g0 + tid;
+        const double *e = l_ex + tid * ex_stride;
+        double *out = l_out + tid * out_stride;
+        double esum = 0.0;
+        for (int x = 0; x < H; ++x) esum += e[x];
+        if (esum < expr_threshold) {
+            for (int s = 0; s < S; ++s) out[s] = init_vec[s];
+        } else {
+            const bool naive = !has_avec[g];
+            const double sg = naive ? 0.450 : sigma;
+            const double denom = -2 * sg * sg;
+            const double *A = l_av + tid * av_stride;
+            // profile unit vector
+            double u[MAX_H];
+            {
+                const bool norm = esum > 1e-6;
+                const double nrm = norm ? seq_norm(e, H, 1) : 1.0;
+                for (int x = 0; x < H; ++x) u[x] = norm ? e[x] / nrm : e[x];
+            }
+            // unit_vector() of every specificity row, once, in place in this thread's LDS block
+            // (the same quotients the reference recomputes for every diplotype)
+            double *U = l_av + tid * av_stride;
+            for (int i = 0; i < H; ++i) {
+                double sm = 0.0, q = 0.0;
                 for (int x = 0; x < H; ++x) {
-                    const double t = u[x] - unit_row(i, x);
-                    d += t * t;
+                    const double a = naive ? (x == i ? 1.0 : 0.0001) : A[i * H + x];
+                    sm += a;
+                    q += a * a;
                 }
-            } else {
-                double gs = 0.0, gq = 0.0;
+                const double rn = sm > 1e-6 ? sqrt(q) : 0.0;
                 for (int x = 0; x < H; ++x) {
-                    const double w = unit_row(i, x) + unit_row(j, x);
-                    gs += w;
-                    gq += w * w;
-                }
-                const bool norm = gs > 1e-6;
-                const double gn = norm ? sqrt(gq) : 1.0;
-                for (int x = 0; x < H; ++x) {
-                    const double w = unit_row(i, x) + unit_row(j, x);
-                    const double t = u[x] - (norm ? w / gn : w);
-                    d += t * t;
+                    const double a = naive ? (x == i ? 1.0 : 0.0001) : A[i * H + x];
+                    U[i * H + x] = rn != 0.0 ? a / rn : a;
                 }
             }
-            const double p = exp(d / denom);
-            out[s_idx++] = p;
-            psum += p;
+            auto unit_row = [&](int i, int x) -> double { return U[i * H + x]; };
+            int s_idx = 0;
+            double psum = 0.0;
+            for (int i = 0; i < H; ++i) {
+                for (int j = i; j < H; ++j) {
+                    double d = 0.0;
+                    if (j == i) {
+                        for (int x = 0; x < H; ++x) {
+                            const double t = u[x] - unit_row(i, x);
+                            d += t * t;
+                        }
+                    } else {
+                        double gs = 0.0, gq = 0.0;
+                        for (int x = 0; x < H; ++x) {
+                            const double w = unit_row(i, x) + unit_row(j, x);
+                            gs += w;
+                            gq += w * w;
+                        }
+                        const bool norm = gs > 1e-6;
+                        const double gn = norm ? sqrt(gq) : 1.0;
+                        for (int x = 0; x < H; ++x) {
+                            const double w = unit_row(i, x) + unit_row(j, x);
+                            const double t = u[x] - (norm ? w / gn : w);
+                            d += t * t;
+                        }
+                    }
+                    const double p = exp(d / denom);
+                    out[s_idx++] = p;
+                    psum += p;
+                }
+            }
+            for (int s = 0; s < S; ++s) out[s] = log(out[s] / psum + TINY);
         }
     }
-    for (int s = 0; s < S; ++s) out[s] = log(out[s] / psum + TINY);
+    __syncthreads();
+    double *dst = eprob + ((int64_t)sample * n_genes + g0) * S;
+    for (int x = tid; x < ng * S; x += 64) dst[x] = l_out[(x / S) * out_stride + x % S];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -269,11 +289,14 @@ forward_viterbi_kernel(int S, int64_t genes_per_sample, int64_t bp_per_sample,
             buf[j] = y_own;
             XS[j] = exp(init_vec[j]);             // so that log(x) + e reproduces init + e
         }
-        double pn[KMAX];
+        // two register sets for the transition block: the step on one set refills the other for
+        // the step after it, so no block is ever copied between registers
+        double pa[KMAX], pb[KMAX];
 #pragma unroll
         for (int m = 0; m < KMAX; ++m) {
             const int k = q * KPT + m;          // contiguous chunk per lane: wide loads
-            pn[m] = ((EXACT || (active && m < KPT && k < S)) && cd.n_trans > 0) ? P[(int64_t)jr * S + k] : 0.0;
+            pa[m] = ((EXACT || (active && m < KPT && k < S)) && cd.n_trans > 0) ? P[(int64_t)jr * S + k] : 0.0;
+            pb[m] = 0.0;
         }
         double pe_next = (owner && n > 1) ? PE[(int64_t)S + j] : 0.0;
         __syncthreads();
@@ -282,17 +305,14 @@ forward_viterbi_kernel(int S, int64_t genes_per_sample, int64_t bp_per_sample,
             AH[j] = y_own * inv_z;
             if (j == 0) IZ[0] = inv_z;
         }
-        for (int i = 1; i < n_steps; ++i) {
+        auto step = [&](int i, const double (&pc)[KMAX], double (&pn)[KMAX]) {
             const double pe = pe_next;
             if (owner && i + 1 < n) pe_next = PE[(int64_t)(i + 1) * S + j];
-            double pc[KMAX];
-#pragma unroll
-            for (int m = 0; m < KMAX; ++m) pc[m] = pn[m];
             if (i < cd.n_trans) {                 // prefetch P[i] for the next step
                 const double *Pn = P + (int64_t)i * S * S;
 #pragma unroll
                 for (int m = 0; m < KMAX; ++m) {
-                    const int k = q * KPT + m;          // contiguous chunk per lane: wide loads
+                    const int k = q * KPT + m;
                     if (EXACT || (active && m < KPT && k < S)) pn[m] = Pn[(int64_t)jr * S + k];
                 }
             }
@@ -300,7 +320,7 @@ forward_viterbi_kernel(int S, int64_t genes_per_sample, int64_t bp_per_sample,
             double s0 = 0.0, s1 = 0.0, s2 = 0.0;
 #pragma unroll
             for (int m = 0; m < KMAX; ++m) {
-                const int k = q * KPT + m;          // contiguous chunk per lane: wide loads
+                const int k = q * KPT + m;
                 if (EXACT || (active && m < KPT && k < S)) {
                     const double yp = y_prev[k];
                     if (m % 3 == 0) s0 = fma(yp, pc[m], s0);
@@ -322,7 +342,13 @@ forward_viterbi_kernel(int S, int64_t genes_per_sample, int64_t bp_per_sample,
                 AH[(int64_t)i * S + j] = y_own * inv_z;
                 if (j == 0) IZ[i] = inv_z;
             }
+        };
+        int i = 1;
+        for (; i + 1 < n_steps; i += 2) {
+            step(i, pa, pb);
+            step(i + 1, pb, pa);
         }
+        if (i < n_steps) step(i, pa, pb);
         return;
     }
 
@@ -338,27 +364,25 @@ forward_viterbi_kernel(int S, int64_t genes_per_sample, int64_t bp_per_sample,
         buf[j] = d_own;
         DL[j] = d_own;
     }
-    double tn[KMAX];
+    double ta[KMAX], tb[KMAX];
 #pragma unroll
     for (int m = 0; m < KMAX; ++m) {
         const int k = q * KPT + m;          // contiguous chunk per lane: wide loads
-        tn[m] = ((EXACT || (active && m < KPT && k < S)) && cd.n_trans > 0) ? T[(int64_t)jr * S + k] : 0.0;
+        ta[m] = ((EXACT || (active && m < KPT && k < S)) && cd.n_trans > 0) ? T[(int64_t)jr * S + k] : 0.0;
+        tb[m] = 0.0;
     }
     double e_next = (owner && n > 1) ? E[(int64_t)S + j] : 0.0;
     __syncthreads();
-    for (int i = 1; i <= n; ++i) {
-        const bool real = i < n_steps;            // produces delta_i
-        if (!real && !(i == n && phantom)) break;
+    // step i: delta_i from delta_{i-1} and T[i-1] (in tc), backpointers of transition i-1; `real`
+    // false = the phantom max-step with T[n-1] that only yields backpointers
+    auto step = [&](int i, bool real, const double (&tc)[KMAX], double (&tn)[KMAX]) {
         const double e = e_next;
         if (owner && i + 1 < n) e_next = E[(int64_t)(i + 1) * S + j];
-        double tc[KMAX];
-#pragma unroll
-        for (int m = 0; m < KMAX; ++m) tc[m] = tn[m];
         if (i < cd.n_trans) {
             const double *Tn = T + (int64_t)i * S * S;
 #pragma unroll
             for (int m = 0; m < KMAX; ++m) {
-                const int k = q * KPT + m;          // contiguous chunk per lane: wide loads
+                const int k = q * KPT + m;
                 if (EXACT || (active && m < KPT && k < S)) tn[m] = Tn[(int64_t)jr * S + k];
             }
         }
@@ -367,7 +391,7 @@ forward_viterbi_kernel(int S, int64_t genes_per_sample, int64_t bp_per_sample,
         int best_k = 0x7fffffff;
 #pragma unroll
         for (int m = 0; m < KMAX; ++m) {
-            const int k = q * KPT + m;          // contiguous chunk per lane: wide loads
+            const int k = q * KPT + m;
             if (EXACT || (active && m < KPT && k < S)) {
                 const double dv = d_prev[k] + tc[m];
                 if (dv > best) { best = dv; best_k = k; }   // ascending k: first max kept
@@ -383,9 +407,24 @@ forward_viterbi_kernel(int S, int64_t genes_per_sample, int64_t bp_per_sample,
                 DL[(int64_t)i * S + j] = d_own;
             }
         }
-        if (!real) break;
-        lds_barrier();
-        cur = nxt;
+        if (real) {
+            lds_barrier();
+            cur = nxt;
+        }
+    };
+    int i = 1;
+    for (; i + 1 < n_steps; i += 2) {
+        step(i, true, ta, tb);
+        step(i + 1, true, tb, ta);
+    }
+    bool on_a = true;                        // which set holds the block for step i
+    if (i < n_steps) {
+        step(i, true, ta, tb);
+        ++i;
+        on_a = false;
+    }
+    if (phantom && i == n) {                 // n_steps == n here: the last real step prefetched T[n-1]
+        if (on_a) step(n, false, ta, tb); else step(n, false, tb, ta);
     }
     // sid = argmax delta[:, n-1] (first max)
     __syncthreads();
@@ -435,19 +474,17 @@ backward_kernel(int S, int64_t genes_per_sample, const ChromDesc *__restrict__ c
         BH[o] = bh;
         w_buf[j] = bh * PE[o];
     }
-    double tn[KMAX];
+    double ta[KMAX], tb[KMAX];
 #pragma unroll
     for (int m = 0; m < KMAX; ++m) {
         const int k = q * KPT + m;          // contiguous chunk per lane: wide loads
-        tn[m] = ((EXACT || (active && m < KPT && k < S)) && n >= 2) ? Pt[((int64_t)(n - 2) * S + jr) * S + k] : 0.0;
+        ta[m] = ((EXACT || (active && m < KPT && k < S)) && n >= 2) ? Pt[((int64_t)(n - 2) * S + jr) * S + k] : 0.0;
+        tb[m] = 0.0;
     }
     double pe_nx = (owner && n >= 2) ? PE[(int64_t)(n - 2) * S + j] : 0.0;
     double iz_nx = n >= 2 ? IZ[n - 2] : 0.0;
     __syncthreads();
-    for (int i = n - 2; i >= 0; --i) {
-        double tc[KMAX];
-#pragma unroll
-        for (int m = 0; m < KMAX; ++m) tc[m] = tn[m];
+    auto step = [&](int i, const double (&tc)[KMAX], double (&tn)[KMAX]) {
         const double pe = pe_nx, iz = iz_nx;
         if (i >= 1) {
             iz_nx = IZ[i - 1];
@@ -455,7 +492,7 @@ backward_kernel(int S, int64_t genes_per_sample, const ChromDesc *__restrict__ c
             const double *Tn = Pt + (int64_t)(i - 1) * S * S;
 #pragma unroll
             for (int m = 0; m < KMAX; ++m) {
-                const int k = q * KPT + m;          // contiguous chunk per lane: wide loads
+                const int k = q * KPT + m;
                 if (EXACT || (active && m < KPT && k < S)) tn[m] = Tn[(int64_t)jr * S + k];
             }
         }
@@ -463,7 +500,7 @@ backward_kernel(int S, int64_t genes_per_sample, const ChromDesc *__restrict__ c
         double s0 = 0.0, s1 = 0.0, s2 = 0.0;
 #pragma unroll
         for (int m = 0; m < KMAX; ++m) {
-            const int k = q * KPT + m;          // contiguous chunk per lane: wide loads
+            const int k = q * KPT + m;
             if (EXACT || (active && m < KPT && k < S)) {
                 const double wv = w_next[k];
                 if (m % 3 == 0) s0 = fma(wv, tc[m], s0);
@@ -479,28 +516,52 @@ backward_kernel(int S, int64_t genes_per_sample, const ChromDesc *__restrict__ c
         }
         lds_barrier();
         cur = nxt;
+    };
+    int i = n - 2;
+    for (; i >= 1; i -= 2) {
+        step(i, ta, tb);
+        step(i - 1, tb, ta);
     }
+    if (i == 0) step(0, ta, tb);
 }
 
 // Log-domain outputs of the reference from the probability-domain sweeps, one thread per
 // (sample, gene):  alpha = log(x) + e - log(Z), scaler = -log(Z), beta = log(bhat),
 // gamma = ahat*bhat / sum_j(ahat*bhat)  (gbrs_utils.py:515-524, :542-549, :558-560).
-__global__ void __launch_bounds__(64)
-hmm_outputs_kernel(int S, int64_t n_rows, const double *__restrict__ eprob, const double *__restrict__ xsum,
+__global__ void __launch_bounds__(1024)
+hmm_outputs_kernel(int S, int OUT_ROWS /* (sample, gene) rows per workgroup */, int64_t n_rows,
+                   const double *__restrict__ eprob, const double *__restrict__ xsum,
                    const double *__restrict__ ahat, const double *__restrict__ invz,
                    const double *__restrict__ bhat, double *__restrict__ alpha, double *__restrict__ scaler,
                    double *__restrict__ beta, double *__restrict__ gamma) {
-    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_rows) return;
-    const double lz = -log(invz[r]);
-    scaler[r] = -lz;
-    const int64_t o = r * S;
-    double norm = 0.0;
-    for (int s = 0; s < S; ++s) norm += ahat[o + s] * bhat[o + s];
-    for (int s = 0; s < S; ++s) {
-        alpha[o + s] = (log(xsum[o + s]) + eprob[o + s]) - lz;
-        beta[o + s] = log(bhat[o + s]);
-        gamma[o + s] = ahat[o + s] * bhat[o + s] / norm;
+    // one thread per (row, state) element: every array is read and written as a contiguous stream
+    extern __shared__ double lds[];               // g[OUT_ROWS * S], norm[OUT_ROWS]
+    double *l_g = lds, *l_norm = lds + OUT_ROWS * S;
+    const int64_t r0 = (int64_t)blockIdx.x * OUT_ROWS;
+    const int nr = (int)min((int64_t)OUT_ROWS, n_rows - r0);
+    const int t = threadIdx.x;
+    const bool live = t < nr * S;
+    const int64_t o = r0 * S + t;
+    double ah = 0.0, bh = 0.0;
+    if (live) {
+        ah = ahat[o];
+        bh = bhat[o];
+        l_g[t] = ah * bh;
+    }
+    __syncthreads();
+    if (t < nr) {
+        double norm = 0.0;
+        for (int s = 0; s < S; ++s) norm += l_g[t * S + s];      // sequential over states, as ndarray.sum(axis=0)
+        l_norm[t] = norm;
+        scaler[r0 + t] = log(invz[r0 + t]);                        // -log(Z)
+    }
+    __syncthreads();
+    if (live) {
+        const int row = t / S;
+        const double lz = -log(invz[r0 + row]);
+        alpha[o] = (log(xsum[o]) + eprob[o]) - lz;
+        beta[o] = log(bh);
+        gamma[o] = ah * bh / l_norm[row];
     }
 }
 
@@ -647,7 +708,10 @@ int hmm_launch(gbrs_hmm *h) {
     hipLaunchKernelGGL((backward_kernel<KMAX, MAXT, EXACT>), dim3(h->n_chrom, h->n_samples), dim3(threads),
                        2 * S * sizeof(double), h->stream, S, h->total_genes, h->d_chroms.p, h->pprob_t.p,
                        h->peprob.p, h->invz.p, h->bhat.p);
-    hipLaunchKernelGGL(hmm_outputs_kernel, dim3((unsigned)((rows + 63) / 64)), dim3(64), 0, h->stream, S, rows,
+    const int out_rows = std::max(1, 1024 / S);
+    hipLaunchKernelGGL(hmm_outputs_kernel, dim3((unsigned)((rows + out_rows - 1) / out_rows)),
+                       dim3(((out_rows * S + 63) / 64) * 64), (size_t)(out_rows * S + out_rows) * sizeof(double),
+                       h->stream, S, out_rows, rows,
                        h->eprob.p, h->xsum.p, h->ahat.p, h->invz.p, h->bhat.p, h->alpha.p, h->scaler.p, h->beta.p,
                        h->gamma.p);
     GBRS_HIP_CHECK(hipEventRecord(h->ev[3], h->stream));
@@ -752,7 +816,10 @@ int gbrs_hmm_set_expression(gbrs_hmm_t *h, int n_samples, const double *const *e
     }
     const int64_t total = h->total_genes * n_samples;
     GBRS_HIP_CHECK(hipEventRecord(h->ev[0], h->stream));
-    hipLaunchKernelGGL(emission_kernel, dim3((unsigned)((total + 63) / 64)), dim3(64), 0, h->stream, H, h->S,
+    const size_t em_lds = (size_t)64 * ((H * H + 1) + (H + 1) + (h->S + 1)) * sizeof(double);
+    const int64_t em_blocks = ((h->total_genes + 63) / 64) * n_samples;
+    (void)total;
+    hipLaunchKernelGGL(emission_kernel, dim3((unsigned)em_blocks), dim3(64), em_lds, h->stream, H, h->S,
                        h->total_genes, n_samples, h->expr.p, h->avecs.p, h->has_avec.p, h->init_vec.p,
                        expr_threshold, sigma, h->eprob.p);
     GBRS_HIP_CHECK(hipEventRecord(h->ev[1], h->stream));
