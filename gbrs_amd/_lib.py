@@ -2,7 +2,7 @@
 
 There is no CPU fallback: importing this module without the built library, or calling into
 it without a visible gfx950 device, raises.  Build with ``python -c "import __graft_entry__ as g;
-g.build()"`` (or ``make -C gbrs_amd/csrc``).
+g.build()"``.
 """
 from __future__ import annotations
 

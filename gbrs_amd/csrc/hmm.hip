@@ -19,7 +19,7 @@ constexpr double TINY = 4.9406564584124654e-324;   // np.nextafter(0, 1)
 constexpr int MAX_H = 16;   // S <= 136 (CC-style 16 founders); DO is H = 8, S = 36
 
 // ------------------------------------------------------------------------------------------
-// Emission: one thread per (sample, gene).  Operation order follows get_genotype_probability:
+// Emission.  Operation order follows get_genotype_probability:
 // builtin (sequential) sums, v / norm divisions, exp(d / (-2 sigma^2)), p / sum(p), log(p + tiny).
 // Compiled with -ffp-contract=off so a*a + s is never fused.
 // ------------------------------------------------------------------------------------------
@@ -30,9 +30,16 @@ __device__ __forceinline__ double seq_norm(const double *v, int H, int stride) {
     return sqrt(s);
 }
 
-// 64 consecutive genes of one sample per workgroup; the genes' specificity matrices, expression
-// vectors and results pass through LDS so that every global access is a coalesced stream (a thread
-// reading its own 512-byte matrix straight from HBM touches 64 different lines per instruction).
+// EM_GENES consecutive genes of one sample per 64-thread workgroup, EM_LANES lanes per gene.  The
+// genes' specificity matrices, expression vectors and results pass through LDS so that every global
+// access is a coalesced stream (a thread reading its own 512-byte matrix straight from HBM touches
+// 64 different lines per instruction).  The lanes of a gene split the unit-row pass by rows and the
+// diplotype pass by states; every per-gene reduction the reference does with builtin sum() is
+// still evaluated sequentially in its order (each lane repeats it), so results do not depend on
+// the split.  A 16-gene block needs 14 KB of LDS at H = 8: ~11 resident waves per CU.
+constexpr int EM_LANES = 4;
+constexpr int EM_GENES = 64 / EM_LANES;
+
 __global__ void __launch_bounds__(64)
 emission_kernel(int H, int S, int64_t n_genes, int n_samples, const double *__restrict__ expr,
                 const double *__restrict__ avecs, const uint8_t *__restrict__ has_avec,
@@ -40,85 +47,94 @@ emission_kernel(int H, int S, int64_t n_genes, int n_samples, const double *__re
                 double *__restrict__ eprob) {
     extern __shared__ double lds[];
     const int HH = H * H, av_stride = HH + 1, ex_stride = H + 1, out_stride = S + 1;
-    double *l_av = lds, *l_ex = l_av + 64 * av_stride, *l_out = l_ex + 64 * ex_stride;
-    const int64_t blocks_per_sample = (n_genes + 63) / 64;
+    double *l_av = lds, *l_ex = l_av + EM_GENES * av_stride, *l_out = l_ex + EM_GENES * ex_stride;
+    const int64_t blocks_per_sample = (n_genes + EM_GENES - 1) / EM_GENES;
     const int sample = (int)(blockIdx.x / blocks_per_sample);
-    const int64_t g0 = (blockIdx.x % blocks_per_sample) * 64;
-    const int ng = (int)min((int64_t)64, n_genes - g0);
+    const int64_t g0 = (blockIdx.x % blocks_per_sample) * EM_GENES;
+    const int ng = (int)min((int64_t)EM_GENES, n_genes - g0);
     const int tid = threadIdx.x;
     for (int x = tid; x < ng * HH; x += 64) l_av[(x / HH) * av_stride + x % HH] = avecs[g0 * HH + x];
     const double *ex_src = expr + ((int64_t)sample * n_genes + g0) * H;
     for (int x = tid; x < ng * H; x += 64) l_ex[(x / H) * ex_stride + x % H] = ex_src[x];
     __syncthreads();
-    if (tid < ng) {
-        const int64_t g = g0 + tid;
-        const double *e = l_ex + tid * ex_stride;
-        double *out = l_out + tid * out_stride;
-        double esum = 0.0;
+
+    const int lg = tid / EM_LANES, q = tid % EM_LANES;
+    const bool in_range = lg < ng;
+    const double *e = l_ex + lg * ex_stride;
+    double *out = l_out + lg * out_stride;
+    double *U = l_av + lg * av_stride;
+    // states of this lane: a contiguous chunk [s_lo, s_hi) of the upper-triangular order
+    const int spl = (S + EM_LANES - 1) / EM_LANES;
+    const int s_lo = min(S, q * spl), s_hi = min(S, s_lo + spl);
+    double esum = 0.0;
+    if (in_range)
         for (int x = 0; x < H; ++x) esum += e[x];
-        if (esum < expr_threshold) {
-            for (int s = 0; s < S; ++s) out[s] = init_vec[s];
-        } else {
-            const bool naive = !has_avec[g];
-            const double sg = naive ? 0.450 : sigma;
-            const double denom = -2 * sg * sg;
-            const double *A = l_av + tid * av_stride;
-            // profile unit vector
-            double u[MAX_H];
-            {
-                const bool norm = esum > 1e-6;
-                const double nrm = norm ? seq_norm(e, H, 1) : 1.0;
-                for (int x = 0; x < H; ++x) u[x] = norm ? e[x] / nrm : e[x];
+    const bool live = in_range && !(esum < expr_threshold);
+    bool naive = false;
+    if (live) {
+        naive = !has_avec[g0 + lg];
+        // unit_vector() of the specificity rows i = q, q + EM_LANES, ... once, in place (the same
+        // quotients the reference recomputes for every diplotype)
+        for (int i = q; i < H; i += EM_LANES) {
+            double sm = 0.0, qq = 0.0;
+            for (int x = 0; x < H; ++x) {
+                const double a = naive ? (x == i ? 1.0 : 0.0001) : U[i * H + x];
+                sm += a;
+                qq += a * a;
             }
-            // unit_vector() of every specificity row, once, in place in this thread's LDS block
-            // (the same quotients the reference recomputes for every diplotype)
-            double *U = l_av + tid * av_stride;
-            for (int i = 0; i < H; ++i) {
-                double sm = 0.0, q = 0.0;
-                for (int x = 0; x < H; ++x) {
-                    const double a = naive ? (x == i ? 1.0 : 0.0001) : A[i * H + x];
-                    sm += a;
-                    q += a * a;
-                }
-                const double rn = sm > 1e-6 ? sqrt(q) : 0.0;
-                for (int x = 0; x < H; ++x) {
-                    const double a = naive ? (x == i ? 1.0 : 0.0001) : A[i * H + x];
-                    U[i * H + x] = rn != 0.0 ? a / rn : a;
-                }
+            const double rn = sm > 1e-6 ? sqrt(qq) : 0.0;
+            for (int x = 0; x < H; ++x) {
+                const double a = naive ? (x == i ? 1.0 : 0.0001) : U[i * H + x];
+                U[i * H + x] = rn != 0.0 ? a / rn : a;
             }
-            auto unit_row = [&](int i, int x) -> double { return U[i * H + x]; };
-            int s_idx = 0;
-            double psum = 0.0;
-            for (int i = 0; i < H; ++i) {
-                for (int j = i; j < H; ++j) {
-                    double d = 0.0;
-                    if (j == i) {
-                        for (int x = 0; x < H; ++x) {
-                            const double t = u[x] - unit_row(i, x);
-                            d += t * t;
-                        }
-                    } else {
-                        double gs = 0.0, gq = 0.0;
-                        for (int x = 0; x < H; ++x) {
-                            const double w = unit_row(i, x) + unit_row(j, x);
-                            gs += w;
-                            gq += w * w;
-                        }
-                        const bool norm = gs > 1e-6;
-                        const double gn = norm ? sqrt(gq) : 1.0;
-                        for (int x = 0; x < H; ++x) {
-                            const double w = unit_row(i, x) + unit_row(j, x);
-                            const double t = u[x] - (norm ? w / gn : w);
-                            d += t * t;
-                        }
-                    }
-                    const double p = exp(d / denom);
-                    out[s_idx++] = p;
-                    psum += p;
-                }
-            }
-            for (int s = 0; s < S; ++s) out[s] = log(out[s] / psum + TINY);
         }
+    }
+    __syncthreads();
+    if (in_range && !live) {
+        for (int s = s_lo; s < s_hi; ++s) out[s] = init_vec[s];
+    } else if (live) {
+        const double sg = naive ? 0.450 : sigma;
+        const double denom = -2 * sg * sg;
+        double u[MAX_H];                       // profile unit vector
+        {
+            const bool norm = esum > 1e-6;
+            const double nrm = norm ? seq_norm(e, H, 1) : 1.0;
+            for (int x = 0; x < H; ++x) u[x] = norm ? e[x] / nrm : e[x];
+        }
+        int i = 0, rem = s_lo;                 // (i, j) of state s_lo
+        while (i < H && rem >= H - i) { rem -= H - i; ++i; }
+        int j = i + rem;
+        for (int s = s_lo; s < s_hi; ++s) {
+            double d = 0.0;
+            if (j == i) {
+                for (int x = 0; x < H; ++x) {
+                    const double t = u[x] - U[i * H + x];
+                    d += t * t;
+                }
+            } else {
+                double gs = 0.0, gq = 0.0;
+                for (int x = 0; x < H; ++x) {
+                    const double w = U[i * H + x] + U[j * H + x];
+                    gs += w;
+                    gq += w * w;
+                }
+                const bool norm = gs > 1e-6;
+                const double gn = norm ? sqrt(gq) : 1.0;
+                for (int x = 0; x < H; ++x) {
+                    const double w = U[i * H + x] + U[j * H + x];
+                    const double t = u[x] - (norm ? w / gn : w);
+                    d += t * t;
+                }
+            }
+            out[s] = exp(d / denom);
+            if (++j == H) { ++i; j = i; }
+        }
+    }
+    __syncthreads();
+    if (live) {
+        double psum = 0.0;
+        for (int s = 0; s < S; ++s) psum += out[s];
+        for (int s = s_lo; s < s_hi; ++s) out[s] = log(out[s] / psum + TINY);
     }
     __syncthreads();
     double *dst = eprob + ((int64_t)sample * n_genes + g0) * S;
@@ -816,8 +832,8 @@ int gbrs_hmm_set_expression(gbrs_hmm_t *h, int n_samples, const double *const *e
     }
     const int64_t total = h->total_genes * n_samples;
     GBRS_HIP_CHECK(hipEventRecord(h->ev[0], h->stream));
-    const size_t em_lds = (size_t)64 * ((H * H + 1) + (H + 1) + (h->S + 1)) * sizeof(double);
-    const int64_t em_blocks = ((h->total_genes + 63) / 64) * n_samples;
+    const size_t em_lds = (size_t)EM_GENES * ((H * H + 1) + (H + 1) + (h->S + 1)) * sizeof(double);
+    const int64_t em_blocks = ((h->total_genes + EM_GENES - 1) / EM_GENES) * n_samples;
     (void)total;
     hipLaunchKernelGGL(emission_kernel, dim3((unsigned)em_blocks), dim3(64), em_lds, h->stream, H, h->S,
                        h->total_genes, n_samples, h->expr.p, h->avecs.p, h->has_avec.p, h->init_vec.p,
