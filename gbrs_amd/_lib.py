@@ -55,6 +55,7 @@ class HmmInfo(C.Structure):
         ("last_emission_ms", C.c_double), ("last_forward_ms", C.c_double),
         ("last_backward_ms", C.c_double), ("last_backtrace_ms", C.c_double),
         ("num_states", C.c_int32), ("n_samples", C.c_int32),
+        ("last_run_ms", C.c_double),
     ]
 
 

@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 
 namespace gbrs {
 
@@ -150,6 +151,7 @@ struct ChromDesc {
     int64_t gene_off;     // offset of the chromosome's first gene in the per-sample gene axis
     int64_t trans_off;    // offset (in S*S blocks) of tprob[c][0] in the transition buffer
     int64_t bp_off;       // offset (in S entries) of the chromosome's backpointer rows
+    int64_t chunk_off;    // offset (in BT_B-row chunks) of the chromosome's backtrace chunk maps
     int32_t n_genes, n_trans;
 };
 
@@ -161,6 +163,16 @@ __device__ __forceinline__ double dpp_f64(double x) {
     hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
     return __hiloint2double(hi, lo);
 }
+#if defined(HMM_ABLATE_SAMEBLOCK)
+#define HMM_BLK(i) 0
+#else
+#define HMM_BLK(i) (i)
+#endif
+#if defined(HMM_PRED_LOADS)
+#define HMM_LOAD_PRED if (act)
+#else
+#define HMM_LOAD_PRED
+#endif
 constexpr int DPP_QUAD_XOR1 = 0xB1;      // quad_perm:[1,0,3,2]
 constexpr int DPP_QUAD_XOR2 = 0x4E;      // quad_perm:[2,3,0,1]
 constexpr int DPP_ROW_HALF_MIRROR = 0x141;
@@ -325,7 +337,7 @@ forward_viterbi_kernel(int S, int64_t genes_per_sample, int64_t bp_per_sample,
             const double pe = pe_next;
             if (owner && i + 1 < n) pe_next = PE[(int64_t)(i + 1) * S + j];
             if (i < cd.n_trans) {                 // prefetch P[i] for the next step
-                const double *Pn = P + (int64_t)i * S * S;
+                const double *Pn = P + (int64_t)HMM_BLK(i) * S * S;
 #pragma unroll
                 for (int m = 0; m < KMAX; ++m) {
                     const int k = q * KPT + m;
@@ -395,7 +407,7 @@ forward_viterbi_kernel(int S, int64_t genes_per_sample, int64_t bp_per_sample,
         const double e = e_next;
         if (owner && i + 1 < n) e_next = E[(int64_t)(i + 1) * S + j];
         if (i < cd.n_trans) {
-            const double *Tn = T + (int64_t)i * S * S;
+            const double *Tn = T + (int64_t)HMM_BLK(i) * S * S;
 #pragma unroll
             for (int m = 0; m < KMAX; ++m) {
                 const int k = q * KPT + m;
@@ -505,7 +517,7 @@ backward_kernel(int S, int64_t genes_per_sample, const ChromDesc *__restrict__ c
         if (i >= 1) {
             iz_nx = IZ[i - 1];
             if (owner) pe_nx = PE[(int64_t)(i - 1) * S + j];
-            const double *Tn = Pt + (int64_t)(i - 1) * S * S;
+            const double *Tn = Pt + (int64_t)HMM_BLK(i - 1) * S * S;
 #pragma unroll
             for (int m = 0; m < KMAX; ++m) {
                 const int k = q * KPT + m;
@@ -541,6 +553,383 @@ backward_kernel(int S, int64_t genes_per_sample, const ChromDesc *__restrict__ c
     if (i == 0) step(0, ta, tb);
 }
 
+// ------------------------------------------------------------------------------------------
+// Single-wave recursions (even S <= 64, i.e. the 8-founder S = 36 case): one lane per state holds
+// its whole transition row in registers, the previous step's vector goes through LDS as broadcast
+// 128-bit reads, and because one wave executes its LDS instructions in order there is no
+// s_barrier, no cross-lane reduction and no predicate in the loop.  A lone wave retires one
+// instruction every ~8 cycles on these dependent chains, so the step time is the instruction
+// count: this form has ~40% of the multi-wave kernels' instructions per step.
+// Lanes j >= S shadow state S-1 and never store.
+// ------------------------------------------------------------------------------------------
+template <int SS>
+__device__ __forceinline__ void load_row(const double *__restrict__ row, double (&dst)[SS]) {
+    const double2 *src = reinterpret_cast<const double2 *>(row);
+#pragma unroll
+    for (int m = 0; m < SS / 2; ++m) {
+        const double2 v = src[m];
+        dst[2 * m] = v.x;
+        dst[2 * m + 1] = v.y;
+    }
+}
+
+// orders this wave's LDS writes before its later LDS reads for the compiler; the hardware keeps
+// one wave's DS instructions in order
+__device__ __forceinline__ void wave_lds_fence() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// Grid (sample, chromosome rank): the samples of a chromosome are neighbours in dispatch order, so
+// they stream the same transition blocks at the same time (one HBM fetch per XCD instead of one
+// per sample), and order[] lists the chromosomes longest first (no long chain starting last).
+//
+// Transition blocks are prefetched NSET-1 steps ahead into a ring of NSET register sets (the loop is
+// unrolled NSET-fold so every set index is a compile-time constant): an HBM miss costs ~0.4 us,
+// a step ~0.25 us, so one step of lead leaves the miss exposed.  Order o <-> the o-th step of the
+// sweep; set o % NSET holds its block, the step refills the set its predecessor just released.
+//
+// Forward: ROLE 0 = alpha recursion, ROLE 1 = delta recursion (values only: the backpointers are
+// argmax_k(delta_t[k] + T[t][j][k]) of stored rows, which viterbi_bp_kernel evaluates for every t
+// in parallel instead of on the sequential path).  The two are separate launches on separate
+// streams (each keeps its own register budget).
+template <int SS, int NSET, int ROLE>
+__global__ void __launch_bounds__(64)
+forward_wave_kernel(int64_t genes_per_sample, const ChromDesc *__restrict__ chroms,
+                    const int32_t *__restrict__ order, const double *__restrict__ tprob, const double *__restrict__ pprob,
+                    const double *__restrict__ eprob, const double *__restrict__ peprob,
+                    const double *__restrict__ init_vec, double *__restrict__ xsum,
+                    double *__restrict__ ahat, double *__restrict__ invz, double *__restrict__ delta,
+                    int32_t *__restrict__ last_state) {
+    static_assert(SS % 2 == 0 && SS <= 64, "one lane per state, 16-byte aligned rows");
+    __shared__ __attribute__((aligned(16))) double buf[2][SS];
+    const int chrom = order[blockIdx.y];
+    const ChromDesc cd = chroms[chrom];
+    const int sample = blockIdx.x;
+    constexpr int role = ROLE;
+    const int n = cd.n_genes;
+    if (n <= 0) return;
+    const int j = threadIdx.x;
+    const bool act = j < SS;
+    const int jr = act ? j : SS - 1;
+    const int64_t g0 = (int64_t)sample * genes_per_sample + cd.gene_off;
+    const int n_ord = min(n, cd.n_trans + 1) - 1;   // step i = o + 1 needs T[o]
+    int cur = 0;
+    // role 0 streams P = exp(T) and pe = exp(e); role 1 streams T and e
+    const double *BLK = (role == 0 ? pprob : tprob) + cd.trans_off * (int64_t)SS * SS;
+    const double *EM = (role == 0 ? peprob : eprob) + g0 * SS;
+    // Loads are unconditional with clamped block indices (a conditional refill would make the
+    // compiler merge whole register sets at every join): past the end they re-read the last block.
+    const int last_o = max(n_ord - 1, 0);
+    const bool any = cd.n_trans > 0 && n > 1;
+    double pr[NSET][SS], em_r[NSET];
+#pragma unroll
+    for (int u = 0; u < NSET; ++u) {
+        const int ou = min(u, last_o);
+        if (any) load_row<SS>(BLK + ((int64_t)HMM_BLK(ou) * SS + jr) * SS, pr[u]);
+        else {
+#pragma unroll
+            for (int m = 0; m < SS; ++m) pr[u][m] = 0.0;
+        }
+        em_r[u] = any ? EM[(int64_t)(ou + 1) * SS + jr] : 0.0;
+    }
+    auto prefetch = [&](int o, double (&pn)[SS], double &em_n) {
+        const int of = min(o + NSET - 1, last_o);
+        HMM_LOAD_PRED load_row<SS>(BLK + ((int64_t)HMM_BLK(of) * SS + jr) * SS, pn);
+        em_n = EM[(int64_t)(of + 1) * SS + jr];
+    };
+
+    if constexpr (role == 0) {
+        const double *E = eprob + g0 * SS;
+        double *XS = xsum + g0 * SS, *AH = ahat + g0 * SS, *IZ = invz + g0;
+        double y_own = exp(init_vec[jr] + E[jr]);
+        if (act) {
+            buf[0][j] = y_own;
+            XS[j] = exp(init_vec[j]);             // so that log(x) + e reproduces init + e
+        }
+        wave_lds_fence();
+        // Z of the vector in buf[cur] comes out of the same broadcast reads as the products: every
+        // lane adds it up itself, no cross-lane operation
+        auto finish = [&](int i_prev, double z) {
+            const double inv_z = fast_recip_pos(z);
+            if (act) {
+                AH[(int64_t)i_prev * SS + j] = y_own * inv_z;
+                if (j == 0) IZ[i_prev] = inv_z;
+            }
+            return inv_z;
+        };
+        auto step = [&](int o, const double (&pc)[SS], double pe, double (&pn)[SS], double &pe_n) {
+            const int i = o + 1;
+            prefetch(o, pn, pe_n);
+            const double2 *yv = reinterpret_cast<const double2 *>(buf[cur]);
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, z0 = 0.0, z1 = 0.0, z2 = 0.0, z3 = 0.0;
+#pragma unroll
+            for (int m = 0; m < SS / 2; ++m) {
+                const double2 v = yv[m];
+                if (m & 1) {
+                    s2 = fma(v.x, pc[2 * m], s2);
+                    s3 = fma(v.y, pc[2 * m + 1], s3);
+                    z2 += v.x;
+                    z3 += v.y;
+                } else {
+                    s0 = fma(v.x, pc[2 * m], s0);
+                    s1 = fma(v.y, pc[2 * m + 1], s1);
+                    z0 += v.x;
+                    z1 += v.y;
+                }
+            }
+            const double inv_z = finish(i - 1, (z0 + z1) + (z2 + z3));
+            const double x = ((s0 + s1) + (s2 + s3)) * inv_z + TINY;
+            y_own = x * pe;
+            cur ^= 1;
+            if (act) {
+                buf[cur][j] = y_own;
+                XS[(int64_t)i * SS + j] = x;
+            }
+            wave_lds_fence();
+        };
+        int o = 0;
+        for (; o + NSET <= n_ord; o += NSET) {
+#pragma unroll
+            for (int u = 0; u < NSET; ++u)
+                step(o + u, pr[u], em_r[u], pr[(u + NSET - 1) % NSET], em_r[(u + NSET - 1) % NSET]);
+        }
+#pragma unroll
+        for (int u = 0; u < NSET - 1; ++u)
+            if (o + u < n_ord) step(o + u, pr[u], em_r[u], pr[(u + NSET - 1) % NSET], em_r[(u + NSET - 1) % NSET]);
+        {
+            const double2 *yv = reinterpret_cast<const double2 *>(buf[cur]);
+            double z0 = 0.0, z1 = 0.0, z2 = 0.0, z3 = 0.0;
+#pragma unroll
+            for (int m = 0; m < SS / 2; ++m) {
+                const double2 v = yv[m];
+                if (m & 1) { z2 += v.x; z3 += v.y; } else { z0 += v.x; z1 += v.y; }
+            }
+            finish(n_ord, (z0 + z1) + (z2 + z3));
+        }
+        return;
+    }
+
+    // role 1: Viterbi values in the log domain (adds and max only: exact)
+    double *DL = delta + g0 * SS;
+    double d_own = init_vec[jr] + EM[jr];
+    if (act) {
+        buf[0][j] = d_own;
+        DL[j] = d_own;
+    }
+    wave_lds_fence();
+    auto step = [&](int o, const double (&tc)[SS], double e, double (&tn)[SS], double &e_n) {
+        const int i = o + 1;
+        prefetch(o, tn, e_n);
+        const double2 *dp = reinterpret_cast<const double2 *>(buf[cur]);
+        double m0, m1, m2, m3;
+        {
+            const double2 v0 = dp[0], v1 = dp[1];
+            m0 = v0.x + tc[0];
+            m1 = v0.y + tc[1];
+            m2 = v1.x + tc[2];
+            m3 = v1.y + tc[3];
+        }
+#pragma unroll
+        for (int m = 2; m < SS / 2; ++m) {
+            const double2 v = dp[m];
+            if (m & 1) {
+                m2 = fmax(m2, v.x + tc[2 * m]);
+                m3 = fmax(m3, v.y + tc[2 * m + 1]);
+            } else {
+                m0 = fmax(m0, v.x + tc[2 * m]);
+                m1 = fmax(m1, v.y + tc[2 * m + 1]);
+            }
+        }
+        d_own = fmax(fmax(m0, m1), fmax(m2, m3)) + e;
+        cur ^= 1;
+        if (act) {
+            buf[cur][j] = d_own;
+            DL[(int64_t)i * SS + j] = d_own;
+        }
+        wave_lds_fence();
+    };
+    int o = 0;
+    for (; o + NSET <= n_ord; o += NSET) {
+#pragma unroll
+        for (int u = 0; u < NSET; ++u)
+            step(o + u, pr[u], em_r[u], pr[(u + NSET - 1) % NSET], em_r[(u + NSET - 1) % NSET]);
+    }
+#pragma unroll
+    for (int u = 0; u < NSET - 1; ++u)
+        if (o + u < n_ord) step(o + u, pr[u], em_r[u], pr[(u + NSET - 1) % NSET], em_r[(u + NSET - 1) % NSET]);
+    if (j == 0) {                            // sid = argmax delta[:, n-1] (first max)
+        const double *dl = buf[cur];
+        double b = dl[0];
+        int bk = 0;
+        for (int s = 1; s < SS; ++s)
+            if (dl[s] > b) { b = dl[s]; bk = s; }
+        last_state[(int64_t)sample * gridDim.y + chrom] = bk;
+    }
+}
+
+// Backpointers bp[t][j] = argmax_k(delta_t[k] + T[t][j][k]) (first max, np.argmax) for
+// t < min(n, n_trans): the quantity the reference's backtrace recomputes along the path
+// (gbrs_utils.py:594), including the row of T[n-1] when len(tprob) >= n.  One workgroup per
+// (t, chromosome): the block is staged once in LDS and applied to every sample's delta row.
+__global__ void __launch_bounds__(256)
+viterbi_bp_kernel(int S, int n_samples, int64_t genes_per_sample, int64_t bp_per_sample,
+                  const ChromDesc *__restrict__ chroms, const double *__restrict__ tprob,
+                  const double *__restrict__ delta, uint16_t *__restrict__ bp) {
+    extern __shared__ double lds[];            // T block, rows padded to S + 1
+    const ChromDesc cd = chroms[blockIdx.y];
+    const int t = blockIdx.x;
+    if (t >= min(cd.n_genes, cd.n_trans)) return;
+    const double *T = tprob + (cd.trans_off + t) * (int64_t)S * S;
+    const int stride = S + 1;
+    for (int x = threadIdx.x; x < S * S; x += blockDim.x) lds[(x / S) * stride + x % S] = T[x];
+    __syncthreads();
+    const int per_pass = blockDim.x / S;       // samples per pass
+    const int sl = threadIdx.x / S, j = threadIdx.x % S;
+    if (sl >= per_pass) return;
+    const double *row = lds + j * stride;
+    for (int s0 = 0; s0 < n_samples; s0 += per_pass) {
+        const int sample = s0 + sl;
+        if (sample >= n_samples) break;
+        const double *d = delta + ((int64_t)sample * genes_per_sample + cd.gene_off + t) * S;
+        double best = d[0] + row[0];
+        int best_k = 0;
+        for (int k = 1; k < S; ++k) {
+            const double dv = d[k] + row[k];
+            if (dv > best) { best = dv; best_k = k; }
+        }
+        bp[((int64_t)sample * bp_per_sample + cd.bp_off + t) * S + j] = (uint16_t)best_k;
+    }
+}
+
+// Backward sweep that does not wait for the forward sweep: instead of the forward normalisers it
+// carries its own scale,
+//     bt_{n-1} = 1        bt_i[j] = r_i * sum_k Pt_i[j][k] * pe_{i+1}[k] * bt_{i+1}[k]
+// with r_i = 1 / sum_k(pe_{i+1}[k] * bt_{i+1}[k]) on every NSET-th step and 1 otherwise (the sums
+// come out of the broadcast reads the products use).  The reference's beta differs from log(bt) by
+// a per-gene constant, log C_i = sum_{t>=i} log(1/Z_t) - sum_{i<=t<=n-2} log(r_t), which
+// beta_corr_kernel adds afterwards; the posterior is scale free.
+template <int SS, int NSET>
+__global__ void __launch_bounds__(64)
+backward_wave_kernel(int64_t genes_per_sample, const ChromDesc *__restrict__ chroms,
+                     const int32_t *__restrict__ order, const double *__restrict__ pprob_t, const double *__restrict__ peprob,
+                     double *__restrict__ bhat, double *__restrict__ bscale) {
+    static_assert(SS % 2 == 0 && SS <= 64, "one lane per state, 16-byte aligned rows");
+    __shared__ __attribute__((aligned(16))) double buf[2][SS];
+    const ChromDesc cd = chroms[order[blockIdx.y]];
+    const int sample = blockIdx.x;
+    const int n = cd.n_genes;
+    if (n <= 0) return;
+    const int j = threadIdx.x;
+    const bool act = j < SS;
+    const int jr = act ? j : SS - 1;
+    const int64_t g0 = (int64_t)sample * genes_per_sample + cd.gene_off;
+    const double *PE = peprob + g0 * SS;
+    double *BH = bhat + g0 * SS, *BS = bscale + g0;
+    const double *Pt = pprob_t + cd.trans_off * (int64_t)SS * SS;
+    int cur = 0;
+    {
+        const int64_t o = (int64_t)(n - 1) * SS + jr;
+        if (act) {
+            BH[o] = 1.0;
+            buf[0][j] = PE[o];
+            if (j == 0) BS[n - 1] = 1.0;
+        }
+    }
+    // order o <-> gene i = n-2-o, transition block i (the host checked n_trans >= n-1)
+    const int n_ord = n - 1;
+    const int last_o = max(n_ord - 1, 0);
+    double tr[NSET][SS], pe_r[NSET];
+#pragma unroll
+    for (int u = 0; u < NSET; ++u) {
+        const int i = n - 2 - min(u, last_o);
+        if (n_ord > 0) load_row<SS>(Pt + ((int64_t)HMM_BLK(i) * SS + jr) * SS, tr[u]);
+        else {
+#pragma unroll
+            for (int m = 0; m < SS; ++m) tr[u][m] = 0.0;
+        }
+        pe_r[u] = n_ord > 0 ? PE[(int64_t)i * SS + jr] : 0.0;
+    }
+    wave_lds_fence();
+    auto step = [&](int o, bool rescale, const double (&tc)[SS], double pe, double (&tn)[SS], double &pe_n) {
+        const int i = n - 2 - o;
+        {
+            const int in = n - 2 - min(o + NSET - 1, last_o);     // clamped: see forward_wave_kernel
+            load_row<SS>(Pt + ((int64_t)HMM_BLK(in) * SS + jr) * SS, tn);
+            pe_n = PE[(int64_t)in * SS + jr];
+        }
+        const double2 *wv = reinterpret_cast<const double2 *>(buf[cur]);
+        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, z0 = 0.0, z1 = 0.0;
+#pragma unroll
+        for (int m = 0; m < SS / 2; ++m) {
+            const double2 v = wv[m];
+            if (m & 1) {
+                s2 = fma(v.x, tc[2 * m], s2);
+                s3 = fma(v.y, tc[2 * m + 1], s3);
+                if (rescale) z1 += v.x + v.y;
+            } else {
+                s0 = fma(v.x, tc[2 * m], s0);
+                s1 = fma(v.y, tc[2 * m + 1], s1);
+                if (rescale) z0 += v.x + v.y;
+            }
+        }
+        const double r = rescale ? fast_recip_pos(z0 + z1) : 1.0;
+        const double bh = ((s0 + s1) + (s2 + s3)) * r;
+        cur ^= 1;
+        if (act) {
+            buf[cur][j] = bh * pe;
+            BH[(int64_t)i * SS + j] = bh;
+            if (j == 0) BS[i] = r;
+        }
+        wave_lds_fence();
+    };
+    int o = 0;
+    for (; o + NSET <= n_ord; o += NSET) {
+#pragma unroll
+        for (int u = 0; u < NSET; ++u)
+            step(o + u, u == 0, tr[u], pe_r[u], tr[(u + NSET - 1) % NSET], pe_r[(u + NSET - 1) % NSET]);
+    }
+#pragma unroll
+    for (int u = 0; u < NSET - 1; ++u)
+        if (o + u < n_ord)
+            step(o + u, u == 0, tr[u], pe_r[u], tr[(u + NSET - 1) % NSET], pe_r[(u + NSET - 1) % NSET]);
+}
+
+// log C_i of backward_wave_kernel's comment for one (chromosome, sample): a suffix sum over genes
+__global__ void __launch_bounds__(256)
+beta_corr_kernel(int64_t genes_per_sample, const ChromDesc *__restrict__ chroms,
+                 const double *__restrict__ invz, const double *__restrict__ bscale,
+                 double *__restrict__ bcorr) {
+    __shared__ double part[256];
+    const ChromDesc cd = chroms[blockIdx.y];
+    const int n = cd.n_genes;
+    if (n <= 0) return;
+    const int64_t g0 = (int64_t)blockIdx.x * genes_per_sample + cd.gene_off;
+    const int t = threadIdx.x;
+    const int seg = (n + 255) / 256;
+    const int lo = min(n, t * seg), hi = min(n, lo + seg);
+    auto term = [&](int i) { return log(invz[g0 + i]) - (i <= n - 2 ? log(bscale[g0 + i]) : 0.0); };
+    double sum = 0.0;
+    for (int i = hi - 1; i >= lo; --i) sum += term(i);
+    part[t] = sum;
+    __syncthreads();
+    if (t == 0) {                               // exclusive suffix sums of the 256 segment totals
+        double run = 0.0;
+        for (int x = 255; x >= 0; --x) {
+            const double v = part[x];
+            part[x] = run;
+            run += v;
+        }
+    }
+    __syncthreads();
+    double run = part[t];
+    for (int i = hi - 1; i >= lo; --i) {
+        run += term(i);
+        bcorr[g0 + i] = run;
+    }
+}
+
 // Log-domain outputs of the reference from the probability-domain sweeps, one thread per
 // (sample, gene):  alpha = log(x) + e - log(Z), scaler = -log(Z), beta = log(bhat),
 // gamma = ahat*bhat / sum_j(ahat*bhat)  (gbrs_utils.py:515-524, :542-549, :558-560).
@@ -548,8 +937,9 @@ __global__ void __launch_bounds__(1024)
 hmm_outputs_kernel(int S, int OUT_ROWS /* (sample, gene) rows per workgroup */, int64_t n_rows,
                    const double *__restrict__ eprob, const double *__restrict__ xsum,
                    const double *__restrict__ ahat, const double *__restrict__ invz,
-                   const double *__restrict__ bhat, double *__restrict__ alpha, double *__restrict__ scaler,
-                   double *__restrict__ beta, double *__restrict__ gamma) {
+                   const double *__restrict__ bhat, const double *__restrict__ bcorr /* nullable */,
+                   double *__restrict__ alpha, double *__restrict__ scaler, double *__restrict__ beta,
+                   double *__restrict__ gamma) {
     // one thread per (row, state) element: every array is read and written as a contiguous stream
     extern __shared__ double lds[];               // g[OUT_ROWS * S], norm[OUT_ROWS]
     double *l_g = lds, *l_norm = lds + OUT_ROWS * S;
@@ -576,50 +966,85 @@ hmm_outputs_kernel(int S, int OUT_ROWS /* (sample, gene) rows per workgroup */, 
         const int row = t / S;
         const double lz = -log(invz[r0 + row]);
         alpha[o] = (log(xsum[o]) + eprob[o]) - lz;
-        beta[o] = log(bh);
+        beta[o] = bcorr ? log(bh) + bcorr[r0 + row] : log(bh);
         gamma[o] = ah * bh / l_norm[row];
     }
 }
 
-// Backtrace (gbrs_utils.py:587-597): chase the backpointers from the last state.  One workgroup
-// per (sample, chromosome); the backpointer rows are staged through LDS in chunks so the
-// dependent chain runs at LDS latency.
-__global__ void __launch_bounds__(256)
-backtrace_kernel(int S, int BT_CHUNK, int64_t genes_per_sample, int64_t bp_per_sample, int64_t states_per_sample,
-                 int n_chrom, const ChromDesc *__restrict__ chroms, const uint16_t *__restrict__ bp,
-                 const int32_t *__restrict__ last_state, int32_t *__restrict__ states,
-                 int32_t *__restrict__ calls) {
-    extern __shared__ uint16_t stage[];        // BT_CHUNK * S
-    __shared__ int s_sid;
-    const ChromDesc cd = chroms[blockIdx.x];
-    const int sample = blockIdx.y;
-    const int n = cd.n_genes;
-    if (n <= 0) return;
-    const int m = min(n, cd.n_trans);
-    const uint16_t *BP = bp + ((int64_t)sample * bp_per_sample + cd.bp_off) * S;
-    int32_t *ST = states + (int64_t)sample * states_per_sample + cd.gene_off + blockIdx.x;
-    int32_t *CL = calls + (int64_t)sample * genes_per_sample + cd.gene_off;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) CL[i] = -1;
-    if (threadIdx.x == 0) {
-        s_sid = last_state[(int64_t)sample * n_chrom + blockIdx.x];
-        ST[m] = s_sid;
-    }
+// Backtrace (gbrs_utils.py:587-597): states[m] = argmax delta[:, n-1], states[t] = bp[t][states[t+1]]
+// for t = m-1 .. 0 (m = min(n, n_trans)).  A chain of 3,000 dependent lookups, cut into chunks of
+// BT_B rows that are walked in parallel: backtrace_maps_kernel walks every chunk from each of the S
+// possible entry states (lane = entry state) and records where it leaves the chunk;
+// backtrace_write_kernel composes the exit maps of the chunks above its own (a few dozen lookups
+// in LDS) to find its true entry state, walks its chunk once more and writes the path.
+constexpr int BT_B = 64;
+
+__global__ void __launch_bounds__(64)
+backtrace_maps_kernel(int S, int64_t bp_per_sample, int64_t chunks_per_sample,
+                      const ChromDesc *__restrict__ chroms, const uint16_t *__restrict__ bp,
+                      uint16_t *__restrict__ exit_map) {
+    extern __shared__ uint16_t stage[];        // BT_B * S
+    const ChromDesc cd = chroms[blockIdx.y];
+    const int sample = blockIdx.z;
+    const int m = min(cd.n_genes, cd.n_trans);
+    const int lo = blockIdx.x * BT_B;
+    if (lo >= m) return;
+    const int hi = min(m, lo + BT_B);
+    const uint16_t *BP = bp + ((int64_t)sample * bp_per_sample + cd.bp_off + lo) * S;
+    for (int x = threadIdx.x; x < (hi - lo) * S; x += 64) stage[x] = BP[x];
     __syncthreads();
-    for (int hi = m; hi > 0; hi -= BT_CHUNK) {
-        const int lo = max(0, hi - BT_CHUNK);
-        const int cnt = (hi - lo) * S;
-        for (int x = threadIdx.x; x < cnt; x += blockDim.x) stage[x] = BP[(int64_t)lo * S + x];
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            int sid = s_sid;
-            for (int i = hi - 1; i >= lo; --i) {
-                sid = stage[(i - lo) * S + sid];
-                ST[i] = sid;
-                CL[i] = sid;
-            }
-            s_sid = sid;
+    for (int s = threadIdx.x; s < S; s += 64) {
+        int sid = s;
+        for (int t = hi - lo - 1; t >= 0; --t) sid = stage[t * S + sid];
+        exit_map[((int64_t)sample * chunks_per_sample + cd.chunk_off + blockIdx.x) * S + s] = (uint16_t)sid;
+    }
+}
+
+__global__ void __launch_bounds__(64)
+backtrace_write_kernel(int S, int64_t genes_per_sample, int64_t bp_per_sample, int64_t states_per_sample,
+                       int64_t chunks_per_sample, int n_chrom, const ChromDesc *__restrict__ chroms,
+                       const uint16_t *__restrict__ bp, const uint16_t *__restrict__ exit_map,
+                       const int32_t *__restrict__ last_state, int32_t *__restrict__ states,
+                       int32_t *__restrict__ calls) {
+    extern __shared__ uint16_t stage[];        // max(BT_B, chunks above) * S maps, then BT_B path entries
+    const ChromDesc cd = chroms[blockIdx.y];
+    const int sample = blockIdx.z;
+    const int n = cd.n_genes;
+    const int m = min(n, cd.n_trans);
+    const int n_chunks = (m + BT_B - 1) / BT_B;
+    const int c = blockIdx.x;
+    if (c >= max(n_chunks, 1)) return;
+    int32_t *ST = states + (int64_t)sample * states_per_sample + cd.gene_off + blockIdx.y;
+    int32_t *CL = calls + (int64_t)sample * genes_per_sample + cd.gene_off;
+    const int last = last_state[(int64_t)sample * n_chrom + blockIdx.y];
+    if (c == 0) {
+        for (int i = m + threadIdx.x; i < n; i += 64) CL[i] = -1;
+        if (threadIdx.x == 0) ST[m] = last;
+    }
+    if (m <= 0) return;
+    const int lo = c * BT_B, hi = min(m, lo + BT_B);
+    // entry state of this chunk: the last state pushed through the chunks above, top down
+    const int above = n_chunks - 1 - c;
+    const uint16_t *EX = exit_map + ((int64_t)sample * chunks_per_sample + cd.chunk_off + c + 1) * S;
+    for (int x = threadIdx.x; x < above * S; x += 64) stage[x] = EX[x];
+    __syncthreads();
+    int sid = last;
+    for (int cc = above - 1; cc >= 0; --cc) sid = stage[cc * S + sid];    // uniform: every thread walks
+    __syncthreads();
+    const uint16_t *BP = bp + ((int64_t)sample * bp_per_sample + cd.bp_off + lo) * S;
+    uint16_t *rows = stage, *path = stage + BT_B * S;
+    for (int x = threadIdx.x; x < (hi - lo) * S; x += 64) rows[x] = BP[x];
+    __syncthreads();
+    if (threadIdx.x == 0)
+        for (int t = hi - lo - 1; t >= 0; --t) {
+            sid = rows[t * S + sid];
+            path[t] = (uint16_t)sid;
         }
-        __syncthreads();
+    __syncthreads();
+    for (int t = threadIdx.x; t < hi - lo; t += 64) {
+        const int v = path[t];
+        ST[lo + t] = v;
+        CL[lo + t] = v;
     }
 }
 
@@ -669,19 +1094,24 @@ using namespace gbrs;
 
 struct gbrs_hmm {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr, stream_b = nullptr, stream_c = nullptr;   // see hmm_launch
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_b = nullptr, ev_c1 = nullptr, ev_c = nullptr;
     int H = 0, S = 0, n_chrom = 0, n_samples = 0;
     std::vector<ChromDesc> chroms;
-    int64_t total_genes = 0, total_trans = 0, total_bp = 0;
+    int64_t total_genes = 0, total_trans = 0, total_bp = 0, total_chunks = 0;
+    int num_cus = 0;
+    int max_bp_rows = 0;                      // max over chromosomes of min(n_genes, n_trans)
     bool have_eprob = false, ran = false;
     DevBuf<ChromDesc> d_chroms;
+    DevBuf<int32_t> d_order;                  // chromosome indices, longest first
     DevBuf<double> tprob, pprob, pprob_t, init_vec;   // log T, exp(T), exp(T) transposed per block
     DevBuf<double> expr, avecs, eprob, peprob, xsum, bhat, alpha, ahat, beta, gamma, delta, scaler, invz;
+    DevBuf<double> bscale, bcorr;             // free-running backward: per-gene scale and log correction
     DevBuf<uint8_t> has_avec;
-    DevBuf<uint16_t> bp;
+    DevBuf<uint16_t> bp, bt_exit;             // backpointers; per-chunk exit maps of the backtrace
     DevBuf<int32_t> last_state, states, calls;
-    double t_emis = 0, t_fwd = 0, t_bwd = 0, t_bt = 0;
+    double t_emis = 0, t_fwd = 0, t_bwd = 0, t_bt = 0, t_run = 0;
 };
 
 namespace {
@@ -696,11 +1126,14 @@ int hmm_alloc_samples(gbrs_hmm *h, int n_samples) {
     GBRS_TRY(h->xsum.alloc(gs * h->S));
     GBRS_TRY(h->bhat.alloc(gs * h->S));
     GBRS_TRY(h->invz.alloc(gs));
+    GBRS_TRY(h->bscale.alloc(gs));
+    GBRS_TRY(h->bcorr.alloc(gs));
     GBRS_TRY(h->beta.alloc(gs * h->S));
     GBRS_TRY(h->gamma.alloc(gs * h->S));
     GBRS_TRY(h->delta.alloc(gs * h->S));
     GBRS_TRY(h->scaler.alloc(gs));
     GBRS_TRY(h->bp.alloc(std::max<size_t>((size_t)h->total_bp * n_samples * h->S, 1)));
+    GBRS_TRY(h->bt_exit.alloc(std::max<size_t>((size_t)h->total_chunks * n_samples * h->S, 1)));
     GBRS_TRY(h->last_state.alloc((size_t)h->n_chrom * n_samples));
     GBRS_TRY(h->states.alloc(((size_t)h->total_genes + h->n_chrom) * n_samples));
     GBRS_TRY(h->calls.alloc(gs));
@@ -708,41 +1141,127 @@ int hmm_alloc_samples(gbrs_hmm *h, int n_samples) {
     return GBRS_OK;
 }
 
+#ifndef HMM_NSET
+#define HMM_NSET 3
+#endif
+
 template <int KMAX, int MAXT, bool EXACT>
 int hmm_launch(gbrs_hmm *h) {
     const int S = h->S;
     const int threads = ((S * 4 + 63) / 64) * 64;
     const int64_t rows = h->total_genes * h->n_samples;
-    GBRS_HIP_CHECK(hipEventRecord(h->ev[1], h->stream));
-    hipLaunchKernelGGL(exp_emission_kernel, dim3((unsigned)((rows * S + 255) / 256)), dim3(256), 0, h->stream,
-                       rows * S, h->eprob.p, h->peprob.p);
-    hipLaunchKernelGGL((forward_viterbi_kernel<KMAX, MAXT, EXACT>), dim3(h->n_chrom, h->n_samples, 2), dim3(threads),
-                       2 * S * sizeof(double), h->stream, S, h->total_genes, h->total_bp, h->d_chroms.p,
-                       h->tprob.p, h->pprob.p, h->eprob.p, h->peprob.p, h->init_vec.p, h->xsum.p, h->ahat.p,
-                       h->invz.p, h->delta.p, h->bp.p, h->last_state.p);
-    GBRS_HIP_CHECK(hipEventRecord(h->ev[2], h->stream));
-    hipLaunchKernelGGL((backward_kernel<KMAX, MAXT, EXACT>), dim3(h->n_chrom, h->n_samples), dim3(threads),
-                       2 * S * sizeof(double), h->stream, S, h->total_genes, h->d_chroms.p, h->pprob_t.p,
-                       h->peprob.p, h->invz.p, h->bhat.p);
     const int out_rows = std::max(1, 1024 / S);
-    hipLaunchKernelGGL(hmm_outputs_kernel, dim3((unsigned)((rows + out_rows - 1) / out_rows)),
-                       dim3(((out_rows * S + 63) / 64) * 64), (size_t)(out_rows * S + out_rows) * sizeof(double),
-                       h->stream, S, out_rows, rows,
-                       h->eprob.p, h->xsum.p, h->ahat.p, h->invz.p, h->bhat.p, h->alpha.p, h->scaler.p, h->beta.p,
-                       h->gamma.p);
-    GBRS_HIP_CHECK(hipEventRecord(h->ev[3], h->stream));
-    const int bt_chunk = std::max(1, std::min(512, 32768 / S));   // <= 64 KiB of staged backpointers
-    hipLaunchKernelGGL(backtrace_kernel, dim3(h->n_chrom, h->n_samples), dim3(256), (size_t)bt_chunk * S * sizeof(uint16_t), h->stream,
-                       S, bt_chunk, h->total_genes, h->total_bp, h->total_genes + h->n_chrom, h->n_chrom,
-                       h->d_chroms.p, h->bp.p, h->last_state.p, h->states.p, h->calls.p);
-    GBRS_HIP_CHECK(hipEventRecord(h->ev[4], h->stream));
-    GBRS_HIP_CHECK(hipGetLastError());
-    GBRS_HIP_CHECK(hipStreamSynchronize(h->stream));
-    float ms = 0.f;
-    if (hipEventElapsedTime(&ms, h->ev[1], h->ev[2]) == hipSuccess) h->t_fwd = ms;
-    if (hipEventElapsedTime(&ms, h->ev[2], h->ev[3]) == hipSuccess) h->t_bwd = ms;
-    if (hipEventElapsedTime(&ms, h->ev[3], h->ev[4]) == hipSuccess) h->t_bt = ms;
-    return GBRS_OK;
+    const dim3 out_grid((unsigned)((rows + out_rows - 1) / out_rows)), out_block(((out_rows * S + 63) / 64) * 64);
+    const size_t out_lds = (size_t)(out_rows * S + out_rows) * sizeof(double);
+    const int bt_chunks = std::max(1, (h->max_bp_rows + BT_B - 1) / BT_B);
+    const dim3 bt_grid(bt_chunks, h->n_chrom, h->n_samples);
+    const size_t bt_maps_lds = (size_t)BT_B * S * sizeof(uint16_t);
+    const size_t bt_write_lds = ((size_t)std::max(BT_B, bt_chunks) * S + BT_B) * sizeof(uint16_t);
+    auto launch_backtrace = [&](hipStream_t st) {
+        hipLaunchKernelGGL(backtrace_maps_kernel, bt_grid, dim3(64), bt_maps_lds, st, S, h->total_bp,
+                           h->total_chunks, h->d_chroms.p, h->bp.p, h->bt_exit.p);
+        hipLaunchKernelGGL(backtrace_write_kernel, bt_grid, dim3(64), bt_write_lds, st, S, h->total_genes,
+                           h->total_bp, h->total_genes + h->n_chrom, h->total_chunks, h->n_chrom, h->d_chroms.p,
+                           h->bp.p, h->bt_exit.p, h->last_state.p, h->states.p, h->calls.p);
+    };
+    const dim3 unit_grid(h->n_chrom, h->n_samples), wave_grid(h->n_samples, h->n_chrom);
+    hipStream_t sa = h->stream, sb = h->stream_b, sc = h->stream_c;
+#if defined(HMM_NO_WAVE)
+    constexpr bool WAVE = false;
+#else
+    constexpr bool WAVE = EXACT && KMAX * 4 <= 64;    // S = 36: the single-wave recursions
+#endif
+    GBRS_HIP_CHECK(hipEventRecord(h->ev[1], sa));
+    hipLaunchKernelGGL(exp_emission_kernel, dim3((unsigned)((rows * S + 255) / 256)), dim3(256), 0, sa,
+                       rows * S, h->eprob.p, h->peprob.p);
+    if constexpr (WAVE) {
+        // Three independent chains from here, each on its own stream (a sample's 40 chromosomes
+        // occupy 40 CUs per chain):  A  alpha -> [join B] beta correction + outputs
+        //                            B  free-running backward
+        //                            C  delta -> backpointers -> backtrace
+        constexpr int SS = KMAX * 4;
+        // While every chain's wave can have a CU of its own, ask for more than half a CU's LDS per
+        // workgroup: the dispatcher then cannot stack two of these single-wave workgroups on one
+        // CU (where they would share a SIMD's issue slots) while other CUs sit idle.
+        size_t pad = 0;
+        {
+            const char *env = std::getenv("GBRS_TUNING_HMM_SPREAD");
+            const bool spread = env ? std::atoi(env) != 0 : true;
+            if (spread && (int64_t)3 * h->n_chrom * h->n_samples <= h->num_cus) pad = 81 * 1024;
+        }
+        if (pad) {
+            GBRS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&forward_wave_kernel<SS, HMM_NSET, 0>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad));
+            GBRS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&forward_wave_kernel<SS, HMM_NSET, 1>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad));
+            GBRS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&backward_wave_kernel<SS, HMM_NSET>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad));
+        }
+        GBRS_HIP_CHECK(hipEventRecord(h->ev_fork, sa));
+        GBRS_HIP_CHECK(hipStreamWaitEvent(sb, h->ev_fork, 0));
+        GBRS_HIP_CHECK(hipStreamWaitEvent(sc, h->ev_fork, 0));
+        hipLaunchKernelGGL((forward_wave_kernel<SS, HMM_NSET, 0>), wave_grid, dim3(64), pad, sa, h->total_genes,
+                           h->d_chroms.p, h->d_order.p, h->tprob.p, h->pprob.p, h->eprob.p, h->peprob.p, h->init_vec.p,
+                           h->xsum.p, h->ahat.p, h->invz.p, h->delta.p, h->last_state.p);
+        GBRS_HIP_CHECK(hipEventRecord(h->ev[2], sa));
+        hipLaunchKernelGGL((backward_wave_kernel<SS, HMM_NSET>), wave_grid, dim3(64), pad, sb, h->total_genes,
+                           h->d_chroms.p, h->d_order.p, h->pprob_t.p, h->peprob.p, h->bhat.p, h->bscale.p);
+        GBRS_HIP_CHECK(hipEventRecord(h->ev_b, sb));
+        hipLaunchKernelGGL((forward_wave_kernel<SS, HMM_NSET, 1>), wave_grid, dim3(64), pad, sc, h->total_genes,
+                           h->d_chroms.p, h->d_order.p, h->tprob.p, h->pprob.p, h->eprob.p, h->peprob.p, h->init_vec.p,
+                           h->xsum.p, h->ahat.p, h->invz.p, h->delta.p, h->last_state.p);
+        if (h->max_bp_rows > 0)
+            hipLaunchKernelGGL(viterbi_bp_kernel, dim3(h->max_bp_rows, h->n_chrom), dim3(256),
+                               (size_t)S * (S + 1) * sizeof(double), sc, S, h->n_samples, h->total_genes,
+                               h->total_bp, h->d_chroms.p, h->tprob.p, h->delta.p, h->bp.p);
+        GBRS_HIP_CHECK(hipEventRecord(h->ev_c1, sc));
+        launch_backtrace(sc);
+        GBRS_HIP_CHECK(hipEventRecord(h->ev_c, sc));
+        GBRS_HIP_CHECK(hipStreamWaitEvent(sa, h->ev_b, 0));
+        hipLaunchKernelGGL(beta_corr_kernel, wave_grid, dim3(256), 0, sa, h->total_genes, h->d_chroms.p,
+                           h->invz.p, h->bscale.p, h->bcorr.p);
+        hipLaunchKernelGGL(hmm_outputs_kernel, out_grid, out_block, out_lds, sa, S, out_rows, rows, h->eprob.p,
+                           h->xsum.p, h->ahat.p, h->invz.p, h->bhat.p, h->bcorr.p, h->alpha.p, h->scaler.p,
+                           h->beta.p, h->gamma.p);
+        GBRS_HIP_CHECK(hipEventRecord(h->ev[3], sa));
+        GBRS_HIP_CHECK(hipStreamWaitEvent(sa, h->ev_c, 0));
+        GBRS_HIP_CHECK(hipEventRecord(h->ev[4], sa));
+        GBRS_HIP_CHECK(hipGetLastError());
+        GBRS_HIP_CHECK(hipStreamSynchronize(sa));
+        // the chains overlap: forward = the longer of alpha and delta + backpointers, backward =
+        // backward sweep + correction + outputs (from the fork), backtrace = the backtrace kernel
+        float ms = 0.f, ms2 = 0.f;
+        if (hipEventElapsedTime(&ms, h->ev[1], h->ev[2]) == hipSuccess &&
+            hipEventElapsedTime(&ms2, h->ev[1], h->ev_c1) == hipSuccess)
+            h->t_fwd = std::max(ms, ms2);
+        if (hipEventElapsedTime(&ms, h->ev_fork, h->ev[3]) == hipSuccess) h->t_bwd = ms;
+        if (hipEventElapsedTime(&ms, h->ev_c1, h->ev_c) == hipSuccess) h->t_bt = ms;
+        if (hipEventElapsedTime(&ms, h->ev[1], h->ev[4]) == hipSuccess) h->t_run = ms;
+        return GBRS_OK;
+    } else {
+        hipLaunchKernelGGL((forward_viterbi_kernel<KMAX, MAXT, EXACT>), dim3(h->n_chrom, h->n_samples, 2), dim3(threads),
+                           2 * S * sizeof(double), sa, S, h->total_genes, h->total_bp, h->d_chroms.p,
+                           h->tprob.p, h->pprob.p, h->eprob.p, h->peprob.p, h->init_vec.p, h->xsum.p, h->ahat.p,
+                           h->invz.p, h->delta.p, h->bp.p, h->last_state.p);
+        GBRS_HIP_CHECK(hipEventRecord(h->ev[2], sa));
+        hipLaunchKernelGGL((backward_kernel<KMAX, MAXT, EXACT>), unit_grid, dim3(threads),
+                           2 * S * sizeof(double), sa, S, h->total_genes, h->d_chroms.p, h->pprob_t.p,
+                           h->peprob.p, h->invz.p, h->bhat.p);
+        hipLaunchKernelGGL(hmm_outputs_kernel, out_grid, out_block, out_lds, sa, S, out_rows, rows, h->eprob.p,
+                           h->xsum.p, h->ahat.p, h->invz.p, h->bhat.p, (const double *)nullptr, h->alpha.p,
+                           h->scaler.p, h->beta.p, h->gamma.p);
+        GBRS_HIP_CHECK(hipEventRecord(h->ev[3], sa));
+        launch_backtrace(sa);
+        GBRS_HIP_CHECK(hipEventRecord(h->ev[4], sa));
+        GBRS_HIP_CHECK(hipGetLastError());
+        GBRS_HIP_CHECK(hipStreamSynchronize(sa));
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, h->ev[1], h->ev[2]) == hipSuccess) h->t_fwd = ms;
+        if (hipEventElapsedTime(&ms, h->ev[2], h->ev[3]) == hipSuccess) h->t_bwd = ms;
+        if (hipEventElapsedTime(&ms, h->ev[3], h->ev[4]) == hipSuccess) h->t_bt = ms;
+        if (hipEventElapsedTime(&ms, h->ev[1], h->ev[4]) == hipSuccess) h->t_run = ms;
+        return GBRS_OK;
+    }
 }
 
 }  // namespace
@@ -775,16 +1294,34 @@ int gbrs_hmm_create(int num_haps, int n_chrom, const int32_t *n_genes, const int
         cd.gene_off = h->total_genes;
         cd.trans_off = h->total_trans;
         cd.bp_off = h->total_bp;
+        cd.chunk_off = h->total_chunks;
+        h->total_chunks += (std::min(n_genes[c], n_trans[c]) + BT_B - 1) / BT_B;
         cd.n_genes = n_genes[c];
         cd.n_trans = n_trans[c];
         h->total_genes += n_genes[c];
         h->total_trans += n_trans[c];
         h->total_bp += std::min(n_genes[c], n_trans[c]);
+        h->max_bp_rows = std::max(h->max_bp_rows, std::min(n_genes[c], n_trans[c]));
+    }
+    {
+        hipDeviceProp_t prop;
+        GBRS_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+        h->num_cus = prop.multiProcessorCount;
     }
     GBRS_HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamDefault));
+    GBRS_HIP_CHECK(hipStreamCreateWithFlags(&h->stream_b, hipStreamNonBlocking));
+    GBRS_HIP_CHECK(hipStreamCreateWithFlags(&h->stream_c, hipStreamNonBlocking));
     for (auto &e : h->ev) GBRS_HIP_CHECK(hipEventCreate(&e));
+    for (hipEvent_t *e : {&h->ev_fork, &h->ev_b, &h->ev_c1, &h->ev_c}) GBRS_HIP_CHECK(hipEventCreate(e));
     GBRS_TRY(h->d_chroms.alloc(n_chrom));
     GBRS_HIP_CHECK(hipMemcpy(h->d_chroms.p, h->chroms.data(), n_chrom * sizeof(ChromDesc), hipMemcpyHostToDevice));
+    {
+        std::vector<int32_t> order(n_chrom);
+        for (int c = 0; c < n_chrom; ++c) order[c] = c;
+        std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return n_genes[a] > n_genes[b]; });
+        GBRS_TRY(h->d_order.alloc(n_chrom));
+        GBRS_HIP_CHECK(hipMemcpy(h->d_order.p, order.data(), n_chrom * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
     const size_t blk = (size_t)S * S;
     GBRS_TRY(h->tprob.alloc(std::max<size_t>(h->total_trans * blk, 1)));
     GBRS_TRY(h->pprob.alloc(std::max<size_t>(h->total_trans * blk, 1)));
@@ -925,6 +1462,7 @@ int gbrs_hmm_info(gbrs_hmm_t *h, gbrs_hmm_info_t *info) {
     info->last_forward_ms = h->t_fwd;
     info->last_backward_ms = h->t_bwd;
     info->last_backtrace_ms = h->t_bt;
+    info->last_run_ms = h->t_run;
     info->num_states = h->S;
     info->n_samples = h->n_samples;
     return GBRS_OK;
@@ -983,10 +1521,14 @@ int gbrs_genoprob_dosage(int num_haps, int64_t n_rows, const double *gprob, doub
 int gbrs_hmm_destroy(gbrs_hmm_t *h) {
     if (!h) return GBRS_OK;
     (void)hipSetDevice(h->device);
-    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (hipStream_t st : {h->stream, h->stream_b, h->stream_c})
+        if (st) (void)hipStreamSynchronize(st);
     for (auto &e : h->ev)
         if (e) (void)hipEventDestroy(e);
-    if (h->stream) (void)hipStreamDestroy(h->stream);
+    for (hipEvent_t e : {h->ev_fork, h->ev_b, h->ev_c1, h->ev_c})
+        if (e) (void)hipEventDestroy(e);
+    for (hipStream_t st : {h->stream, h->stream_b, h->stream_c})
+        if (st) (void)hipStreamDestroy(st);
     delete h;
     return GBRS_OK;
 }

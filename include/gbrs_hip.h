@@ -232,8 +232,13 @@ int gbrs_hmm_get(gbrs_hmm_t *hmm, int sample, int chrom, double *gamma, int32_t 
 typedef struct gbrs_hmm_info {
     uint64_t total_genes;        /* sum_c n_genes[c]                                        */
     uint64_t algorithmic_bytes;  /* per sample: sum_c n_c * (16 S^2 + 64 S)     */
+    /* Device time of the phases of the last run.  For 8 founders (S = 36) the forward, backward and
+     * Viterbi chains run concurrently on three streams, so forward (the longer of alpha and
+     * delta + backpointers) and backward (sweep + outputs) overlap; last_run_ms is the whole of
+     * gbrs_hmm_run on the device. */
     double   last_emission_ms, last_forward_ms, last_backward_ms, last_backtrace_ms;
     int32_t  num_states, n_samples;
+    double   last_run_ms;
 } gbrs_hmm_info_t;
 int gbrs_hmm_info(gbrs_hmm_t *hmm, gbrs_hmm_info_t *info);
 
