@@ -573,6 +573,14 @@ __device__ __forceinline__ void load_row(const double *__restrict__ row, double 
     }
 }
 
+template <int SS>
+__device__ __forceinline__ void read_vec(const double *lds_vec, double2 (&v)[SS / 2]) {
+    const double2 *src = reinterpret_cast<const double2 *>(lds_vec);
+#pragma unroll
+    for (int m = 0; m < SS / 2; ++m) v[m] = src[m];
+    asm volatile("" ::: "memory");
+}
+
 // orders this wave's LDS writes before its later LDS reads for the compiler; the hardware keeps
 // one wave's DS instructions in order
 __device__ __forceinline__ void wave_lds_fence() {
@@ -594,36 +602,44 @@ __device__ __forceinline__ void wave_lds_fence() {
 // argmax_k(delta_t[k] + T[t][j][k]) of stored rows, which viterbi_bp_kernel evaluates for every t
 // in parallel instead of on the sequential path).  The two are separate launches on separate
 // streams (each keeps its own register budget).
-template <int SS, int NSET, int ROLE>
+template <int SS, int NSET, int SB, int ROLE, bool HOIST>
 __global__ void __launch_bounds__(64)
-forward_wave_kernel(int64_t genes_per_sample, const ChromDesc *__restrict__ chroms,
+forward_wave_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *__restrict__ chroms,
                     const int32_t *__restrict__ order, const double *__restrict__ tprob, const double *__restrict__ pprob,
                     const double *__restrict__ eprob, const double *__restrict__ peprob,
                     const double *__restrict__ init_vec, double *__restrict__ xsum,
                     double *__restrict__ ahat, double *__restrict__ invz, double *__restrict__ delta,
                     int32_t *__restrict__ last_state) {
     static_assert(SS % 2 == 0 && SS <= 64, "one lane per state, 16-byte aligned rows");
-    __shared__ __attribute__((aligned(16))) double buf[2][SS];
+    __shared__ __attribute__((aligned(16))) double buf[SB][2][SS];
     const int chrom = order[blockIdx.y];
     const ChromDesc cd = chroms[chrom];
-    const int sample = blockIdx.x;
     constexpr int role = ROLE;
     const int n = cd.n_genes;
     if (n <= 0) return;
     const int j = threadIdx.x;
     const bool act = j < SS;
     const int jr = act ? j : SS - 1;
-    const int64_t g0 = (int64_t)sample * genes_per_sample + cd.gene_off;
+    // the SB samples of this wave share every transition block it loads; a sample index past the
+    // end shadows the last sample and never stores
+    bool sv[SB];
+    int64_t g0[SB];
+#pragma unroll
+    for (int b = 0; b < SB; ++b) {
+        const int sample = blockIdx.x * SB + b;
+        sv[b] = sample < n_samples;
+        g0[b] = (int64_t)min(sample, n_samples - 1) * genes_per_sample + cd.gene_off;
+    }
     const int n_ord = min(n, cd.n_trans + 1) - 1;   // step i = o + 1 needs T[o]
     int cur = 0;
     // role 0 streams P = exp(T) and pe = exp(e); role 1 streams T and e
     const double *BLK = (role == 0 ? pprob : tprob) + cd.trans_off * (int64_t)SS * SS;
-    const double *EM = (role == 0 ? peprob : eprob) + g0 * SS;
+    const double *EM = role == 0 ? peprob : eprob;
     // Loads are unconditional with clamped block indices (a conditional refill would make the
     // compiler merge whole register sets at every join): past the end they re-read the last block.
     const int last_o = max(n_ord - 1, 0);
     const bool any = cd.n_trans > 0 && n > 1;
-    double pr[NSET][SS], em_r[NSET];
+    double pr[NSET][SS], em_r[NSET][SB];
 #pragma unroll
     for (int u = 0; u < NSET; ++u) {
         const int ou = min(u, last_o);
@@ -632,61 +648,74 @@ forward_wave_kernel(int64_t genes_per_sample, const ChromDesc *__restrict__ chro
 #pragma unroll
             for (int m = 0; m < SS; ++m) pr[u][m] = 0.0;
         }
-        em_r[u] = any ? EM[(int64_t)(ou + 1) * SS + jr] : 0.0;
+#pragma unroll
+        for (int b = 0; b < SB; ++b) em_r[u][b] = any ? EM[(g0[b] + ou + 1) * SS + jr] : 0.0;
     }
-    auto prefetch = [&](int o, double (&pn)[SS], double &em_n) {
+    auto prefetch = [&](int o, double (&pn)[SS], double (&em_n)[SB]) {
         const int of = min(o + NSET - 1, last_o);
-        HMM_LOAD_PRED load_row<SS>(BLK + ((int64_t)HMM_BLK(of) * SS + jr) * SS, pn);
-        em_n = EM[(int64_t)(of + 1) * SS + jr];
+        load_row<SS>(BLK + ((int64_t)HMM_BLK(of) * SS + jr) * SS, pn);
+#pragma unroll
+        for (int b = 0; b < SB; ++b) em_n[b] = EM[(g0[b] + of + 1) * SS + jr];
     };
 
     if constexpr (role == 0) {
-        const double *E = eprob + g0 * SS;
-        double *XS = xsum + g0 * SS, *AH = ahat + g0 * SS, *IZ = invz + g0;
-        double y_own = exp(init_vec[jr] + E[jr]);
-        if (act) {
-            buf[0][j] = y_own;
-            XS[j] = exp(init_vec[j]);             // so that log(x) + e reproduces init + e
+        double y_own[SB];
+#pragma unroll
+        for (int b = 0; b < SB; ++b) {
+            y_own[b] = exp(init_vec[jr] + eprob[g0[b] * SS + jr]);
+            if (act) buf[b][0][j] = y_own[b];
+            if (act && sv[b]) xsum[g0[b] * SS + j] = exp(init_vec[j]);   // so that log(x) + e reproduces init + e
         }
         wave_lds_fence();
-        // Z of the vector in buf[cur] comes out of the same broadcast reads as the products: every
-        // lane adds it up itself, no cross-lane operation
-        auto finish = [&](int i_prev, double z) {
+        // Z of the vector in buf[.][cur] comes out of the same broadcast reads as the products:
+        // every lane adds it up itself, no cross-lane operation
+        auto finish = [&](int b, int i_prev, double z) {
             const double inv_z = fast_recip_pos(z);
-            if (act) {
-                AH[(int64_t)i_prev * SS + j] = y_own * inv_z;
-                if (j == 0) IZ[i_prev] = inv_z;
+            if (act && sv[b]) {
+                ahat[(g0[b] + i_prev) * SS + j] = y_own[b] * inv_z;
+                if (j == 0) invz[g0[b] + i_prev] = inv_z;
             }
             return inv_z;
         };
-        auto step = [&](int o, const double (&pc)[SS], double pe, double (&pn)[SS], double &pe_n) {
+        auto step = [&](int o, const double (&pc)[SS], const double (&pe)[SB], double (&pn)[SS], double (&pe_n)[SB]) {
             const int i = o + 1;
-            prefetch(o, pn, pe_n);
-            const double2 *yv = reinterpret_cast<const double2 *>(buf[cur]);
-            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, z0 = 0.0, z1 = 0.0, z2 = 0.0, z3 = 0.0;
+            double pe_now[SB];
 #pragma unroll
-            for (int m = 0; m < SS / 2; ++m) {
-                const double2 v = yv[m];
-                if (m & 1) {
-                    s2 = fma(v.x, pc[2 * m], s2);
-                    s3 = fma(v.y, pc[2 * m + 1], s3);
-                    z2 += v.x;
-                    z3 += v.y;
-                } else {
-                    s0 = fma(v.x, pc[2 * m], s0);
-                    s1 = fma(v.y, pc[2 * m + 1], s1);
-                    z0 += v.x;
-                    z1 += v.y;
+            for (int b = 0; b < SB; ++b) pe_now[b] = pe[b];
+            prefetch(o, pn, pe_n);
+#pragma unroll
+            for (int b = 0; b < SB; ++b) {
+                // HOIST: every broadcast read goes out before the products (a compiler left alone
+                // keeps ~4 in flight); it costs SS registers, so only where the sets leave room
+                double2 yv_r[HOIST ? SS / 2 : 1];
+                const double2 *yv = reinterpret_cast<const double2 *>(buf[b][cur]);
+                if constexpr (HOIST) {
+                    read_vec<SS>(buf[b][cur], yv_r);
+                    yv = yv_r;
                 }
+                double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, z0 = 0.0, z1 = 0.0, z2 = 0.0, z3 = 0.0;
+#pragma unroll
+                for (int m = 0; m < SS / 2; ++m) {
+                    const double2 v = yv[m];
+                    if (m & 1) {
+                        s2 = fma(v.x, pc[2 * m], s2);
+                        s3 = fma(v.y, pc[2 * m + 1], s3);
+                        z2 += v.x;
+                        z3 += v.y;
+                    } else {
+                        s0 = fma(v.x, pc[2 * m], s0);
+                        s1 = fma(v.y, pc[2 * m + 1], s1);
+                        z0 += v.x;
+                        z1 += v.y;
+                    }
+                }
+                const double inv_z = finish(b, i - 1, (z0 + z1) + (z2 + z3));
+                const double x = ((s0 + s1) + (s2 + s3)) * inv_z + TINY;
+                y_own[b] = x * pe_now[b];
+                if (act) buf[b][cur ^ 1][j] = y_own[b];
+                if (act && sv[b]) xsum[(g0[b] + i) * SS + j] = x;
             }
-            const double inv_z = finish(i - 1, (z0 + z1) + (z2 + z3));
-            const double x = ((s0 + s1) + (s2 + s3)) * inv_z + TINY;
-            y_own = x * pe;
             cur ^= 1;
-            if (act) {
-                buf[cur][j] = y_own;
-                XS[(int64_t)i * SS + j] = x;
-            }
             wave_lds_fence();
         };
         int o = 0;
@@ -698,56 +727,66 @@ forward_wave_kernel(int64_t genes_per_sample, const ChromDesc *__restrict__ chro
 #pragma unroll
         for (int u = 0; u < NSET - 1; ++u)
             if (o + u < n_ord) step(o + u, pr[u], em_r[u], pr[(u + NSET - 1) % NSET], em_r[(u + NSET - 1) % NSET]);
-        {
-            const double2 *yv = reinterpret_cast<const double2 *>(buf[cur]);
+#pragma unroll
+        for (int b = 0; b < SB; ++b) {
+            const double2 *yv = reinterpret_cast<const double2 *>(buf[b][cur]);
             double z0 = 0.0, z1 = 0.0, z2 = 0.0, z3 = 0.0;
 #pragma unroll
             for (int m = 0; m < SS / 2; ++m) {
                 const double2 v = yv[m];
                 if (m & 1) { z2 += v.x; z3 += v.y; } else { z0 += v.x; z1 += v.y; }
             }
-            finish(n_ord, (z0 + z1) + (z2 + z3));
+            finish(b, n_ord, (z0 + z1) + (z2 + z3));
         }
         return;
     }
 
     // role 1: Viterbi values in the log domain (adds and max only: exact)
-    double *DL = delta + g0 * SS;
-    double d_own = init_vec[jr] + EM[jr];
-    if (act) {
-        buf[0][j] = d_own;
-        DL[j] = d_own;
+#pragma unroll
+    for (int b = 0; b < SB; ++b) {
+        const double d0 = init_vec[jr] + EM[g0[b] * SS + jr];
+        if (act) buf[b][0][j] = d0;
+        if (act && sv[b]) delta[g0[b] * SS + j] = d0;
     }
     wave_lds_fence();
-    auto step = [&](int o, const double (&tc)[SS], double e, double (&tn)[SS], double &e_n) {
+    auto step = [&](int o, const double (&tc)[SS], const double (&e)[SB], double (&tn)[SS], double (&e_n)[SB]) {
         const int i = o + 1;
-        prefetch(o, tn, e_n);
-        const double2 *dp = reinterpret_cast<const double2 *>(buf[cur]);
-        double m0, m1, m2, m3;
-        {
-            const double2 v0 = dp[0], v1 = dp[1];
-            m0 = v0.x + tc[0];
-            m1 = v0.y + tc[1];
-            m2 = v1.x + tc[2];
-            m3 = v1.y + tc[3];
-        }
+        double e_now[SB];
 #pragma unroll
-        for (int m = 2; m < SS / 2; ++m) {
-            const double2 v = dp[m];
-            if (m & 1) {
-                m2 = fmax(m2, v.x + tc[2 * m]);
-                m3 = fmax(m3, v.y + tc[2 * m + 1]);
-            } else {
-                m0 = fmax(m0, v.x + tc[2 * m]);
-                m1 = fmax(m1, v.y + tc[2 * m + 1]);
+        for (int b = 0; b < SB; ++b) e_now[b] = e[b];
+        prefetch(o, tn, e_n);
+#pragma unroll
+        for (int b = 0; b < SB; ++b) {
+            double2 dp_r[HOIST ? SS / 2 : 1];
+            const double2 *dp = reinterpret_cast<const double2 *>(buf[b][cur]);
+            if constexpr (HOIST) {
+                read_vec<SS>(buf[b][cur], dp_r);
+                dp = dp_r;
             }
+            double m0, m1, m2, m3;
+            {
+                const double2 v0 = dp[0], v1 = dp[1];
+                m0 = v0.x + tc[0];
+                m1 = v0.y + tc[1];
+                m2 = v1.x + tc[2];
+                m3 = v1.y + tc[3];
+            }
+#pragma unroll
+            for (int m = 2; m < SS / 2; ++m) {
+                const double2 v = dp[m];
+                if (m & 1) {
+                    m2 = fmax(m2, v.x + tc[2 * m]);
+                    m3 = fmax(m3, v.y + tc[2 * m + 1]);
+                } else {
+                    m0 = fmax(m0, v.x + tc[2 * m]);
+                    m1 = fmax(m1, v.y + tc[2 * m + 1]);
+                }
+            }
+            const double d = fmax(fmax(m0, m1), fmax(m2, m3)) + e_now[b];
+            if (act) buf[b][cur ^ 1][j] = d;
+            if (act && sv[b]) delta[(g0[b] + i) * SS + j] = d;
         }
-        d_own = fmax(fmax(m0, m1), fmax(m2, m3)) + e;
         cur ^= 1;
-        if (act) {
-            buf[cur][j] = d_own;
-            DL[(int64_t)i * SS + j] = d_own;
-        }
         wave_lds_fence();
     };
     int o = 0;
@@ -759,13 +798,13 @@ forward_wave_kernel(int64_t genes_per_sample, const ChromDesc *__restrict__ chro
 #pragma unroll
     for (int u = 0; u < NSET - 1; ++u)
         if (o + u < n_ord) step(o + u, pr[u], em_r[u], pr[(u + NSET - 1) % NSET], em_r[(u + NSET - 1) % NSET]);
-    if (j == 0) {                            // sid = argmax delta[:, n-1] (first max)
-        const double *dl = buf[cur];
-        double b = dl[0];
+    if (j < SB && blockIdx.x * SB + j < n_samples) {      // sid = argmax delta[:, n-1] (first max)
+        const double *dl = buf[j][cur];
+        double bv = dl[0];
         int bk = 0;
         for (int s = 1; s < SS; ++s)
-            if (dl[s] > b) { b = dl[s]; bk = s; }
-        last_state[(int64_t)sample * gridDim.y + chrom] = bk;
+            if (dl[s] > bv) { bv = dl[s]; bk = s; }
+        last_state[(int64_t)(blockIdx.x * SB + j) * gridDim.y + chrom] = bk;
     }
 }
 
@@ -810,37 +849,42 @@ viterbi_bp_kernel(int S, int n_samples, int64_t genes_per_sample, int64_t bp_per
 // come out of the broadcast reads the products use).  The reference's beta differs from log(bt) by
 // a per-gene constant, log C_i = sum_{t>=i} log(1/Z_t) - sum_{i<=t<=n-2} log(r_t), which
 // beta_corr_kernel adds afterwards; the posterior is scale free.
-template <int SS, int NSET>
+template <int SS, int NSET, int SB>
 __global__ void __launch_bounds__(64)
-backward_wave_kernel(int64_t genes_per_sample, const ChromDesc *__restrict__ chroms,
-                     const int32_t *__restrict__ order, const double *__restrict__ pprob_t, const double *__restrict__ peprob,
-                     double *__restrict__ bhat, double *__restrict__ bscale) {
+backward_wave_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *__restrict__ chroms,
+                     const int32_t *__restrict__ order, const double *__restrict__ pprob_t,
+                     const double *__restrict__ peprob, double *__restrict__ bhat, double *__restrict__ bscale) {
     static_assert(SS % 2 == 0 && SS <= 64, "one lane per state, 16-byte aligned rows");
-    __shared__ __attribute__((aligned(16))) double buf[2][SS];
+    __shared__ __attribute__((aligned(16))) double buf[SB][2][SS];
     const ChromDesc cd = chroms[order[blockIdx.y]];
-    const int sample = blockIdx.x;
     const int n = cd.n_genes;
     if (n <= 0) return;
     const int j = threadIdx.x;
     const bool act = j < SS;
     const int jr = act ? j : SS - 1;
-    const int64_t g0 = (int64_t)sample * genes_per_sample + cd.gene_off;
-    const double *PE = peprob + g0 * SS;
-    double *BH = bhat + g0 * SS, *BS = bscale + g0;
+    bool sv[SB];
+    int64_t g0[SB];
+#pragma unroll
+    for (int b = 0; b < SB; ++b) {
+        const int sample = blockIdx.x * SB + b;
+        sv[b] = sample < n_samples;
+        g0[b] = (int64_t)min(sample, n_samples - 1) * genes_per_sample + cd.gene_off;
+    }
     const double *Pt = pprob_t + cd.trans_off * (int64_t)SS * SS;
     int cur = 0;
-    {
-        const int64_t o = (int64_t)(n - 1) * SS + jr;
-        if (act) {
-            BH[o] = 1.0;
-            buf[0][j] = PE[o];
-            if (j == 0) BS[n - 1] = 1.0;
+#pragma unroll
+    for (int b = 0; b < SB; ++b) {
+        const int64_t o = (g0[b] + n - 1) * SS + jr;
+        if (act) buf[b][0][j] = peprob[o];
+        if (act && sv[b]) {
+            bhat[o] = 1.0;
+            if (j == 0) bscale[g0[b] + n - 1] = 1.0;
         }
     }
     // order o <-> gene i = n-2-o, transition block i (the host checked n_trans >= n-1)
     const int n_ord = n - 1;
     const int last_o = max(n_ord - 1, 0);
-    double tr[NSET][SS], pe_r[NSET];
+    double tr[NSET][SS], pe_r[NSET][SB];
 #pragma unroll
     for (int u = 0; u < NSET; ++u) {
         const int i = n - 2 - min(u, last_o);
@@ -849,39 +893,49 @@ backward_wave_kernel(int64_t genes_per_sample, const ChromDesc *__restrict__ chr
 #pragma unroll
             for (int m = 0; m < SS; ++m) tr[u][m] = 0.0;
         }
-        pe_r[u] = n_ord > 0 ? PE[(int64_t)i * SS + jr] : 0.0;
+#pragma unroll
+        for (int b = 0; b < SB; ++b) pe_r[u][b] = n_ord > 0 ? peprob[(g0[b] + i) * SS + jr] : 0.0;
     }
     wave_lds_fence();
-    auto step = [&](int o, bool rescale, const double (&tc)[SS], double pe, double (&tn)[SS], double &pe_n) {
+    auto step = [&](int o, bool rescale, const double (&tc)[SS], const double (&pe)[SB], double (&tn)[SS],
+                    double (&pe_n)[SB]) {
         const int i = n - 2 - o;
-        {
-            const int in = n - 2 - min(o + NSET - 1, last_o);     // clamped: see forward_wave_kernel
-            load_row<SS>(Pt + ((int64_t)HMM_BLK(in) * SS + jr) * SS, tn);
-            pe_n = PE[(int64_t)in * SS + jr];
-        }
-        const double2 *wv = reinterpret_cast<const double2 *>(buf[cur]);
-        double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, z0 = 0.0, z1 = 0.0;
+        double pe_now[SB];
 #pragma unroll
-        for (int m = 0; m < SS / 2; ++m) {
-            const double2 v = wv[m];
-            if (m & 1) {
-                s2 = fma(v.x, tc[2 * m], s2);
-                s3 = fma(v.y, tc[2 * m + 1], s3);
-                if (rescale) z1 += v.x + v.y;
-            } else {
-                s0 = fma(v.x, tc[2 * m], s0);
-                s1 = fma(v.y, tc[2 * m + 1], s1);
-                if (rescale) z0 += v.x + v.y;
+        for (int b = 0; b < SB; ++b) pe_now[b] = pe[b];
+        const int in = n - 2 - min(o + NSET - 1, last_o);     // clamped: see forward_wave_kernel
+#pragma unroll
+        for (int b = 0; b < SB; ++b) pe_n[b] = peprob[(g0[b] + in) * SS + jr];
+        load_row<SS>(Pt + ((int64_t)HMM_BLK(in) * SS + jr) * SS, tn);
+#pragma unroll
+        for (int b = 0; b < SB; ++b) {
+            // all broadcast reads of the vector go out first (a compiler left alone keeps ~4 in
+            // flight and the step becomes a chain of LDS latencies)
+            double2 wv[SS / 2];
+            read_vec<SS>(buf[b][cur], wv);
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, z0 = 0.0, z1 = 0.0;
+#pragma unroll
+            for (int m = 0; m < SS / 2; ++m) {
+                const double2 v = wv[m];
+                if (m & 1) {
+                    s2 = fma(v.x, tc[2 * m], s2);
+                    s3 = fma(v.y, tc[2 * m + 1], s3);
+                    if (rescale) z1 += v.x + v.y;
+                } else {
+                    s0 = fma(v.x, tc[2 * m], s0);
+                    s1 = fma(v.y, tc[2 * m + 1], s1);
+                    if (rescale) z0 += v.x + v.y;
+                }
+            }
+            const double r = rescale ? fast_recip_pos(z0 + z1) : 1.0;
+            const double bh = ((s0 + s1) + (s2 + s3)) * r;
+            if (act) buf[b][cur ^ 1][j] = bh * pe_now[b];
+            if (act && sv[b]) {
+                bhat[(g0[b] + i) * SS + j] = bh;
+                if (j == 0) bscale[g0[b] + i] = r;
             }
         }
-        const double r = rescale ? fast_recip_pos(z0 + z1) : 1.0;
-        const double bh = ((s0 + s1) + (s2 + s3)) * r;
         cur ^= 1;
-        if (act) {
-            buf[cur][j] = bh * pe;
-            BH[(int64_t)i * SS + j] = bh;
-            if (j == 0) BS[i] = r;
-        }
         wave_lds_fence();
     };
     int o = 0;
@@ -1142,7 +1196,19 @@ int hmm_alloc_samples(gbrs_hmm *h, int n_samples) {
 }
 
 #ifndef HMM_NSET
-#define HMM_NSET 3
+#define HMM_NSET 3        // register sets of the one-sample-per-wave recursions
+#endif
+#ifndef HMM_HOIST_A
+#define HMM_HOIST_A true    // hoisted LDS reads in the one-sample alpha / delta recursions
+#endif
+#ifndef HMM_HOIST_D
+#define HMM_HOIST_D true
+#endif
+#ifndef HMM_SB
+#define HMM_SB 4          // samples per wave once n_samples >= HMM_SB
+#endif
+#ifndef HMM_NSET_B
+#define HMM_NSET_B 2      // register sets of the HMM_SB-samples-per-wave recursions
 #endif
 
 template <int KMAX, int MAXT, bool EXACT>
@@ -1164,7 +1230,7 @@ int hmm_launch(gbrs_hmm *h) {
                            h->total_bp, h->total_genes + h->n_chrom, h->total_chunks, h->n_chrom, h->d_chroms.p,
                            h->bp.p, h->bt_exit.p, h->last_state.p, h->states.p, h->calls.p);
     };
-    const dim3 unit_grid(h->n_chrom, h->n_samples), wave_grid(h->n_samples, h->n_chrom);
+    const dim3 unit_grid(h->n_chrom, h->n_samples);
     hipStream_t sa = h->stream, sb = h->stream_b, sc = h->stream_c;
 #if defined(HMM_NO_WAVE)
     constexpr bool WAVE = false;
@@ -1180,6 +1246,11 @@ int hmm_launch(gbrs_hmm *h) {
         //                            B  free-running backward
         //                            C  delta -> backpointers -> backtrace
         constexpr int SS = KMAX * 4;
+        // Few samples: one sample per wave and a 3-deep prefetch ring (latency).  Many samples:
+        // HMM_SB samples share each wave's transition registers and 2 sets suffice (throughput:
+        // a quarter of the block loads per sample and two waves per SIMD).
+        const bool batched = h->n_samples >= HMM_SB;
+        const dim3 wave_grid(batched ? (h->n_samples + HMM_SB - 1) / HMM_SB : h->n_samples, h->n_chrom);
         // While every chain's wave can have a CU of its own, ask for more than half a CU's LDS per
         // workgroup: the dispatcher then cannot stack two of these single-wave workgroups on one
         // CU (where they would share a SIMD's issue slots) while other CUs sit idle.
@@ -1187,29 +1258,32 @@ int hmm_launch(gbrs_hmm *h) {
         {
             const char *env = std::getenv("GBRS_TUNING_HMM_SPREAD");
             const bool spread = env ? std::atoi(env) != 0 : true;
-            if (spread && (int64_t)3 * h->n_chrom * h->n_samples <= h->num_cus) pad = 81 * 1024;
+            if (!batched && spread && (int64_t)3 * h->n_chrom * h->n_samples <= h->num_cus) pad = 81 * 1024;
         }
+        auto k_alpha = batched ? &forward_wave_kernel<SS, HMM_NSET_B, HMM_SB, 0, true> : &forward_wave_kernel<SS, HMM_NSET, 1, 0, HMM_HOIST_A>;
+        auto k_delta = batched ? &forward_wave_kernel<SS, HMM_NSET_B, HMM_SB, 1, true> : &forward_wave_kernel<SS, HMM_NSET, 1, 1, HMM_HOIST_D>;
+        auto k_back = batched ? &backward_wave_kernel<SS, HMM_NSET_B, HMM_SB> : &backward_wave_kernel<SS, HMM_NSET, 1>;
         if (pad) {
-            GBRS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&forward_wave_kernel<SS, HMM_NSET, 0>),
+            GBRS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_alpha),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad));
-            GBRS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&forward_wave_kernel<SS, HMM_NSET, 1>),
+            GBRS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_delta),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad));
-            GBRS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(&backward_wave_kernel<SS, HMM_NSET>),
+            GBRS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_back),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad));
         }
         GBRS_HIP_CHECK(hipEventRecord(h->ev_fork, sa));
         GBRS_HIP_CHECK(hipStreamWaitEvent(sb, h->ev_fork, 0));
         GBRS_HIP_CHECK(hipStreamWaitEvent(sc, h->ev_fork, 0));
-        hipLaunchKernelGGL((forward_wave_kernel<SS, HMM_NSET, 0>), wave_grid, dim3(64), pad, sa, h->total_genes,
-                           h->d_chroms.p, h->d_order.p, h->tprob.p, h->pprob.p, h->eprob.p, h->peprob.p, h->init_vec.p,
-                           h->xsum.p, h->ahat.p, h->invz.p, h->delta.p, h->last_state.p);
+        hipLaunchKernelGGL(k_alpha, wave_grid, dim3(64), pad, sa, h->n_samples, h->total_genes,
+                           h->d_chroms.p, h->d_order.p, h->tprob.p, h->pprob.p, h->eprob.p, h->peprob.p,
+                           h->init_vec.p, h->xsum.p, h->ahat.p, h->invz.p, h->delta.p, h->last_state.p);
         GBRS_HIP_CHECK(hipEventRecord(h->ev[2], sa));
-        hipLaunchKernelGGL((backward_wave_kernel<SS, HMM_NSET>), wave_grid, dim3(64), pad, sb, h->total_genes,
+        hipLaunchKernelGGL(k_back, wave_grid, dim3(64), pad, sb, h->n_samples, h->total_genes,
                            h->d_chroms.p, h->d_order.p, h->pprob_t.p, h->peprob.p, h->bhat.p, h->bscale.p);
         GBRS_HIP_CHECK(hipEventRecord(h->ev_b, sb));
-        hipLaunchKernelGGL((forward_wave_kernel<SS, HMM_NSET, 1>), wave_grid, dim3(64), pad, sc, h->total_genes,
-                           h->d_chroms.p, h->d_order.p, h->tprob.p, h->pprob.p, h->eprob.p, h->peprob.p, h->init_vec.p,
-                           h->xsum.p, h->ahat.p, h->invz.p, h->delta.p, h->last_state.p);
+        hipLaunchKernelGGL(k_delta, wave_grid, dim3(64), pad, sc, h->n_samples, h->total_genes,
+                           h->d_chroms.p, h->d_order.p, h->tprob.p, h->pprob.p, h->eprob.p, h->peprob.p,
+                           h->init_vec.p, h->xsum.p, h->ahat.p, h->invz.p, h->delta.p, h->last_state.p);
         if (h->max_bp_rows > 0)
             hipLaunchKernelGGL(viterbi_bp_kernel, dim3(h->max_bp_rows, h->n_chrom), dim3(256),
                                (size_t)S * (S + 1) * sizeof(double), sc, S, h->n_samples, h->total_genes,
@@ -1218,7 +1292,7 @@ int hmm_launch(gbrs_hmm *h) {
         launch_backtrace(sc);
         GBRS_HIP_CHECK(hipEventRecord(h->ev_c, sc));
         GBRS_HIP_CHECK(hipStreamWaitEvent(sa, h->ev_b, 0));
-        hipLaunchKernelGGL(beta_corr_kernel, wave_grid, dim3(256), 0, sa, h->total_genes, h->d_chroms.p,
+        hipLaunchKernelGGL(beta_corr_kernel, dim3(h->n_samples, h->n_chrom), dim3(256), 0, sa, h->total_genes, h->d_chroms.p,
                            h->invz.p, h->bscale.p, h->bcorr.p);
         hipLaunchKernelGGL(hmm_outputs_kernel, out_grid, out_block, out_lds, sa, S, out_rows, rows, h->eprob.p,
                            h->xsum.p, h->ahat.p, h->invz.p, h->bhat.p, h->bcorr.p, h->alpha.p, h->scaler.p,
