@@ -25,7 +25,7 @@ def test_struct_sizes():
     import ctypes as C
     from gbrs_amd import _lib
     assert C.sizeof(_lib.EmInfo) == 8 * 8 + 4 * 4 + 3 * 8
-    assert C.sizeof(_lib.HmmInfo) == 2 * 8 + 4 * 8 + 2 * 4
+    assert C.sizeof(_lib.HmmInfo) == 2 * 8 + 4 * 8 + 2 * 4 + 8
 
 
 def test_no_cpu_fallback_without_device(hip_lib):
