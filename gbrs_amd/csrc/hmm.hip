@@ -988,13 +988,14 @@ beta_corr_kernel(int64_t genes_per_sample, const ChromDesc *__restrict__ chroms,
 // (sample, gene):  alpha = log(x) + e - log(Z), scaler = -log(Z), beta = log(bhat),
 // gamma = ahat*bhat / sum_j(ahat*bhat)  (gbrs_utils.py:515-524, :542-549, :558-560).
 __global__ void __launch_bounds__(1024)
-hmm_outputs_kernel(int S, int OUT_ROWS /* (sample, gene) rows per workgroup */, int64_t n_rows,
+hmm_outputs_kernel(int S, int OUT_ROWS /* (sample, gene) rows per workgroup */, int64_t n_rows, int parts,
                    const double *__restrict__ eprob, const double *__restrict__ xsum,
                    const double *__restrict__ ahat, const double *__restrict__ invz,
                    const double *__restrict__ bhat, const double *__restrict__ bcorr /* nullable */,
                    double *__restrict__ alpha, double *__restrict__ scaler, double *__restrict__ beta,
                    double *__restrict__ gamma) {
-    // one thread per (row, state) element: every array is read and written as a contiguous stream
+    // one thread per (row, state) element: every array is read and written as a contiguous stream.
+    // parts & 1: alpha and scaler (forward results only);  parts & 2: beta and gamma (both sweeps)
     extern __shared__ double lds[];               // g[OUT_ROWS * S], norm[OUT_ROWS]
     double *l_g = lds, *l_norm = lds + OUT_ROWS * S;
     const int64_t r0 = (int64_t)blockIdx.x * OUT_ROWS;
@@ -1002,6 +1003,12 @@ hmm_outputs_kernel(int S, int OUT_ROWS /* (sample, gene) rows per workgroup */, 
     const int t = threadIdx.x;
     const bool live = t < nr * S;
     const int64_t o = r0 * S + t;
+    const int row = t / S;
+    if (parts & 1) {
+        if (t < nr) scaler[r0 + t] = log(invz[r0 + t]);              // -log(Z)
+        if (live) alpha[o] = (log(xsum[o]) + eprob[o]) + log(invz[r0 + row]);
+    }
+    if (!(parts & 2)) return;
     double ah = 0.0, bh = 0.0;
     if (live) {
         ah = ahat[o];
@@ -1013,13 +1020,9 @@ hmm_outputs_kernel(int S, int OUT_ROWS /* (sample, gene) rows per workgroup */, 
         double norm = 0.0;
         for (int s = 0; s < S; ++s) norm += l_g[t * S + s];      // sequential over states, as ndarray.sum(axis=0)
         l_norm[t] = norm;
-        scaler[r0 + t] = log(invz[r0 + t]);                        // -log(Z)
     }
     __syncthreads();
     if (live) {
-        const int row = t / S;
-        const double lz = -log(invz[r0 + row]);
-        alpha[o] = (log(xsum[o]) + eprob[o]) - lz;
         beta[o] = bcorr ? log(bh) + bcorr[r0 + row] : log(bh);
         gamma[o] = ah * bh / l_norm[row];
     }
@@ -1232,6 +1235,7 @@ int hmm_launch(gbrs_hmm *h) {
     };
     const dim3 unit_grid(h->n_chrom, h->n_samples);
     hipStream_t sa = h->stream, sb = h->stream_b, sc = h->stream_c;
+    if (const char *env = std::getenv("GBRS_TUNING_HMM_SERIAL"); env && std::atoi(env)) sb = sc = sa;
 #if defined(HMM_NO_WAVE)
     constexpr bool WAVE = false;
 #else
@@ -1277,6 +1281,9 @@ int hmm_launch(gbrs_hmm *h) {
         hipLaunchKernelGGL(k_alpha, wave_grid, dim3(64), pad, sa, h->n_samples, h->total_genes,
                            h->d_chroms.p, h->d_order.p, h->tprob.p, h->pprob.p, h->eprob.p, h->peprob.p,
                            h->init_vec.p, h->xsum.p, h->ahat.p, h->invz.p, h->delta.p, h->last_state.p);
+        hipLaunchKernelGGL(hmm_outputs_kernel, out_grid, out_block, out_lds, sa, S, out_rows, rows, 1, h->eprob.p,
+                           h->xsum.p, h->ahat.p, h->invz.p, h->bhat.p, h->bcorr.p, h->alpha.p, h->scaler.p,
+                           h->beta.p, h->gamma.p);
         GBRS_HIP_CHECK(hipEventRecord(h->ev[2], sa));
         hipLaunchKernelGGL(k_back, wave_grid, dim3(64), pad, sb, h->n_samples, h->total_genes,
                            h->d_chroms.p, h->d_order.p, h->pprob_t.p, h->peprob.p, h->bhat.p, h->bscale.p);
@@ -1294,7 +1301,7 @@ int hmm_launch(gbrs_hmm *h) {
         GBRS_HIP_CHECK(hipStreamWaitEvent(sa, h->ev_b, 0));
         hipLaunchKernelGGL(beta_corr_kernel, dim3(h->n_samples, h->n_chrom), dim3(256), 0, sa, h->total_genes, h->d_chroms.p,
                            h->invz.p, h->bscale.p, h->bcorr.p);
-        hipLaunchKernelGGL(hmm_outputs_kernel, out_grid, out_block, out_lds, sa, S, out_rows, rows, h->eprob.p,
+        hipLaunchKernelGGL(hmm_outputs_kernel, out_grid, out_block, out_lds, sa, S, out_rows, rows, 2, h->eprob.p,
                            h->xsum.p, h->ahat.p, h->invz.p, h->bhat.p, h->bcorr.p, h->alpha.p, h->scaler.p,
                            h->beta.p, h->gamma.p);
         GBRS_HIP_CHECK(hipEventRecord(h->ev[3], sa));
@@ -1321,7 +1328,7 @@ int hmm_launch(gbrs_hmm *h) {
         hipLaunchKernelGGL((backward_kernel<KMAX, MAXT, EXACT>), unit_grid, dim3(threads),
                            2 * S * sizeof(double), sa, S, h->total_genes, h->d_chroms.p, h->pprob_t.p,
                            h->peprob.p, h->invz.p, h->bhat.p);
-        hipLaunchKernelGGL(hmm_outputs_kernel, out_grid, out_block, out_lds, sa, S, out_rows, rows, h->eprob.p,
+        hipLaunchKernelGGL(hmm_outputs_kernel, out_grid, out_block, out_lds, sa, S, out_rows, rows, 3, h->eprob.p,
                            h->xsum.p, h->ahat.p, h->invz.p, h->bhat.p, (const double *)nullptr, h->alpha.p,
                            h->scaler.p, h->beta.p, h->gamma.p);
         GBRS_HIP_CHECK(hipEventRecord(h->ev[3], sa));
