@@ -602,7 +602,7 @@ __device__ __forceinline__ void wave_lds_fence() {
 // argmax_k(delta_t[k] + T[t][j][k]) of stored rows, which viterbi_bp_kernel evaluates for every t
 // in parallel instead of on the sequential path).  The two are separate launches on separate
 // streams (each keeps its own register budget).
-template <int SS, int NSET, int SB, int ROLE, bool HOIST>
+template <int SS, int NSET, int SB, int ROLE, int HB>
 __global__ void __launch_bounds__(64)
 forward_wave_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *__restrict__ chroms,
                     const int32_t *__restrict__ order, const double *__restrict__ tprob, const double *__restrict__ pprob,
@@ -685,28 +685,37 @@ forward_wave_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *__
             prefetch(o, pn, pe_n);
 #pragma unroll
             for (int b = 0; b < SB; ++b) {
-                // HOIST: every broadcast read goes out before the products (a compiler left alone
-                // keeps ~4 in flight); it costs SS registers, so only where the sets leave room
-                double2 yv_r[HOIST ? SS / 2 : 1];
+                // HB > 0: the broadcast reads go out HB at a time before the products that use them
+                // (a compiler left alone keeps ~4 in flight and the step becomes a chain of LDS
+                // latencies); a batch costs 4*HB registers, so HB is sized to what the sets leave
+                constexpr int NV = SS / 2, BATCH = HB > 0 ? HB : NV;
                 const double2 *yv = reinterpret_cast<const double2 *>(buf[b][cur]);
-                if constexpr (HOIST) {
-                    read_vec<SS>(buf[b][cur], yv_r);
-                    yv = yv_r;
-                }
                 double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0, z0 = 0.0, z1 = 0.0, z2 = 0.0, z3 = 0.0;
 #pragma unroll
-                for (int m = 0; m < SS / 2; ++m) {
-                    const double2 v = yv[m];
-                    if (m & 1) {
-                        s2 = fma(v.x, pc[2 * m], s2);
-                        s3 = fma(v.y, pc[2 * m + 1], s3);
-                        z2 += v.x;
-                        z3 += v.y;
-                    } else {
-                        s0 = fma(v.x, pc[2 * m], s0);
-                        s1 = fma(v.y, pc[2 * m + 1], s1);
-                        z0 += v.x;
-                        z1 += v.y;
+                for (int mb = 0; mb < NV; mb += BATCH) {
+                    double2 yv_r[BATCH];
+                    if constexpr (HB > 0) {
+#pragma unroll
+                        for (int q = 0; q < BATCH; ++q)
+                            if (mb + q < NV) yv_r[q] = yv[mb + q];
+                        asm volatile("" ::: "memory");
+                    }
+#pragma unroll
+                    for (int q = 0; q < BATCH; ++q) {
+                        const int m = mb + q;
+                        if (m >= NV) break;
+                        const double2 v = HB > 0 ? yv_r[q] : yv[m];
+                        if (m & 1) {
+                            s2 = fma(v.x, pc[2 * m], s2);
+                            s3 = fma(v.y, pc[2 * m + 1], s3);
+                            z2 += v.x;
+                            z3 += v.y;
+                        } else {
+                            s0 = fma(v.x, pc[2 * m], s0);
+                            s1 = fma(v.y, pc[2 * m + 1], s1);
+                            z0 += v.x;
+                            z1 += v.y;
+                        }
                     }
                 }
                 const double inv_z = finish(b, i - 1, (z0 + z1) + (z2 + z3));
@@ -757,29 +766,28 @@ forward_wave_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *__
         prefetch(o, tn, e_n);
 #pragma unroll
         for (int b = 0; b < SB; ++b) {
-            double2 dp_r[HOIST ? SS / 2 : 1];
+            constexpr int NV = SS / 2, BATCH = HB > 0 ? HB : NV;
             const double2 *dp = reinterpret_cast<const double2 *>(buf[b][cur]);
-            if constexpr (HOIST) {
-                read_vec<SS>(buf[b][cur], dp_r);
-                dp = dp_r;
-            }
-            double m0, m1, m2, m3;
-            {
-                const double2 v0 = dp[0], v1 = dp[1];
-                m0 = v0.x + tc[0];
-                m1 = v0.y + tc[1];
-                m2 = v1.x + tc[2];
-                m3 = v1.y + tc[3];
-            }
+            double m0 = 0.0, m1 = 0.0, m2 = 0.0, m3 = 0.0;
 #pragma unroll
-            for (int m = 2; m < SS / 2; ++m) {
-                const double2 v = dp[m];
-                if (m & 1) {
-                    m2 = fmax(m2, v.x + tc[2 * m]);
-                    m3 = fmax(m3, v.y + tc[2 * m + 1]);
-                } else {
-                    m0 = fmax(m0, v.x + tc[2 * m]);
-                    m1 = fmax(m1, v.y + tc[2 * m + 1]);
+            for (int mb = 0; mb < NV; mb += BATCH) {
+                double2 dp_r[BATCH];
+                if constexpr (HB > 0) {
+#pragma unroll
+                    for (int q = 0; q < BATCH; ++q)
+                        if (mb + q < NV) dp_r[q] = dp[mb + q];
+                    asm volatile("" ::: "memory");
+                }
+#pragma unroll
+                for (int q = 0; q < BATCH; ++q) {
+                    const int m = mb + q;
+                    if (m >= NV) break;
+                    const double2 v = HB > 0 ? dp_r[q] : dp[m];
+                    const double a = v.x + tc[2 * m], c = v.y + tc[2 * m + 1];
+                    if (m == 0) { m0 = a; m1 = c; }
+                    else if (m == 1) { m2 = a; m3 = c; }
+                    else if (m & 1) { m2 = fmax(m2, a); m3 = fmax(m3, c); }
+                    else { m0 = fmax(m0, a); m1 = fmax(m1, c); }
                 }
             }
             const double d = fmax(fmax(m0, m1), fmax(m2, m3)) + e_now[b];
@@ -1202,10 +1210,10 @@ int hmm_alloc_samples(gbrs_hmm *h, int n_samples) {
 #define HMM_NSET 3        // register sets of the one-sample-per-wave recursions
 #endif
 #ifndef HMM_HOIST_A
-#define HMM_HOIST_A true    // hoisted LDS reads in the one-sample alpha / delta recursions
+#define HMM_HOIST_A 18      // LDS reads (double2) hoisted per batch in the one-sample alpha / delta recursions
 #endif
 #ifndef HMM_HOIST_D
-#define HMM_HOIST_D true
+#define HMM_HOIST_D 18
 #endif
 #ifndef HMM_SB
 #define HMM_SB 4          // samples per wave once n_samples >= HMM_SB
@@ -1264,8 +1272,8 @@ int hmm_launch(gbrs_hmm *h) {
             const bool spread = env ? std::atoi(env) != 0 : true;
             if (!batched && spread && (int64_t)3 * h->n_chrom * h->n_samples <= h->num_cus) pad = 81 * 1024;
         }
-        auto k_alpha = batched ? &forward_wave_kernel<SS, HMM_NSET_B, HMM_SB, 0, true> : &forward_wave_kernel<SS, HMM_NSET, 1, 0, HMM_HOIST_A>;
-        auto k_delta = batched ? &forward_wave_kernel<SS, HMM_NSET_B, HMM_SB, 1, true> : &forward_wave_kernel<SS, HMM_NSET, 1, 1, HMM_HOIST_D>;
+        auto k_alpha = batched ? &forward_wave_kernel<SS, HMM_NSET_B, HMM_SB, 0, 18> : &forward_wave_kernel<SS, HMM_NSET, 1, 0, HMM_HOIST_A>;
+        auto k_delta = batched ? &forward_wave_kernel<SS, HMM_NSET_B, HMM_SB, 1, 18> : &forward_wave_kernel<SS, HMM_NSET, 1, 1, HMM_HOIST_D>;
         auto k_back = batched ? &backward_wave_kernel<SS, HMM_NSET_B, HMM_SB> : &backward_wave_kernel<SS, HMM_NSET, 1>;
         if (pad) {
             GBRS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_alpha),
