@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--hmm-samples", type=int, default=1)
     ap.add_argument("--hmm-batch", type=int, default=64, help="second HMM measurement with this many samples in one launch (0 = skip)")
     ap.add_argument("--hmm-reps", type=int, default=5)
+    ap.add_argument("--hmm-haps", type=int, default=8, help="founder haplotypes of the HMM measurement (16 = config 5's 136 states)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo only to rehearse N>1 on one GPU)")
     return ap.parse_args()
 
@@ -179,10 +180,11 @@ def hmm_bench(args, torch, ns=None, with_cpu=True):
     import numpy as np
     from gbrs_amd import synth
     from gbrs_amd.hmm import DiplotypeHMM
-    prob = synth.make_hmm_problem(H=8)
+    HH = args.hmm_haps
+    prob = synth.make_hmm_problem(H=HH)
     chroms = prob.chroms
     ns = args.hmm_samples if ns is None else ns
-    hmm = DiplotypeHMM(8, chroms, [len(prob.gene_ids[c]) for c in chroms], [prob.tprob[c] for c in chroms],
+    hmm = DiplotypeHMM(HH, chroms, [len(prob.gene_ids[c]) for c in chroms], [prob.tprob[c] for c in chroms],
                        device=torch.cuda.current_device())
     rng = np.random.default_rng(1)
     ex, av, ha = [], [], []
@@ -194,7 +196,7 @@ def hmm_bench(args, torch, ns=None, with_cpu=True):
                                 for _ in range(ns - 1)])
         ex.append(e)
         ha.append(np.array([g in prob.avecs for g in ids], dtype=np.uint8))
-        av.append(np.array([prob.avecs.get(g, np.zeros((8, 8))) for g in ids]))
+        av.append(np.array([prob.avecs.get(g, np.zeros((HH, HH))) for g in ids]))
     hmm.set_expression(ex, av, ha, 1.5, 0.12)
     hmm.run()
     emis, tot = [], []
@@ -209,7 +211,7 @@ def hmm_bench(args, torch, ns=None, with_cpu=True):
     units = prob.num_genes * ns
     out = dict(metric="HMM gene x sample /s (emission+forward+backward+posterior+Viterbi)",
                value=units / (ms * 1e-3), unit="genes/s", ms_per_pass=ms, n_samples=ns,
-               genes=prob.num_genes, states=36,
+               genes=prob.num_genes, states=HH * (HH + 1) // 2,
                kernels_ms=dict(emission=inf.last_emission_ms, forward_viterbi=inf.last_forward_ms,
                                backward_posterior=inf.last_backward_ms, backtrace=inf.last_backtrace_ms,
                                run=inf.last_run_ms,

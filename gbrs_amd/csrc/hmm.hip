@@ -13,6 +13,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdlib>
+#include <functional>
 
 namespace gbrs {
 
@@ -244,6 +245,30 @@ __global__ void exp_blocks_kernel(int S, int64_t n_blocks, const double *__restr
         const double v = exp(t[x]);
         p[x] = v;
         pt[b * S * S + (int64_t)kk * S + jj] = v;
+    }
+}
+
+// The quad chains (S = 4*KMAX) read their tables in lane order: double2 number m2 of lane
+// t = 4*j + q (state j, row quarter q) sits at double offset (m2*4S + t)*2 of the block, so one
+// wave-instruction reads 1 KiB contiguously instead of 64 pieces of 64 different rows (at S = 136
+// a step streams 148 KB; row-strided lanes ran it at a seventh of this).  p_q = exp(T), pt_q =
+// exp(T) transposed, t_q = T, all in that order.
+__global__ void quad_blocks_kernel(int S, int KMAX, int64_t n_blocks, const double *__restrict__ t,
+                                   double *__restrict__ p_q, double *__restrict__ pt_q,
+                                   double *__restrict__ t_q) {
+    const int64_t bs = (int64_t)S * S, total = n_blocks * bs;
+    for (int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; x < total;
+         x += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = x / bs;
+        const int within = (int)(x - b * bs);
+        const int m2 = within / (8 * S), rem = within % (8 * S);
+        const int tl = rem / 2, e = rem % 2;
+        const int jj = tl / 4, q = tl % 4;
+        const int kk = q * KMAX + 2 * m2 + e;
+        const double v = t[b * bs + (int64_t)jj * S + kk];
+        t_q[x] = v;
+        p_q[x] = exp(v);
+        pt_q[x] = exp(t[b * bs + (int64_t)kk * S + jj]);
     }
 }
 
@@ -581,6 +606,19 @@ __device__ __forceinline__ void read_vec(const double *lds_vec, double2 (&v)[SS 
     asm volatile("" ::: "memory");
 }
 
+// In-place refill of a register set: the reload of element m must issue after the product that
+// consumed the old element m (otherwise old and new values are live together and the set costs
+// twice its registers; the scheduler hoists independent loads to the top of the step).  The empty
+// asm makes the load's per-lane offset formally depend on that product.
+__device__ __forceinline__ void pin_after(unsigned &lane_off, double consumed) {
+    asm volatile("" : "+v"(lane_off) : "v"(consumed));
+}
+// uniform base (SGPR pair) + 32-bit unsigned lane offset: the saddr form of global_load, no per-load
+// 64-bit address arithmetic
+__device__ __forceinline__ double2 load_pinned(const char *uniform_base, unsigned lane_off_bytes) {
+    return *reinterpret_cast<const double2 *>(uniform_base + lane_off_bytes);
+}
+
 // orders this wave's LDS writes before its later LDS reads for the compiler; the hardware keeps
 // one wave's DS instructions in order
 __device__ __forceinline__ void wave_lds_fence() {
@@ -816,6 +854,180 @@ forward_wave_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *__
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// The same three chains for state counts beyond one wave (S = 4*KMAX, KMAX even; S = 136 for 16
+// founders): 4 adjacent lanes per state, each holding a contiguous quarter of the state's
+// transition row in registers (KMAX doubles), quad sums / maxima on DPP, the vector double
+// buffered in LDS with one LDS-only barrier per step.  A step moves 8*S*S bytes (148 KB at
+// S = 136) through one CU, ~1-2 us, so one step of lead (two register sets) hides the HBM miss.
+// ROLE 0 = alpha (Z from the lanes' own quarter sums + quad sum), 1 = delta values, 2 = free-running
+// backward (see backward_wave_kernel).  Padding lanes shadow the last state and never store.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double quad_max(double v) {
+    v = fmax(v, dpp_f64<DPP_QUAD_XOR1>(v));
+    v = fmax(v, dpp_f64<DPP_QUAD_XOR2>(v));
+    return v;
+}
+
+template <int KMAX, int ROLE>
+__global__ void __launch_bounds__(((KMAX * 16 + 63) / 64) * 64)
+quad_chain_kernel(int64_t genes_per_sample, const ChromDesc *__restrict__ chroms,
+                  const int32_t *__restrict__ order, const double *__restrict__ blocks,
+                  const double *__restrict__ em, const double *__restrict__ eprob,
+                  const double *__restrict__ init_vec, double *__restrict__ out_vec /* xsum | delta | bhat */,
+                  double *__restrict__ ahat, double *__restrict__ scal /* invz | - | bscale */,
+                  int32_t *__restrict__ last_state) {
+    static_assert(KMAX % 2 == 0, "16-byte aligned row quarters");
+    constexpr int S = 4 * KMAX, NSET = 1, NV = KMAX / 2;   // one register set refilled in place: one step of lead
+    __shared__ __attribute__((aligned(16))) double buf[2][S];
+    const int chrom = order[blockIdx.y];
+    const ChromDesc cd = chroms[chrom];
+    const int sample = blockIdx.x;
+    const int n = cd.n_genes;
+    if (n <= 0) return;
+    const int j = threadIdx.x / 4, q = threadIdx.x % 4;
+    const bool valid = j < S;
+    const int jr = valid ? j : S - 1;
+    const bool owner = valid && q == 0;
+    const int64_t g0 = (int64_t)sample * genes_per_sample + cd.gene_off;
+    // tables in lane order (quad_blocks_kernel): double2 m of this lane at byte (m*4S + lane)*16
+    const double *BLK0 = blocks + cd.trans_off * (int64_t)S * S;
+    unsigned row_off = min((int)threadIdx.x, 4 * S - 1) * 16;
+    constexpr int M_STRIDE = 4 * S * 16;
+    // order o: forward roles step i = o + 1 on block o; backward gene i = n-2-o on block i
+    const int n_ord = ROLE == 2 ? n - 1 : min(n, cd.n_trans + 1) - 1;
+    const int last_o = max(n_ord - 1, 0);
+    auto blk_of = [&](int o) { return ROLE == 2 ? n - 2 - o : o; };
+    auto em_of = [&](int o) { return ROLE == 2 ? n - 2 - o : o + 1; };
+    double pr[NSET][KMAX], em_r[NSET];
+#pragma unroll
+    for (int u = 0; u < NSET; ++u) {
+        const int ou = min(u, last_o);
+        if (n_ord > 0) {
+            const char *src = reinterpret_cast<const char *>(BLK0 + (int64_t)HMM_BLK(blk_of(ou)) * S * S) + row_off;
+#pragma unroll
+            for (int m = 0; m < NV; ++m) {
+                const double2 g = *reinterpret_cast<const double2 *>(src + (size_t)m * M_STRIDE);
+                pr[u][2 * m] = g.x;
+                pr[u][2 * m + 1] = g.y;
+            }
+        } else {
+#pragma unroll
+            for (int m = 0; m < KMAX; ++m) pr[u][m] = 0.0;
+        }
+        em_r[u] = n_ord > 0 ? em[(g0 + em_of(ou)) * S + jr] : 0.0;
+    }
+    int cur = 0;
+    double own = 0.0;                               // this state's current vector entry
+    if (ROLE == 0) {
+        own = exp(init_vec[jr] + eprob[g0 * S + jr]);
+        if (owner) out_vec[g0 * S + j] = exp(init_vec[j]);          // so that log(x) + e reproduces init + e
+    } else if (ROLE == 1) {
+        own = init_vec[jr] + em[g0 * S + jr];
+        if (owner) out_vec[g0 * S + j] = own;
+    } else {
+        own = em[(g0 + n - 1) * S + jr];           // pe_{n-1} * bt_{n-1}, bt_{n-1} = 1
+        if (owner) {
+            out_vec[(g0 + n - 1) * S + j] = 1.0;
+            if (j == 0) scal[g0 + n - 1] = 1.0;
+        }
+    }
+    if (owner) buf[0][j] = own;
+    __syncthreads();
+    auto alpha_finish = [&](int i_prev, double z) {
+        const double inv_z = fast_recip_pos(z);
+        if (owner) {
+            ahat[(g0 + i_prev) * S + j] = own * inv_z;
+            if (j == 0) scal[g0 + i_prev] = inv_z;
+        }
+        return inv_z;
+    };
+    auto step = [&](int o, bool rescale, double (&pc)[KMAX], double &e_slot) {
+        const double e = e_slot;
+        const int of = min(o + NSET, last_o);
+        e_slot = em[(g0 + em_of(of)) * S + jr];
+        const double *nblk = BLK0 + (int64_t)HMM_BLK(blk_of(of)) * S * S;
+        const double2 *src = reinterpret_cast<const double2 *>(buf[cur] + q * KMAX);
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, z0 = 0.0, z1 = 0.0;
+        // LDS reads go out in batches sized to the register budget (9 waves per workgroup: 168)
+#ifndef HMM_QUAD_HB
+#define HMM_QUAD_HB 1
+#endif
+        constexpr int HBQ = ROLE == 1 ? (NV + 1) / 2 : HMM_QUAD_HB;
+#pragma unroll
+        for (int mb = 0; mb < NV; mb += HBQ) {
+            double2 v[HBQ];
+#pragma unroll
+            for (int t = 0; t < HBQ; ++t)
+                if (mb + t < NV) v[t] = src[mb + t];
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int t = 0; t < HBQ; ++t) {
+                const int m = mb + t;
+                if (m >= NV) break;
+                if (ROLE == 1) {
+                    const double x = v[t].x + pc[2 * m], y = v[t].y + pc[2 * m + 1];
+                    if (m == 0) { a0 = x; a1 = y; }
+                    else if (m == 1) { a2 = x; a3 = y; }
+                    else if (m & 1) { a2 = fmax(a2, x); a3 = fmax(a3, y); }
+                    else { a0 = fmax(a0, x); a1 = fmax(a1, y); }
+                } else {
+                    if (m & 1) { a2 = fma(v[t].x, pc[2 * m], a2); a3 = fma(v[t].y, pc[2 * m + 1], a3); }
+                    else { a0 = fma(v[t].x, pc[2 * m], a0); a1 = fma(v[t].y, pc[2 * m + 1], a1); }
+                    if (ROLE == 0 || rescale) {
+                        if (m & 1) z1 += v[t].x + v[t].y; else z0 += v[t].x + v[t].y;
+                    }
+                }
+                pin_after(row_off, (m & 1) ? a3 : a1);          // in-place refill: see forward_wave_kernel
+                const double2 g = load_pinned(reinterpret_cast<const char *>(nblk) + (size_t)m * M_STRIDE, row_off);
+                pc[2 * m] = g.x;
+                pc[2 * m + 1] = g.y;
+            }
+        }
+        const int i = ROLE == 2 ? n - 2 - o : o + 1;
+        if (ROLE == 0) {
+            const double inv_z = alpha_finish(i - 1, quad_sum(z0 + z1));
+            const double x = quad_sum((a0 + a1) + (a2 + a3)) * inv_z + TINY;
+            own = x * e;
+            if (owner) out_vec[(g0 + i) * S + j] = x;
+        } else if (ROLE == 1) {
+            own = quad_max(fmax(fmax(a0, a1), fmax(a2, a3))) + e;
+            if (owner) out_vec[(g0 + i) * S + j] = own;
+        } else {
+            const double r = rescale ? fast_recip_pos(quad_sum(z0 + z1)) : 1.0;
+            const double bh = quad_sum((a0 + a1) + (a2 + a3)) * r;
+            own = bh * e;
+            if (owner) {
+                out_vec[(g0 + i) * S + j] = bh;
+                if (j == 0) scal[g0 + i] = r;
+            }
+        }
+        if (owner) buf[cur ^ 1][j] = own;
+        cur ^= 1;
+        lds_barrier();
+    };
+    int o = 0;
+    for (; o < n_ord; ++o) step(o, true, pr[0], em_r[0]);    // backward: rescale every step (one loop body)
+    if (ROLE == 0) {
+        const double2 *src = reinterpret_cast<const double2 *>(buf[cur] + q * KMAX);
+        double z0 = 0.0, z1 = 0.0;
+#pragma unroll
+        for (int m = 0; m < NV; ++m) {
+            const double2 v = src[m];
+            if (m & 1) z1 += v.x + v.y; else z0 += v.x + v.y;
+        }
+        alpha_finish(n_ord, quad_sum(z0 + z1));
+    }
+    if (ROLE == 1 && threadIdx.x == 0) {       // sid = argmax delta[:, n-1] (first max)
+        const double *dl = buf[cur];
+        double bv = dl[0];
+        int bk = 0;
+        for (int t = 1; t < S; ++t)
+            if (dl[t] > bv) { bv = dl[t]; bk = t; }
+        last_state[(int64_t)sample * gridDim.y + chrom] = bk;
+    }
+}
+
 // Backpointers bp[t][j] = argmax_k(delta_t[k] + T[t][j][k]) (first max, np.argmax) for
 // t < min(n, n_trans): the quantity the reference's backtrace recomputes along the path
 // (gbrs_utils.py:594), including the row of T[n-1] when len(tprob) >= n.  One workgroup per
@@ -847,6 +1059,50 @@ viterbi_bp_kernel(int S, int n_samples, int64_t genes_per_sample, int64_t bp_per
             if (dv > best) { best = dv; best_k = k; }
         }
         bp[((int64_t)sample * bp_per_sample + cd.bp_off + t) * S + j] = (uint16_t)best_k;
+    }
+}
+
+// Backpointers for the quad chains: same result as viterbi_bp_kernel, but the block comes straight
+// from the lane-ordered table (coalesced, no 148 KB LDS image) into registers and is reused for
+// every sample; 4 lanes per state, quad argmax with np.argmax's first-max rule.
+template <int KMAX>
+__global__ void __launch_bounds__(((KMAX * 16 + 63) / 64) * 64)
+viterbi_bp_quad_kernel(int n_samples, int64_t genes_per_sample, int64_t bp_per_sample,
+                       const ChromDesc *__restrict__ chroms, const double *__restrict__ tprob_q,
+                       const double *__restrict__ delta, uint16_t *__restrict__ bp) {
+    constexpr int S = 4 * KMAX, NV = KMAX / 2, M_STRIDE = 4 * S * 16;
+    __shared__ __attribute__((aligned(16))) double drow[S];
+    const ChromDesc cd = chroms[blockIdx.y];
+    const int t = blockIdx.x;
+    if (t >= min(cd.n_genes, cd.n_trans)) return;
+    const int j = threadIdx.x / 4, q = threadIdx.x % 4;
+    const bool owner = j < S && q == 0;
+    const char *src = reinterpret_cast<const char *>(tprob_q + (cd.trans_off + t) * (int64_t)S * S) +
+                      min((int)threadIdx.x, 4 * S - 1) * 16;
+    double tr[KMAX];
+#pragma unroll
+    for (int m = 0; m < NV; ++m) {
+        const double2 g = *reinterpret_cast<const double2 *>(src + (size_t)m * M_STRIDE);
+        tr[2 * m] = g.x;
+        tr[2 * m + 1] = g.y;
+    }
+    for (int sample = 0; sample < n_samples; ++sample) {
+        const double *d = delta + ((int64_t)sample * genes_per_sample + cd.gene_off + t) * S;
+        __syncthreads();
+        for (int x = threadIdx.x; x < S; x += blockDim.x) drow[x] = d[x];
+        __syncthreads();
+        const double2 *dv = reinterpret_cast<const double2 *>(drow + q * KMAX);
+        double best = -DBL_MAX;
+        int best_k = 0x7fffffff;
+#pragma unroll
+        for (int m = 0; m < NV; ++m) {
+            const double2 v = dv[m];
+            const double x = v.x + tr[2 * m], y = v.y + tr[2 * m + 1];
+            if (x > best) { best = x; best_k = q * KMAX + 2 * m; }          // ascending k: first max kept
+            if (y > best) { best = y; best_k = q * KMAX + 2 * m + 1; }
+        }
+        quad_argmax(best, best_k);
+        if (owner) bp[((int64_t)sample * bp_per_sample + cd.bp_off + t) * S + j] = (uint16_t)best_k;
     }
 }
 
@@ -1171,6 +1427,8 @@ struct gbrs_hmm {
     DevBuf<ChromDesc> d_chroms;
     DevBuf<int32_t> d_order;                  // chromosome indices, longest first
     DevBuf<double> tprob, pprob, pprob_t, init_vec;   // log T, exp(T), exp(T) transposed per block
+    DevBuf<double> tprob_q;                   // S = 136: log T in the quad chains' lane order (pprob, pprob_t too)
+    bool quad = false;
     DevBuf<double> expr, avecs, eprob, peprob, xsum, bhat, alpha, ahat, beta, gamma, delta, scaler, invz;
     DevBuf<double> bscale, bcorr;             // free-running backward: per-gene scale and log correction
     DevBuf<uint8_t> has_avec;
@@ -1249,60 +1507,97 @@ int hmm_launch(gbrs_hmm *h) {
 #else
     constexpr bool WAVE = EXACT && KMAX * 4 <= 64;    // S = 36: the single-wave recursions
 #endif
+    constexpr bool QUAD = EXACT && KMAX * 4 > 64 && KMAX % 2 == 0;   // S = 136: the quad chains (tables in lane order)
     GBRS_HIP_CHECK(hipEventRecord(h->ev[1], sa));
     hipLaunchKernelGGL(exp_emission_kernel, dim3((unsigned)((rows * S + 255) / 256)), dim3(256), 0, sa,
                        rows * S, h->eprob.p, h->peprob.p);
-    if constexpr (WAVE) {
+    if constexpr (WAVE || QUAD) {
         // Three independent chains from here, each on its own stream (a sample's 40 chromosomes
         // occupy 40 CUs per chain):  A  alpha -> [join B] beta correction + outputs
         //                            B  free-running backward
         //                            C  delta -> backpointers -> backtrace
-        constexpr int SS = KMAX * 4;
-        // Few samples: one sample per wave and a 3-deep prefetch ring (latency).  Many samples:
-        // HMM_SB samples share each wave's transition registers and 2 sets suffice (throughput:
-        // a quarter of the block loads per sample and two waves per SIMD).
-        const bool batched = h->n_samples >= HMM_SB;
-        const dim3 wave_grid(batched ? (h->n_samples + HMM_SB - 1) / HMM_SB : h->n_samples, h->n_chrom);
-        // While every chain's wave can have a CU of its own, ask for more than half a CU's LDS per
-        // workgroup: the dispatcher then cannot stack two of these single-wave workgroups on one
-        // CU (where they would share a SIMD's issue slots) while other CUs sit idle.
-        size_t pad = 0;
-        {
-            const char *env = std::getenv("GBRS_TUNING_HMM_SPREAD");
-            const bool spread = env ? std::atoi(env) != 0 : true;
-            if (!batched && spread && (int64_t)3 * h->n_chrom * h->n_samples <= h->num_cus) pad = 81 * 1024;
+        std::function<void(hipStream_t)> launch_alpha, launch_back, launch_delta;
+        if constexpr (WAVE) {
+            constexpr int SS = KMAX * 4;
+            // Few samples: one sample per wave and a 3-deep prefetch ring (latency).  Many samples:
+            // HMM_SB samples share each wave's transition registers and 2 sets suffice (throughput:
+            // a quarter of the block loads per sample and two waves per SIMD).
+            const bool batched = h->n_samples >= HMM_SB;
+            const dim3 wave_grid(batched ? (h->n_samples + HMM_SB - 1) / HMM_SB : h->n_samples, h->n_chrom);
+            // While every chain's wave can have a CU of its own, ask for more than half a CU's LDS per
+            // workgroup: the dispatcher then cannot stack two of these single-wave workgroups on one
+            // CU (where they would share a SIMD's issue slots) while other CUs sit idle.
+            size_t pad = 0;
+            {
+                const char *env = std::getenv("GBRS_TUNING_HMM_SPREAD");
+                const bool spread = env ? std::atoi(env) != 0 : true;
+                if (!batched && spread && (int64_t)3 * h->n_chrom * h->n_samples <= h->num_cus) pad = 81 * 1024;
+            }
+            auto k_alpha = batched ? &forward_wave_kernel<SS, HMM_NSET_B, HMM_SB, 0, 18> : &forward_wave_kernel<SS, HMM_NSET, 1, 0, HMM_HOIST_A>;
+            auto k_delta = batched ? &forward_wave_kernel<SS, HMM_NSET_B, HMM_SB, 1, 18> : &forward_wave_kernel<SS, HMM_NSET, 1, 1, HMM_HOIST_D>;
+            auto k_back = batched ? &backward_wave_kernel<SS, HMM_NSET_B, HMM_SB> : &backward_wave_kernel<SS, HMM_NSET, 1>;
+            if (pad) {
+                GBRS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_alpha),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad));
+                GBRS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_delta),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad));
+                GBRS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_back),
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad));
+            }
+            launch_alpha = [=](hipStream_t st) {
+                hipLaunchKernelGGL(k_alpha, wave_grid, dim3(64), pad, st, h->n_samples, h->total_genes,
+                                   h->d_chroms.p, h->d_order.p, h->tprob.p, h->pprob.p, h->eprob.p, h->peprob.p,
+                                   h->init_vec.p, h->xsum.p, h->ahat.p, h->invz.p, h->delta.p, h->last_state.p);
+            };
+            launch_back = [=](hipStream_t st) {
+                hipLaunchKernelGGL(k_back, wave_grid, dim3(64), pad, st, h->n_samples, h->total_genes,
+                                   h->d_chroms.p, h->d_order.p, h->pprob_t.p, h->peprob.p, h->bhat.p, h->bscale.p);
+            };
+            launch_delta = [=](hipStream_t st) {
+                hipLaunchKernelGGL(k_delta, wave_grid, dim3(64), pad, st, h->n_samples, h->total_genes,
+                                   h->d_chroms.p, h->d_order.p, h->tprob.p, h->pprob.p, h->eprob.p, h->peprob.p,
+                                   h->init_vec.p, h->xsum.p, h->ahat.p, h->invz.p, h->delta.p, h->last_state.p);
+            };
+        } else {
+            const dim3 quad_grid(h->n_samples, h->n_chrom), quad_block(threads);
+            launch_alpha = [=](hipStream_t st) {
+                hipLaunchKernelGGL((quad_chain_kernel<KMAX, 0>), quad_grid, quad_block, 0, st, h->total_genes,
+                                   h->d_chroms.p, h->d_order.p, h->pprob.p, h->peprob.p, h->eprob.p, h->init_vec.p,
+                                   h->xsum.p, h->ahat.p, h->invz.p, h->last_state.p);
+            };
+            launch_back = [=](hipStream_t st) {
+                hipLaunchKernelGGL((quad_chain_kernel<KMAX, 2>), quad_grid, quad_block, 0, st, h->total_genes,
+                                   h->d_chroms.p, h->d_order.p, h->pprob_t.p, h->peprob.p, h->eprob.p, h->init_vec.p,
+                                   h->bhat.p, h->ahat.p, h->bscale.p, h->last_state.p);
+            };
+            launch_delta = [=](hipStream_t st) {
+                hipLaunchKernelGGL((quad_chain_kernel<KMAX, 1>), quad_grid, quad_block, 0, st, h->total_genes,
+                                   h->d_chroms.p, h->d_order.p, h->tprob_q.p, h->eprob.p, h->eprob.p, h->init_vec.p,
+                                   h->delta.p, h->ahat.p, h->invz.p, h->last_state.p);
+            };
         }
-        auto k_alpha = batched ? &forward_wave_kernel<SS, HMM_NSET_B, HMM_SB, 0, 18> : &forward_wave_kernel<SS, HMM_NSET, 1, 0, HMM_HOIST_A>;
-        auto k_delta = batched ? &forward_wave_kernel<SS, HMM_NSET_B, HMM_SB, 1, 18> : &forward_wave_kernel<SS, HMM_NSET, 1, 1, HMM_HOIST_D>;
-        auto k_back = batched ? &backward_wave_kernel<SS, HMM_NSET_B, HMM_SB> : &backward_wave_kernel<SS, HMM_NSET, 1>;
-        if (pad) {
-            GBRS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_alpha),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad));
-            GBRS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_delta),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad));
-            GBRS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_back),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad));
-        }
+        const size_t bp_lds = (size_t)S * (S + 1) * sizeof(double);
         GBRS_HIP_CHECK(hipEventRecord(h->ev_fork, sa));
         GBRS_HIP_CHECK(hipStreamWaitEvent(sb, h->ev_fork, 0));
         GBRS_HIP_CHECK(hipStreamWaitEvent(sc, h->ev_fork, 0));
-        hipLaunchKernelGGL(k_alpha, wave_grid, dim3(64), pad, sa, h->n_samples, h->total_genes,
-                           h->d_chroms.p, h->d_order.p, h->tprob.p, h->pprob.p, h->eprob.p, h->peprob.p,
-                           h->init_vec.p, h->xsum.p, h->ahat.p, h->invz.p, h->delta.p, h->last_state.p);
+        launch_alpha(sa);
         hipLaunchKernelGGL(hmm_outputs_kernel, out_grid, out_block, out_lds, sa, S, out_rows, rows, 1, h->eprob.p,
                            h->xsum.p, h->ahat.p, h->invz.p, h->bhat.p, h->bcorr.p, h->alpha.p, h->scaler.p,
                            h->beta.p, h->gamma.p);
         GBRS_HIP_CHECK(hipEventRecord(h->ev[2], sa));
-        hipLaunchKernelGGL(k_back, wave_grid, dim3(64), pad, sb, h->n_samples, h->total_genes,
-                           h->d_chroms.p, h->d_order.p, h->pprob_t.p, h->peprob.p, h->bhat.p, h->bscale.p);
+        launch_back(sb);
         GBRS_HIP_CHECK(hipEventRecord(h->ev_b, sb));
-        hipLaunchKernelGGL(k_delta, wave_grid, dim3(64), pad, sc, h->n_samples, h->total_genes,
-                           h->d_chroms.p, h->d_order.p, h->tprob.p, h->pprob.p, h->eprob.p, h->peprob.p,
-                           h->init_vec.p, h->xsum.p, h->ahat.p, h->invz.p, h->delta.p, h->last_state.p);
-        if (h->max_bp_rows > 0)
-            hipLaunchKernelGGL(viterbi_bp_kernel, dim3(h->max_bp_rows, h->n_chrom), dim3(256),
-                               (size_t)S * (S + 1) * sizeof(double), sc, S, h->n_samples, h->total_genes,
-                               h->total_bp, h->d_chroms.p, h->tprob.p, h->delta.p, h->bp.p);
+        launch_delta(sc);
+        if (h->max_bp_rows > 0) {
+            if constexpr (QUAD)
+                hipLaunchKernelGGL((viterbi_bp_quad_kernel<KMAX>), dim3(h->max_bp_rows, h->n_chrom), dim3(threads), 0,
+                                   sc, h->n_samples, h->total_genes, h->total_bp, h->d_chroms.p, h->tprob_q.p,
+                                   h->delta.p, h->bp.p);
+            else
+                hipLaunchKernelGGL(viterbi_bp_kernel, dim3(h->max_bp_rows, h->n_chrom), dim3(256),
+                                   bp_lds, sc, S, h->n_samples, h->total_genes,
+                                   h->total_bp, h->d_chroms.p, h->tprob.p, h->delta.p, h->bp.p);
+        }
         GBRS_HIP_CHECK(hipEventRecord(h->ev_c1, sc));
         launch_backtrace(sc);
         GBRS_HIP_CHECK(hipEventRecord(h->ev_c, sc));
@@ -1415,13 +1710,20 @@ int gbrs_hmm_create(int num_haps, int n_chrom, const int32_t *n_genes, const int
     GBRS_TRY(h->tprob.alloc(std::max<size_t>(h->total_trans * blk, 1)));
     GBRS_TRY(h->pprob.alloc(std::max<size_t>(h->total_trans * blk, 1)));
     GBRS_TRY(h->pprob_t.alloc(std::max<size_t>(h->total_trans * blk, 1)));
+    h->quad = S == 136;                            // the state count hmm_launch runs on the quad chains
+    if (h->quad) GBRS_TRY(h->tprob_q.alloc(std::max<size_t>(h->total_trans * blk, 1)));
     for (int c = 0; c < n_chrom; ++c)
         if (n_trans[c] > 0)
             GBRS_HIP_CHECK(hipMemcpy(h->tprob.p + h->chroms[c].trans_off * blk, tprob[c],
                                      (size_t)n_trans[c] * blk * sizeof(double), hipMemcpyHostToDevice));
-    if (h->total_trans > 0)
-        hipLaunchKernelGGL(exp_blocks_kernel, dim3(2048), dim3(256), 0, h->stream, S, h->total_trans,
-                           h->tprob.p, h->pprob.p, h->pprob_t.p);
+    if (h->total_trans > 0) {
+        if (h->quad)
+            hipLaunchKernelGGL(quad_blocks_kernel, dim3(4096), dim3(256), 0, h->stream, S, S / 4, h->total_trans,
+                               h->tprob.p, h->pprob.p, h->pprob_t.p, h->tprob_q.p);
+        else
+            hipLaunchKernelGGL(exp_blocks_kernel, dim3(2048), dim3(256), 0, h->stream, S, h->total_trans,
+                               h->tprob.p, h->pprob.p, h->pprob_t.p);
+    }
     // init_vec (gbrs_utils.py:465-471): log(1/H^2) homozygous, log(2/H^2) heterozygous
     std::vector<double> iv;
     for (int a = 0; a < num_haps; ++a)
