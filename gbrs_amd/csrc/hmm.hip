@@ -248,23 +248,25 @@ __global__ void exp_blocks_kernel(int S, int64_t n_blocks, const double *__restr
     }
 }
 
-// The quad chains (S = 4*KMAX) read their tables in lane order: double2 number m2 of lane
-// t = 4*j + q (state j, row quarter q) sits at double offset (m2*4S + t)*2 of the block, so one
-// wave-instruction reads 1 KiB contiguously instead of 64 pieces of 64 different rows (at S = 136
-// a step streams 148 KB; row-strided lanes ran it at a seventh of this).  p_q = exp(T), pt_q =
-// exp(T) transposed, t_q = T, all in that order.
-__global__ void quad_blocks_kernel(int S, int KMAX, int64_t n_blocks, const double *__restrict__ t,
+// The chain kernels read their tables in lane order: with LPS lanes per state (1 for the single-wave
+// kernels, 4 for the quad chains) and KPL = S / LPS columns per lane, double2 number m2 of lane
+// t = LPS*j + q (state j, row part q) sits at double offset (m2 * LPS*S + t) * 2 of the block, so one
+// wave-instruction reads a contiguous run (1 KiB for the quad chains) instead of one 16-byte piece
+// from each of up to 64 rows (at S = 136 a step streams 148 KB; row-strided lanes ran it at a
+// seventh of this).  p_q = exp(T), pt_q = exp(T) transposed, t_q = T, all in that order.
+__global__ void lane_blocks_kernel(int S, int LPS, int KPL, int64_t n_blocks, const double *__restrict__ t,
                                    double *__restrict__ p_q, double *__restrict__ pt_q,
                                    double *__restrict__ t_q) {
     const int64_t bs = (int64_t)S * S, total = n_blocks * bs;
+    const int lanes2 = 2 * LPS * S;
     for (int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; x < total;
          x += (int64_t)gridDim.x * blockDim.x) {
         const int64_t b = x / bs;
         const int within = (int)(x - b * bs);
-        const int m2 = within / (8 * S), rem = within % (8 * S);
+        const int m2 = within / lanes2, rem = within % lanes2;
         const int tl = rem / 2, e = rem % 2;
-        const int jj = tl / 4, q = tl % 4;
-        const int kk = q * KMAX + 2 * m2 + e;
+        const int jj = tl / LPS, q = tl % LPS;
+        const int kk = q * KPL + 2 * m2 + e;
         const double v = t[b * bs + (int64_t)jj * S + kk];
         t_q[x] = v;
         p_q[x] = exp(v);
@@ -619,6 +621,18 @@ __device__ __forceinline__ double2 load_pinned(const char *uniform_base, unsigne
     return *reinterpret_cast<const double2 *>(uniform_base + lane_off_bytes);
 }
 
+// lane j's row from a lane-ordered block (lane_blocks_kernel, LPS = 1): double2 m at (m*SS + j)*16 bytes
+template <int SS>
+__device__ __forceinline__ void load_lane(const double *__restrict__ block, int lane, double (&dst)[SS]) {
+    const char *src = reinterpret_cast<const char *>(block) + lane * 16;
+#pragma unroll
+    for (int m = 0; m < SS / 2; ++m) {
+        const double2 v = *reinterpret_cast<const double2 *>(src + m * (SS * 16));
+        dst[2 * m] = v.x;
+        dst[2 * m + 1] = v.y;
+    }
+}
+
 // orders this wave's LDS writes before its later LDS reads for the compiler; the hardware keeps
 // one wave's DS instructions in order
 __device__ __forceinline__ void wave_lds_fence() {
@@ -681,7 +695,7 @@ forward_wave_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *__
 #pragma unroll
     for (int u = 0; u < NSET; ++u) {
         const int ou = min(u, last_o);
-        if (any) load_row<SS>(BLK + ((int64_t)HMM_BLK(ou) * SS + jr) * SS, pr[u]);
+        if (any) load_lane<SS>(BLK + (int64_t)HMM_BLK(ou) * SS * SS, jr, pr[u]);
         else {
 #pragma unroll
             for (int m = 0; m < SS; ++m) pr[u][m] = 0.0;
@@ -691,7 +705,7 @@ forward_wave_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *__
     }
     auto prefetch = [&](int o, double (&pn)[SS], double (&em_n)[SB]) {
         const int of = min(o + NSET - 1, last_o);
-        load_row<SS>(BLK + ((int64_t)HMM_BLK(of) * SS + jr) * SS, pn);
+        load_lane<SS>(BLK + (int64_t)HMM_BLK(of) * SS * SS, jr, pn);
 #pragma unroll
         for (int b = 0; b < SB; ++b) em_n[b] = EM[(g0[b] + of + 1) * SS + jr];
     };
@@ -890,7 +904,7 @@ quad_chain_kernel(int64_t genes_per_sample, const ChromDesc *__restrict__ chroms
     const int jr = valid ? j : S - 1;
     const bool owner = valid && q == 0;
     const int64_t g0 = (int64_t)sample * genes_per_sample + cd.gene_off;
-    // tables in lane order (quad_blocks_kernel): double2 m of this lane at byte (m*4S + lane)*16
+    // tables in lane order (lane_blocks_kernel, LPS = 4): double2 m of this lane at byte (m*4S + lane)*16
     const double *BLK0 = blocks + cd.trans_off * (int64_t)S * S;
     unsigned row_off = min((int)threadIdx.x, 4 * S - 1) * 16;
     constexpr int M_STRIDE = 4 * S * 16;
@@ -1152,7 +1166,7 @@ backward_wave_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *_
 #pragma unroll
     for (int u = 0; u < NSET; ++u) {
         const int i = n - 2 - min(u, last_o);
-        if (n_ord > 0) load_row<SS>(Pt + ((int64_t)HMM_BLK(i) * SS + jr) * SS, tr[u]);
+        if (n_ord > 0) load_lane<SS>(Pt + (int64_t)HMM_BLK(i) * SS * SS, jr, tr[u]);
         else {
 #pragma unroll
             for (int m = 0; m < SS; ++m) tr[u][m] = 0.0;
@@ -1170,7 +1184,7 @@ backward_wave_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *_
         const int in = n - 2 - min(o + NSET - 1, last_o);     // clamped: see forward_wave_kernel
 #pragma unroll
         for (int b = 0; b < SB; ++b) pe_n[b] = peprob[(g0[b] + in) * SS + jr];
-        load_row<SS>(Pt + ((int64_t)HMM_BLK(in) * SS + jr) * SS, tn);
+        load_lane<SS>(Pt + (int64_t)HMM_BLK(in) * SS * SS, jr, tn);
 #pragma unroll
         for (int b = 0; b < SB; ++b) {
             // all broadcast reads of the vector go out first (a compiler left alone keeps ~4 in
@@ -1427,8 +1441,8 @@ struct gbrs_hmm {
     DevBuf<ChromDesc> d_chroms;
     DevBuf<int32_t> d_order;                  // chromosome indices, longest first
     DevBuf<double> tprob, pprob, pprob_t, init_vec;   // log T, exp(T), exp(T) transposed per block
-    DevBuf<double> tprob_q;                   // S = 136: log T in the quad chains' lane order (pprob, pprob_t too)
-    bool quad = false;
+    DevBuf<double> tprob_q;                   // S = 36 / 136: log T in the chain kernels' lane order (pprob, pprob_t too)
+    bool quad = false;                        // tables are in lane order
     DevBuf<double> expr, avecs, eprob, peprob, xsum, bhat, alpha, ahat, beta, gamma, delta, scaler, invz;
     DevBuf<double> bscale, bcorr;             // free-running backward: per-gene scale and log correction
     DevBuf<uint8_t> has_avec;
@@ -1502,11 +1516,7 @@ int hmm_launch(gbrs_hmm *h) {
     const dim3 unit_grid(h->n_chrom, h->n_samples);
     hipStream_t sa = h->stream, sb = h->stream_b, sc = h->stream_c;
     if (const char *env = std::getenv("GBRS_TUNING_HMM_SERIAL"); env && std::atoi(env)) sb = sc = sa;
-#if defined(HMM_NO_WAVE)
-    constexpr bool WAVE = false;
-#else
-    constexpr bool WAVE = EXACT && KMAX * 4 <= 64;    // S = 36: the single-wave recursions
-#endif
+    constexpr bool WAVE = EXACT && KMAX * 4 <= 64;    // S = 36: the single-wave recursions (tables in lane order)
     constexpr bool QUAD = EXACT && KMAX * 4 > 64 && KMAX % 2 == 0;   // S = 136: the quad chains (tables in lane order)
     GBRS_HIP_CHECK(hipEventRecord(h->ev[1], sa));
     hipLaunchKernelGGL(exp_emission_kernel, dim3((unsigned)((rows * S + 255) / 256)), dim3(256), 0, sa,
@@ -1546,7 +1556,7 @@ int hmm_launch(gbrs_hmm *h) {
             }
             launch_alpha = [=](hipStream_t st) {
                 hipLaunchKernelGGL(k_alpha, wave_grid, dim3(64), pad, st, h->n_samples, h->total_genes,
-                                   h->d_chroms.p, h->d_order.p, h->tprob.p, h->pprob.p, h->eprob.p, h->peprob.p,
+                                   h->d_chroms.p, h->d_order.p, h->tprob_q.p, h->pprob.p, h->eprob.p, h->peprob.p,
                                    h->init_vec.p, h->xsum.p, h->ahat.p, h->invz.p, h->delta.p, h->last_state.p);
             };
             launch_back = [=](hipStream_t st) {
@@ -1555,7 +1565,7 @@ int hmm_launch(gbrs_hmm *h) {
             };
             launch_delta = [=](hipStream_t st) {
                 hipLaunchKernelGGL(k_delta, wave_grid, dim3(64), pad, st, h->n_samples, h->total_genes,
-                                   h->d_chroms.p, h->d_order.p, h->tprob.p, h->pprob.p, h->eprob.p, h->peprob.p,
+                                   h->d_chroms.p, h->d_order.p, h->tprob_q.p, h->pprob.p, h->eprob.p, h->peprob.p,
                                    h->init_vec.p, h->xsum.p, h->ahat.p, h->invz.p, h->delta.p, h->last_state.p);
             };
         } else {
@@ -1710,7 +1720,9 @@ int gbrs_hmm_create(int num_haps, int n_chrom, const int32_t *n_genes, const int
     GBRS_TRY(h->tprob.alloc(std::max<size_t>(h->total_trans * blk, 1)));
     GBRS_TRY(h->pprob.alloc(std::max<size_t>(h->total_trans * blk, 1)));
     GBRS_TRY(h->pprob_t.alloc(std::max<size_t>(h->total_trans * blk, 1)));
-    h->quad = S == 136;                            // the state count hmm_launch runs on the quad chains
+    // state counts hmm_launch runs on the chain kernels keep exp(T), exp(T)^T and a copy of T in lane order
+    const int lps = S == 136 ? 4 : S == 36 ? 1 : 0;
+    h->quad = lps != 0;
     if (h->quad) GBRS_TRY(h->tprob_q.alloc(std::max<size_t>(h->total_trans * blk, 1)));
     for (int c = 0; c < n_chrom; ++c)
         if (n_trans[c] > 0)
@@ -1718,8 +1730,8 @@ int gbrs_hmm_create(int num_haps, int n_chrom, const int32_t *n_genes, const int
                                      (size_t)n_trans[c] * blk * sizeof(double), hipMemcpyHostToDevice));
     if (h->total_trans > 0) {
         if (h->quad)
-            hipLaunchKernelGGL(quad_blocks_kernel, dim3(4096), dim3(256), 0, h->stream, S, S / 4, h->total_trans,
-                               h->tprob.p, h->pprob.p, h->pprob_t.p, h->tprob_q.p);
+            hipLaunchKernelGGL(lane_blocks_kernel, dim3(4096), dim3(256), 0, h->stream, S, lps, S / lps,
+                               h->total_trans, h->tprob.p, h->pprob.p, h->pprob_t.p, h->tprob_q.p);
         else
             hipLaunchKernelGGL(exp_blocks_kernel, dim3(2048), dim3(256), 0, h->stream, S, h->total_trans,
                                h->tprob.p, h->pprob.p, h->pprob_t.p);
