@@ -1494,7 +1494,9 @@ int hmm_alloc_samples(gbrs_hmm *h, int n_samples) {
 #define HMM_NSET_B 2      // register sets of the HMM_SB-samples-per-wave recursions
 #endif
 
-template <int KMAX, int MAXT, bool EXACT>
+// SS_WAVE > 0: the single-wave chain kernels for that (even, <= 64) state count; otherwise KMAX / MAXT /
+// EXACT select the quad chains (EXACT, S = 4*KMAX > 64) or the generic multi-wave kernels.
+template <int SS_WAVE, int KMAX, int MAXT, bool EXACT>
 int hmm_launch(gbrs_hmm *h) {
     const int S = h->S;
     const int threads = ((S * 4 + 63) / 64) * 64;
@@ -1516,8 +1518,8 @@ int hmm_launch(gbrs_hmm *h) {
     const dim3 unit_grid(h->n_chrom, h->n_samples);
     hipStream_t sa = h->stream, sb = h->stream_b, sc = h->stream_c;
     if (const char *env = std::getenv("GBRS_TUNING_HMM_SERIAL"); env && std::atoi(env)) sb = sc = sa;
-    constexpr bool WAVE = EXACT && KMAX * 4 <= 64;    // S = 36: the single-wave recursions (tables in lane order)
-    constexpr bool QUAD = EXACT && KMAX * 4 > 64 && KMAX % 2 == 0;   // S = 136: the quad chains (tables in lane order)
+    constexpr bool WAVE = SS_WAVE > 0;                // the single-wave recursions (tables in lane order)
+    constexpr bool QUAD = !WAVE && EXACT && KMAX * 4 > 64 && KMAX % 2 == 0;   // S = 136: the quad chains (tables in lane order)
     GBRS_HIP_CHECK(hipEventRecord(h->ev[1], sa));
     hipLaunchKernelGGL(exp_emission_kernel, dim3((unsigned)((rows * S + 255) / 256)), dim3(256), 0, sa,
                        rows * S, h->eprob.p, h->peprob.p);
@@ -1528,7 +1530,7 @@ int hmm_launch(gbrs_hmm *h) {
         //                            C  delta -> backpointers -> backtrace
         std::function<void(hipStream_t)> launch_alpha, launch_back, launch_delta;
         if constexpr (WAVE) {
-            constexpr int SS = KMAX * 4;
+            constexpr int SS = SS_WAVE;
             // Few samples: one sample per wave and a 3-deep prefetch ring (latency).  Many samples:
             // HMM_SB samples share each wave's transition registers and 2 sets suffice (throughput:
             // a quarter of the block loads per sample and two waves per SIMD).
@@ -1721,7 +1723,7 @@ int gbrs_hmm_create(int num_haps, int n_chrom, const int32_t *n_genes, const int
     GBRS_TRY(h->pprob.alloc(std::max<size_t>(h->total_trans * blk, 1)));
     GBRS_TRY(h->pprob_t.alloc(std::max<size_t>(h->total_trans * blk, 1)));
     // state counts hmm_launch runs on the chain kernels keep exp(T), exp(T)^T and a copy of T in lane order
-    const int lps = S == 136 ? 4 : S == 36 ? 1 : 0;
+    const int lps = S == 136 ? 4 : (S == 36 || S == 28 || S == 10 || S == 6) ? 1 : 0;
     h->quad = lps != 0;
     if (h->quad) GBRS_TRY(h->tprob_q.alloc(std::max<size_t>(h->total_trans * blk, 1)));
     for (int c = 0; c < n_chrom; ++c)
@@ -1814,11 +1816,14 @@ int gbrs_hmm_run(gbrs_hmm_t *h) {
     int rc;
     // 4 lanes per state, KMAX = ceil(S / 4); the two production shapes (DO: H = 8, CC-style:
     // H = 16) divide evenly and get predicate-free instantiations
-    if (S == 36) rc = hmm_launch<9, 192, true>(h);
-    else if (S == 136) rc = hmm_launch<34, 576, true>(h);
-    else if (S <= 48) rc = hmm_launch<12, 192, false>(h);
-    else if (S <= 64) rc = hmm_launch<16, 256, false>(h);
-    else rc = hmm_launch<34, 576, false>(h);            // S <= 136 (MAX_H = 16)
+    if (S == 36) rc = hmm_launch<36, 9, 192, true>(h);            // 8 founders
+    else if (S == 28) rc = hmm_launch<28, 12, 192, false>(h);     // 7
+    else if (S == 10) rc = hmm_launch<10, 12, 192, false>(h);     // 4
+    else if (S == 6) rc = hmm_launch<6, 12, 192, false>(h);       // 3
+    else if (S == 136) rc = hmm_launch<0, 34, 576, true>(h);      // 16
+    else if (S <= 48) rc = hmm_launch<0, 12, 192, false>(h);
+    else if (S <= 64) rc = hmm_launch<0, 16, 256, false>(h);
+    else rc = hmm_launch<0, 34, 576, false>(h);        // S <= 136 (MAX_H = 16)
     if (rc == GBRS_OK) h->ran = true;
     return rc;
 }

@@ -196,3 +196,37 @@ def test_hmm_sixteen_founders(n_samples, minus_one):
                 np.testing.assert_allclose(r[k], res[c][k], rtol=1e-9, atol=1e-9, err_msg=f"{k} sample {s} chrom {c}")
             np.testing.assert_allclose(r["gamma"], res[c]["gamma"], rtol=1e-8, atol=1e-300)
     hmm.close()
+
+
+@pytest.mark.parametrize("H", [2, 3, 4, 5, 7, 9])
+def test_hmm_other_founder_counts(H):
+    """Founder counts other than 8 and 16: 3, 4 and 7 run on the single-wave chain kernels (even
+    state counts <= 64), 2, 5 and 9 on the generic multi-wave kernels; 5 samples, oracle per sample."""
+    from gbrs_amd import synth
+    from gbrs_amd.hmm import DiplotypeHMM
+    from oracle import hmm_oracle
+    lens = [1, 2, 3, 6, 65, 130]
+    probs = [synth.make_hmm_problem(H=H, genes_per_chrom=lens, seed=777 + s, tprob_len_minus_one=bool(H % 2))
+             for s in range(5)]
+    p0 = probs[0]
+    chroms = p0.chroms
+    hmm = DiplotypeHMM(H, chroms, [len(p0.gene_ids[c]) for c in chroms], [p0.tprob[c] for c in chroms])
+    ex, av, ha = [], [], []
+    for c in chroms:
+        ids = p0.gene_ids[c]
+        ex.append(np.array([[p.expr[g] for g in ids] for p in probs]))
+        ha.append(np.array([g in p0.avecs for g in ids], dtype=np.uint8))
+        av.append(np.array([p0.avecs.get(g, np.zeros((H, H))) for g in ids]))
+    hmm.set_expression(ex, av, ha, 1.5, 0.12)
+    hmm.run()
+    want = ("gamma", "states", "calls", "alpha", "beta", "delta", "scaler")
+    for s, p in enumerate(probs):
+        res = hmm_oracle.reconstruct_arrays(p0.hap_names, chroms, p0.gene_ids, p0.tprob, p.expr, p0.avecs)
+        for ci, c in enumerate(chroms):
+            r = hmm.get(ci, sample=s, want=want)
+            np.testing.assert_array_equal(r["states"], res[c]["states"], err_msg=f"sample {s} chrom {c}")
+            np.testing.assert_array_equal(r["calls"], res[c]["calls"], err_msg=f"sample {s} chrom {c}")
+            for k in ("alpha", "beta", "delta", "scaler"):
+                np.testing.assert_allclose(r[k], res[c][k], rtol=1e-9, atol=1e-9, err_msg=f"{k} sample {s} chrom {c}")
+            np.testing.assert_allclose(r["gamma"], res[c]["gamma"], rtol=1e-8, atol=1e-300)
+    hmm.close()
