@@ -883,31 +883,44 @@ __device__ __forceinline__ double quad_max(double v) {
     return v;
 }
 
-template <int KMAX, int ROLE>
-__global__ void __launch_bounds__(((KMAX * 16 + 63) / 64) * 64)
-quad_chain_kernel(int64_t genes_per_sample, const ChromDesc *__restrict__ chroms,
+template <int LPS>
+__device__ __forceinline__ double group_sum(double v) {
+    v += dpp_f64<DPP_QUAD_XOR1>(v);
+    if (LPS == 4) v += dpp_f64<DPP_QUAD_XOR2>(v);
+    return v;
+}
+template <int LPS>
+__device__ __forceinline__ double group_max(double v) {
+    v = fmax(v, dpp_f64<DPP_QUAD_XOR1>(v));
+    if (LPS == 4) v = fmax(v, dpp_f64<DPP_QUAD_XOR2>(v));
+    return v;
+}
+
+template <int LPS, int KMAX, int NSET, int HBQ_SUM, int ROLE>
+__global__ void __launch_bounds__(((LPS * LPS * KMAX + 63) / 64) * 64)
+group_chain_kernel(int64_t genes_per_sample, const ChromDesc *__restrict__ chroms,
                   const int32_t *__restrict__ order, const double *__restrict__ blocks,
                   const double *__restrict__ em, const double *__restrict__ eprob,
                   const double *__restrict__ init_vec, double *__restrict__ out_vec /* xsum | delta | bhat */,
                   double *__restrict__ ahat, double *__restrict__ scal /* invz | - | bscale */,
                   int32_t *__restrict__ last_state) {
-    static_assert(KMAX % 2 == 0, "16-byte aligned row quarters");
-    constexpr int S = 4 * KMAX, NSET = 1, NV = KMAX / 2;   // one register set refilled in place: one step of lead
+    static_assert(KMAX % 2 == 0 && (LPS == 2 || LPS == 4), "16-byte aligned row parts, DPP group of 2 or 4");
+    constexpr int S = LPS * KMAX, NV = KMAX / 2;   // NSET register sets refilled in place: NSET steps of lead
     __shared__ __attribute__((aligned(16))) double buf[2][S];
     const int chrom = order[blockIdx.y];
     const ChromDesc cd = chroms[chrom];
     const int sample = blockIdx.x;
     const int n = cd.n_genes;
     if (n <= 0) return;
-    const int j = threadIdx.x / 4, q = threadIdx.x % 4;
+    const int j = threadIdx.x / LPS, q = threadIdx.x % LPS;
     const bool valid = j < S;
     const int jr = valid ? j : S - 1;
     const bool owner = valid && q == 0;
     const int64_t g0 = (int64_t)sample * genes_per_sample + cd.gene_off;
-    // tables in lane order (lane_blocks_kernel, LPS = 4): double2 m of this lane at byte (m*4S + lane)*16
+    // tables in lane order (lane_blocks_kernel): double2 m of this lane at byte (m*LPS*S + lane)*16
     const double *BLK0 = blocks + cd.trans_off * (int64_t)S * S;
-    unsigned row_off = min((int)threadIdx.x, 4 * S - 1) * 16;
-    constexpr int M_STRIDE = 4 * S * 16;
+    unsigned row_off = min((int)threadIdx.x, LPS * S - 1) * 16;
+    constexpr int M_STRIDE = LPS * S * 16;
     // order o: forward roles step i = o + 1 on block o; backward gene i = n-2-o on block i
     const int n_ord = ROLE == 2 ? n - 1 : min(n, cd.n_trans + 1) - 1;
     const int last_o = max(n_ord - 1, 0);
@@ -963,11 +976,8 @@ quad_chain_kernel(int64_t genes_per_sample, const ChromDesc *__restrict__ chroms
         const double *nblk = BLK0 + (int64_t)HMM_BLK(blk_of(of)) * S * S;
         const double2 *src = reinterpret_cast<const double2 *>(buf[cur] + q * KMAX);
         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, z0 = 0.0, z1 = 0.0;
-        // LDS reads go out in batches sized to the register budget (9 waves per workgroup: 168)
-#ifndef HMM_QUAD_HB
-#define HMM_QUAD_HB 1
-#endif
-        constexpr int HBQ = ROLE == 1 ? (NV + 1) / 2 : HMM_QUAD_HB;
+        // LDS reads go out in batches sized to the register budget (168 with 9 waves per workgroup)
+        constexpr int HBQ = ROLE == 1 ? (NV + 1) / 2 : HBQ_SUM;
 #pragma unroll
         for (int mb = 0; mb < NV; mb += HBQ) {
             double2 v[HBQ];
@@ -1000,16 +1010,16 @@ quad_chain_kernel(int64_t genes_per_sample, const ChromDesc *__restrict__ chroms
         }
         const int i = ROLE == 2 ? n - 2 - o : o + 1;
         if (ROLE == 0) {
-            const double inv_z = alpha_finish(i - 1, quad_sum(z0 + z1));
-            const double x = quad_sum((a0 + a1) + (a2 + a3)) * inv_z + TINY;
+            const double inv_z = alpha_finish(i - 1, group_sum<LPS>(z0 + z1));
+            const double x = group_sum<LPS>((a0 + a1) + (a2 + a3)) * inv_z + TINY;
             own = x * e;
             if (owner) out_vec[(g0 + i) * S + j] = x;
         } else if (ROLE == 1) {
-            own = quad_max(fmax(fmax(a0, a1), fmax(a2, a3))) + e;
+            own = group_max<LPS>(fmax(fmax(a0, a1), fmax(a2, a3))) + e;
             if (owner) out_vec[(g0 + i) * S + j] = own;
         } else {
-            const double r = rescale ? fast_recip_pos(quad_sum(z0 + z1)) : 1.0;
-            const double bh = quad_sum((a0 + a1) + (a2 + a3)) * r;
+            const double r = rescale ? fast_recip_pos(group_sum<LPS>(z0 + z1)) : 1.0;
+            const double bh = group_sum<LPS>((a0 + a1) + (a2 + a3)) * r;
             own = bh * e;
             if (owner) {
                 out_vec[(g0 + i) * S + j] = bh;
@@ -1020,8 +1030,14 @@ quad_chain_kernel(int64_t genes_per_sample, const ChromDesc *__restrict__ chroms
         cur ^= 1;
         lds_barrier();
     };
-    int o = 0;
-    for (; o < n_ord; ++o) step(o, true, pr[0], em_r[0]);    // backward: rescale every step (one loop body)
+    int o = 0;                                   // backward: rescale every step (one loop body)
+    for (; o + NSET <= n_ord; o += NSET) {
+#pragma unroll
+        for (int u = 0; u < NSET; ++u) step(o + u, true, pr[u], em_r[u]);
+    }
+#pragma unroll
+    for (int u = 0; u < NSET - 1; ++u)
+        if (o + u < n_ord) step(o + u, true, pr[u], em_r[u]);
     if (ROLE == 0) {
         const double2 *src = reinterpret_cast<const double2 *>(buf[cur] + q * KMAX);
         double z0 = 0.0, z1 = 0.0;
@@ -1030,7 +1046,7 @@ quad_chain_kernel(int64_t genes_per_sample, const ChromDesc *__restrict__ chroms
             const double2 v = src[m];
             if (m & 1) z1 += v.x + v.y; else z0 += v.x + v.y;
         }
-        alpha_finish(n_ord, quad_sum(z0 + z1));
+        alpha_finish(n_ord, group_sum<LPS>(z0 + z1));
     }
     if (ROLE == 1 && threadIdx.x == 0) {       // sid = argmax delta[:, n-1] (first max)
         const double *dl = buf[cur];
@@ -1573,17 +1589,17 @@ int hmm_launch(gbrs_hmm *h) {
         } else {
             const dim3 quad_grid(h->n_samples, h->n_chrom), quad_block(threads);
             launch_alpha = [=](hipStream_t st) {
-                hipLaunchKernelGGL((quad_chain_kernel<KMAX, 0>), quad_grid, quad_block, 0, st, h->total_genes,
+                hipLaunchKernelGGL((group_chain_kernel<4, KMAX, 1, 1, 0>), quad_grid, quad_block, 0, st, h->total_genes,
                                    h->d_chroms.p, h->d_order.p, h->pprob.p, h->peprob.p, h->eprob.p, h->init_vec.p,
                                    h->xsum.p, h->ahat.p, h->invz.p, h->last_state.p);
             };
             launch_back = [=](hipStream_t st) {
-                hipLaunchKernelGGL((quad_chain_kernel<KMAX, 2>), quad_grid, quad_block, 0, st, h->total_genes,
+                hipLaunchKernelGGL((group_chain_kernel<4, KMAX, 1, 1, 2>), quad_grid, quad_block, 0, st, h->total_genes,
                                    h->d_chroms.p, h->d_order.p, h->pprob_t.p, h->peprob.p, h->eprob.p, h->init_vec.p,
                                    h->bhat.p, h->ahat.p, h->bscale.p, h->last_state.p);
             };
             launch_delta = [=](hipStream_t st) {
-                hipLaunchKernelGGL((quad_chain_kernel<KMAX, 1>), quad_grid, quad_block, 0, st, h->total_genes,
+                hipLaunchKernelGGL((group_chain_kernel<4, KMAX, 1, 1, 1>), quad_grid, quad_block, 0, st, h->total_genes,
                                    h->d_chroms.p, h->d_order.p, h->tprob_q.p, h->eprob.p, h->eprob.p, h->init_vec.p,
                                    h->delta.p, h->ahat.p, h->invz.p, h->last_state.p);
             };
