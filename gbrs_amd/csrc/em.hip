@@ -126,11 +126,29 @@ constexpr int ERR_BLOCKS = 64;
 // reduces the M-step's block partials to S_prev / S_new itself (fixed order), writes its partial
 // of err_sum and takes a ticket; the block that draws the last ticket sums the partials in fixed
 // order, so the result does not depend on the order in which blocks finish.
-__global__ void __launch_bounds__(RED_THREADS)
-err_finish_kernel(uint32_t L, int nblocks, const double *__restrict__ tot_prev,
-                  const double *__restrict__ tot_new, double *__restrict__ partials,
-                  EmScalars *__restrict__ sc, double target_err, double *__restrict__ err_hist,
-                  int err_hist_cap) {
+// Arguments of the error pass, as one value: gather_kernel carries them for the deferred form.
+struct ErrArgs {
+    uint32_t L;
+    int nblocks;                 // M-step accumulator slots in use (RED_BLOCKS)
+    const double *tot_prev, *tot_new;
+    double *partials;
+    EmScalars *sc;
+    double target_err;
+    double *err_hist;
+    int err_hist_cap;
+    uint32_t n_err_blocks;       // workgroups that run the pass (0: none)
+};
+
+__device__ __forceinline__ void err_finish_body(const ErrArgs &ea, unsigned bid) {
+    const uint32_t L = ea.L;
+    const int nblocks = ea.nblocks;
+    const double *__restrict__ tot_prev = ea.tot_prev, *__restrict__ tot_new = ea.tot_new;
+    double *__restrict__ partials = ea.partials;
+    EmScalars *__restrict__ sc = ea.sc;
+    const double target_err = ea.target_err;
+    double *__restrict__ err_hist = ea.err_hist;
+    const int err_hist_cap = ea.err_hist_cap;
+    const unsigned nb = ea.n_err_blocks;
     __shared__ double lds[16];
     __shared__ double s_sums[2];
     __shared__ int s_last;
@@ -144,21 +162,21 @@ err_finish_kernel(uint32_t L, int nblocks, const double *__restrict__ tot_prev,
     __syncthreads();
     const double cp = 1000000.0 / s_sums[0], cn = 1000000.0 / s_sums[1];
     double e = 0.0;
-    for (uint32_t l = blockIdx.x * blockDim.x + threadIdx.x; l < L; l += gridDim.x * blockDim.x)
+    for (uint32_t l = bid * blockDim.x + threadIdx.x; l < L; l += nb * blockDim.x)
         e += fabs(tot_new[l] * cn - tot_prev[l] * cp);
     e = block_sum(e, lds);
     if (threadIdx.x == 0) {
-        partials[2 * RED_BLOCKS + blockIdx.x] = e;
+        partials[2 * RED_BLOCKS + bid] = e;
         __threadfence();                                        // publish before the ticket
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the compiler may drop the fence's own wait)
         const int ticket = atomicAdd(&sc->ticket, 1);
-        s_last = ticket == (int)gridDim.x - 1;
+        s_last = ticket == (int)nb - 1;
         if (s_last) __threadfence();                            // acquire the other blocks' partials
     }
     __syncthreads();
     if (!s_last) return;
     double tot = 0.0;
-    for (int i = threadIdx.x; i < (int)gridDim.x; i += blockDim.x)
+    for (int i = threadIdx.x; i < (int)nb; i += blockDim.x)
         tot += __hip_atomic_load(&partials[2 * RED_BLOCKS + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     tot = block_sum(tot, lds);
     for (int i = threadIdx.x; i < 2 * RED_BLOCKS; i += blockDim.x) partials[i] = 0.0;   // for the next M-step
@@ -173,6 +191,11 @@ err_finish_kernel(uint32_t L, int nblocks, const double *__restrict__ tot_prev,
         if (!(tot > target_err)) sc->stop = 1;
         if (!(s_sums[0] > 0.0) || !(s_sums[1] > 0.0) || tot != tot) sc->float_error = 1;
     }
+}
+
+__global__ void __launch_bounds__(RED_THREADS)
+err_finish_kernel(ErrArgs ea) {
+    err_finish_body(ea, blockIdx.x);
 }
 
 // pseudocount rule, EMfactory.py:105-111: every haplotype of a locus with any nonzero haplotype
@@ -383,6 +406,12 @@ struct gbrs_em {
     int err_hist_cap = 0;
     double last_estep_ms = 0.0, last_step_ms = 0.0;   // means over the steps of the last call
     bool time_steps = true;
+    // The error pass of a step may be deferred into the gather launch of the next step (it runs there
+    // on extra workgroups beside the gather's, one launch and ~9 us less per iteration); it is
+    // flushed as its own launch before anything reads the scalars.
+    bool err_pending = false;
+    double err_pending_target = -1.0;
+    hipEvent_t ev_after_estep = nullptr;      // timed step: recorded between the E-step kernels and the gather
     std::vector<hipEvent_t> ev_pool;                   // 3 events per timed step of gbrs_em_step
 
     int red_blocks() const { return (int)std::min<uint64_t>(RED_BLOCKS, (L + RED_THREADS - 1) / RED_THREADS); }
@@ -390,7 +419,10 @@ struct gbrs_em {
 
 namespace {
 
+int em_flush_err(gbrs_em *em);
+
 int em_check_float(gbrs_em *em, EmScalars &host) {
+    GBRS_TRY(em_flush_err(em));
     GBRS_HIP_CHECK(hipMemcpyAsync(&host, em->scalars.p, sizeof(EmScalars), hipMemcpyDeviceToHost, em->stream));
     GBRS_HIP_CHECK(hipStreamSynchronize(em->stream));
     static const bool no_check = std::getenv("GBRS_TUNING_NO_FLOAT_CHECK") != nullptr;   // ablation builds only
@@ -419,8 +451,13 @@ int em_estep_tiles_h(gbrs_em *em) {
 
 // materialize: write the full A into em->acc (needed before an all-reduce); otherwise only the
 // heavy loci are gathered here and the M-step kernel gathers the rest itself.
+ErrArgs em_err_args(gbrs_em *em, double target_err);
+int em_flush_err(gbrs_em *em);
+
 template <bool ONES>
 int em_estep_tiles(gbrs_em *em, bool materialize) {
+    if (ONES) GBRS_TRY(em_flush_err(em));        // prepare: nothing may be pending across it
+
     TileLayout &tl = em->tl;
     switch (em->H) {
         case 1: GBRS_TRY((em_estep_tiles_h<1, ONES>(em))); break;
@@ -436,6 +473,10 @@ int em_estep_tiles(gbrs_em *em, bool materialize) {
                            tl.n_long, em->H, tl.long_ptr.p, tl.long_loc.p, tl.long_mask.p, tl.long_weight.p,
                            em->theta.p, tl.acc_extra.p, em->scalars.p);
     }
+    if (em->ev_after_estep) {
+        GBRS_HIP_CHECK(hipEventRecord(em->ev_after_estep, em->stream));
+        em->ev_after_estep = nullptr;
+    }
     uint32_t HP = 1;
     while (HP < em->H) HP <<= 1;
     const bool pow2 = (em->H & (em->H - 1)) == 0;
@@ -444,12 +485,16 @@ int em_estep_tiles(gbrs_em *em, bool materialize) {
     const unsigned light = (unsigned)((elems + 255) / 256);
     const unsigned heavy = (unsigned)((tl.n_heavy + 3) / 4);
     em->acc_needs_extra = !all && tl.n_long > 0;
-    if (light + heavy > 0)
-        hipLaunchKernelGGL(gather_kernel, dim3(light + heavy), dim3(256), 0, em->stream, em->L, em->H, HP, light,
-                           (uint32_t)tl.n_heavy, all ? 1 : 0, (uint32_t)tl.n_light, tl.light_loci.p, tl.slot_ptr.p,
-                           tl.slot_list.p, tl.heavy_loci.p, tl.locus_class.p, tl.partials.p,
+    // a deferred error pass of the previous step rides on this launch as extra workgroups
+    ErrArgs ea = em_err_args(em, em->err_pending_target);
+    if (ONES || !em->err_pending) ea.n_err_blocks = 0;
+    em->err_pending = false;
+    if (light + heavy + ea.n_err_blocks > 0)
+        hipLaunchKernelGGL(gather_kernel, dim3(light + heavy + ea.n_err_blocks), dim3(256), 0, em->stream, em->L, em->H,
+                           HP, light, heavy, (uint32_t)tl.n_heavy, all ? 1 : 0, (uint32_t)tl.n_light, tl.light_loci.p,
+                           tl.slot_ptr.p, tl.slot_list.p, tl.heavy_loci.p, tl.locus_class.p, tl.partials.p,
                            (tl.n_long && all) ? tl.acc_extra.p : (const double *)nullptr, em->acc.p, em->scalars.p,
-                           ONES ? 0 : 1);
+                           ONES ? 0 : 1, ea);
     GBRS_HIP_CHECK(hipGetLastError());
     return GBRS_OK;
 }
@@ -495,11 +540,43 @@ int em_launch_mstep(gbrs_em *em) {
 }
 
 // Everything after the E-step of one EM iteration.
-int em_finish_step(gbrs_em *em, double target_err) {
+ErrArgs em_err_args(gbrs_em *em, double target_err) {
+    ErrArgs ea;
+    ea.L = em->L;
+    ea.nblocks = RED_BLOCKS;
+    ea.tot_prev = em->tot_prev.p;
+    ea.tot_new = em->tot_new.p;
+    ea.partials = em->partials.p;
+    ea.sc = em->scalars.p;
+    ea.target_err = target_err;
+    ea.err_hist = em->err_hist.p;
+    ea.err_hist_cap = em->err_hist_cap;
+    ea.n_err_blocks = (uint32_t)std::min<uint64_t>(ERR_BLOCKS, (em->L + RED_THREADS - 1) / RED_THREADS);
+    return ea;
+}
+
+// Runs a deferred error pass now (before anything that reads or resets the step scalars).
+int em_flush_err(gbrs_em *em) {
+    if (!em->err_pending) return GBRS_OK;
+    em->err_pending = false;
+    const ErrArgs ea = em_err_args(em, em->err_pending_target);
+    hipLaunchKernelGGL(err_finish_kernel, dim3(ea.n_err_blocks), dim3(RED_THREADS), 0, em->stream, ea);
+    GBRS_HIP_CHECK(hipGetLastError());
+    return GBRS_OK;
+}
+
+// Everything after the E-step of one EM iteration.  `defer`: leave the error pass to the next
+// step's gather launch (em_estep_tiles) or to em_flush_err.
+int em_finish_step(gbrs_em *em, double target_err, bool defer = false) {
+    GBRS_TRY(em_flush_err(em));
     GBRS_TRY(em_launch_mstep<0>(em));
-    const int ne = (int)std::min<uint64_t>(ERR_BLOCKS, (em->L + RED_THREADS - 1) / RED_THREADS);
-    hipLaunchKernelGGL(err_finish_kernel, dim3(ne), dim3(RED_THREADS), 0, em->stream, em->L, RED_BLOCKS, em->tot_prev.p,
-                       em->tot_new.p, em->partials.p, em->scalars.p, target_err, em->err_hist.p, em->err_hist_cap);
+    if (defer && em->layout == 1) {
+        em->err_pending = true;
+        em->err_pending_target = target_err;
+        return GBRS_OK;
+    }
+    const ErrArgs ea = em_err_args(em, target_err);
+    hipLaunchKernelGGL(err_finish_kernel, dim3(ea.n_err_blocks), dim3(RED_THREADS), 0, em->stream, ea);
     GBRS_HIP_CHECK(hipGetLastError());
     return GBRS_OK;
 }
@@ -508,12 +585,15 @@ int em_finish_step(gbrs_em *em, double target_err) {
 // queue ~4 us of idle time on this hardware, so callers time a sample of the iterations (every
 // EM_TIME_STRIDE-th), not each one.
 constexpr int EM_TIME_STRIDE = 8;
-int em_one_step(gbrs_em *em, double target_err, hipEvent_t *ev = nullptr) {
+int em_one_step(gbrs_em *em, double target_err, hipEvent_t *ev = nullptr, bool defer_err = false) {
     const bool timed = ev != nullptr && em->time_steps;
     if (timed) GBRS_HIP_CHECK(hipEventRecord(ev[0], em->stream));
+    // ev[1] closes the E-step kernel itself (tile layout: before the gather; CSC layout: after the pass)
+    em->ev_after_estep = timed && em->layout == 1 ? ev[1] : nullptr;
     GBRS_TRY(em_estep<false>(em));
-    if (timed) GBRS_HIP_CHECK(hipEventRecord(ev[1], em->stream));
-    GBRS_TRY(em_finish_step(em, target_err));
+    em->ev_after_estep = nullptr;
+    if (timed && em->layout != 1) GBRS_HIP_CHECK(hipEventRecord(ev[1], em->stream));
+    GBRS_TRY(em_finish_step(em, target_err, defer_err));
     if (timed) GBRS_HIP_CHECK(hipEventRecord(ev[2], em->stream));
     return GBRS_OK;
 }
@@ -542,6 +622,7 @@ int em_finish_prepare(gbrs_em *em, double pseudocount) {
 }
 
 int em_reset_scalars(gbrs_em *em, bool keep_iters) {
+    GBRS_TRY(em_flush_err(em));
     EmScalars host;
     std::memset(&host, 0, sizeof(host));
     if (keep_iters) {
@@ -831,7 +912,7 @@ int gbrs_em_step(gbrs_em_t *em, int n_iters, double *err_sum_out) {
     for (int i = 0; i < n_iters; ++i) {
         const int slot = i / EM_TIME_STRIDE;
         const bool t = i % EM_TIME_STRIDE == 0 && slot < timed;
-        GBRS_TRY(em_one_step(em, -1.0, t ? &em->ev_pool[3 * slot] : nullptr));
+        GBRS_TRY(em_one_step(em, -1.0, t ? &em->ev_pool[3 * slot] : nullptr, i + 1 < n_iters));
     }
     EmScalars host;
     GBRS_TRY(em_check_float(em, host));
@@ -875,7 +956,8 @@ int gbrs_em_run(gbrs_em_t *em, int model, double tol, int max_iters, int *n_iter
         while (done < max_iters) {
             const int nb = std::min(batch, max_iters - done);
             hipEvent_t ev[3] = {em->ev0, em->ev1, em->ev2};
-            for (int i = 0; i < nb; ++i) GBRS_TRY(em_one_step(em, target, i == 0 ? ev : nullptr));   // one timed step per batch
+            for (int i = 0; i < nb; ++i)       // one timed step per batch; the batch's last error pass is not deferred
+                GBRS_TRY(em_one_step(em, target, i == 0 ? ev : nullptr, i + 1 < nb));
             GBRS_TRY(em_check_float(em, host));
             done = host.iters_done;
             if (host.stop) break;
