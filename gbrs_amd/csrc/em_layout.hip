@@ -319,12 +319,10 @@ tile_dict_kernel(uint32_t dcap, const uint32_t *__restrict__ tile_row, const uin
                  const uint32_t *__restrict__ wordoff, uint32_t *__restrict__ tmpdict,
                  uint32_t *__restrict__ dcount, BuildFlags *flags) {
     __shared__ uint32_t a[SORT_CAP];
-    __shared__ uint32_t s_count;
     const uint32_t t = blockIdx.x;
     const uint32_t m0 = tile_row[t], m1 = tile_row[t + 1];
     const uint32_t w0 = wordoff[m0];
     for (int i = threadIdx.x; i < SORT_CAP; i += blockDim.x) a[i] = 0xFFFFFFFFu;
-    if (threadIdx.x == 0) s_count = 0;
     __syncthreads();
     for (uint32_t m = m0 + threadIdx.x; m < m1; m += blockDim.x) {
         const uint32_t r = hrow[m], p0 = rowstart[r], cnt = rowstart[r + 1] - p0;
