@@ -297,8 +297,8 @@ __global__ void exp_emission_kernel(int64_t n, const double *__restrict__ e, dou
 // and no global load sits on the sequential critical path:
 //     x_j = (sum_k y_{i-1}[k] * P[j,k]) / Z_{i-1} + tiny        P = exp(T), precomputed
 //     y_j = x_j * pe_i[j]                Z_i = sum_j y_j         pe = exp(e), precomputed
-// The kernel stores x, alpha-hat = y/Z and 1/Z; hmm_outputs_kernel turns them into the
-// log-domain alpha and scaler of the reference (same quantities up to rounding) in parallel.
+// The kernel stores x and 1/Z; hmm_outputs_kernel turns them into the log-domain alpha and scaler
+// of the reference (same quantities up to rounding) and alpha-hat = x*pe/Z in parallel.
 // delta stays in the log domain on T itself: additions and max only, i.e. exact.
 template <int KMAX, int MAXT, bool EXACT>
 __global__ void __launch_bounds__(MAXT)
@@ -306,7 +306,7 @@ forward_viterbi_kernel(int S, int64_t genes_per_sample, int64_t bp_per_sample,
                        const ChromDesc *__restrict__ chroms, const double *__restrict__ tprob,
                        const double *__restrict__ pprob, const double *__restrict__ eprob,
                        const double *__restrict__ peprob, const double *__restrict__ init_vec,
-                       double *__restrict__ xsum, double *__restrict__ ahat, double *__restrict__ invz,
+                       double *__restrict__ xsum, double *__restrict__ invz,
                        double *__restrict__ delta, uint16_t *__restrict__ bp,
                        int32_t *__restrict__ last_state) {
     constexpr int LPS = 4;
@@ -335,7 +335,7 @@ forward_viterbi_kernel(int S, int64_t genes_per_sample, int64_t bp_per_sample,
 #endif
     if (role == 0) {
         const double *E = eprob + g0 * S, *PE = peprob + g0 * S;
-        double *XS = xsum + g0 * S, *AH = ahat + g0 * S, *IZ = invz + g0;
+        double *XS = xsum + g0 * S, *IZ = invz + g0;
         const double *P = pprob + cd.trans_off * (int64_t)S * S;
         double y_own = 0.0;
         if (owner) {
@@ -357,7 +357,6 @@ forward_viterbi_kernel(int S, int64_t genes_per_sample, int64_t bp_per_sample,
         __syncthreads();
         double inv_z = fast_recip_pos(wave_sum_lds(buf, S));
         if (owner) {
-            AH[j] = y_own * inv_z;
             if (j == 0) IZ[0] = inv_z;
         }
         auto step = [&](int i, const double (&pc)[KMAX], double (&pn)[KMAX]) {
@@ -394,7 +393,6 @@ forward_viterbi_kernel(int S, int64_t genes_per_sample, int64_t bp_per_sample,
             cur = nxt;
             inv_z = fast_recip_pos(wave_sum_lds(buf + cur * S, S));
             if (owner) {
-                AH[(int64_t)i * S + j] = y_own * inv_z;
                 if (j == 0) IZ[i] = inv_z;
             }
         };
@@ -660,7 +658,7 @@ forward_wave_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *__
                     const int32_t *__restrict__ order, const double *__restrict__ tprob, const double *__restrict__ pprob,
                     const double *__restrict__ eprob, const double *__restrict__ peprob,
                     const double *__restrict__ init_vec, double *__restrict__ xsum,
-                    double *__restrict__ ahat, double *__restrict__ invz, double *__restrict__ delta,
+                    double *__restrict__ invz, double *__restrict__ delta,
                     int32_t *__restrict__ last_state) {
     static_assert(SS % 2 == 0 && SS <= 64, "one lane per state, 16-byte aligned rows");
     __shared__ __attribute__((aligned(16))) double buf[SB][2][SS];
@@ -724,7 +722,6 @@ forward_wave_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *__
         auto finish = [&](int b, int i_prev, double z) {
             const double inv_z = fast_recip_pos(z);
             if (act && sv[b]) {
-                ahat[(g0[b] + i_prev) * SS + j] = y_own[b] * inv_z;
                 if (j == 0) invz[g0[b] + i_prev] = inv_z;
             }
             return inv_z;
@@ -902,7 +899,7 @@ group_chain_kernel(int64_t genes_per_sample, const ChromDesc *__restrict__ chrom
                   const int32_t *__restrict__ order, const double *__restrict__ blocks,
                   const double *__restrict__ em, const double *__restrict__ eprob,
                   const double *__restrict__ init_vec, double *__restrict__ out_vec /* xsum | delta | bhat */,
-                  double *__restrict__ ahat, double *__restrict__ scal /* invz | - | bscale */,
+                  double *__restrict__ scal /* invz | - | bscale */,
                   int32_t *__restrict__ last_state) {
     static_assert(KMAX % 2 == 0 && (LPS == 2 || LPS == 4), "16-byte aligned row parts, DPP group of 2 or 4");
     constexpr int S = LPS * KMAX, NV = KMAX / 2;   // NSET register sets refilled in place: NSET steps of lead
@@ -964,7 +961,6 @@ group_chain_kernel(int64_t genes_per_sample, const ChromDesc *__restrict__ chrom
     auto alpha_finish = [&](int i_prev, double z) {
         const double inv_z = fast_recip_pos(z);
         if (owner) {
-            ahat[(g0 + i_prev) * S + j] = own * inv_z;
             if (j == 0) scal[g0 + i_prev] = inv_z;
         }
         return inv_z;
@@ -1280,11 +1276,11 @@ beta_corr_kernel(int64_t genes_per_sample, const ChromDesc *__restrict__ chroms,
 
 // Log-domain outputs of the reference from the probability-domain sweeps, one thread per
 // (sample, gene):  alpha = log(x) + e - log(Z), scaler = -log(Z), beta = log(bhat),
-// gamma = ahat*bhat / sum_j(ahat*bhat)  (gbrs_utils.py:515-524, :542-549, :558-560).
+// gamma = ahat*bhat / sum_j(ahat*bhat), ahat = x*pe/Z recomputed here  (gbrs_utils.py:515-524, :542-549, :558-560).
 __global__ void __launch_bounds__(1024)
 hmm_outputs_kernel(int S, int OUT_ROWS /* (sample, gene) rows per workgroup */, int64_t n_rows, int parts,
                    const double *__restrict__ eprob, const double *__restrict__ xsum,
-                   const double *__restrict__ ahat, const double *__restrict__ invz,
+                   const double *__restrict__ peprob, const double *__restrict__ invz,
                    const double *__restrict__ bhat, const double *__restrict__ bcorr /* nullable */,
                    double *__restrict__ alpha, double *__restrict__ scaler, double *__restrict__ beta,
                    double *__restrict__ gamma) {
@@ -1305,7 +1301,7 @@ hmm_outputs_kernel(int S, int OUT_ROWS /* (sample, gene) rows per workgroup */, 
     if (!(parts & 2)) return;
     double ah = 0.0, bh = 0.0;
     if (live) {
-        ah = ahat[o];
+        ah = (xsum[o] * peprob[o]) * invz[r0 + row];      // alpha-hat = y / Z, y = x * pe as in the sweep
         bh = bhat[o];
         l_g[t] = ah * bh;
     }
@@ -1459,7 +1455,7 @@ struct gbrs_hmm {
     DevBuf<double> tprob, pprob, pprob_t, init_vec;   // log T, exp(T), exp(T) transposed per block
     DevBuf<double> tprob_q;                   // S = 36 / 136: log T in the chain kernels' lane order (pprob, pprob_t too)
     bool quad = false;                        // tables are in lane order
-    DevBuf<double> expr, avecs, eprob, peprob, xsum, bhat, alpha, ahat, beta, gamma, delta, scaler, invz;
+    DevBuf<double> expr, avecs, eprob, peprob, xsum, bhat, alpha, beta, gamma, delta, scaler, invz;
     DevBuf<double> bscale, bcorr;             // free-running backward: per-gene scale and log correction
     DevBuf<uint8_t> has_avec;
     DevBuf<uint16_t> bp, bt_exit;             // backpointers; per-chunk exit maps of the backtrace
@@ -1474,7 +1470,6 @@ int hmm_alloc_samples(gbrs_hmm *h, int n_samples) {
     const size_t gs = (size_t)h->total_genes * n_samples;
     GBRS_TRY(h->eprob.alloc(gs * h->S));
     GBRS_TRY(h->alpha.alloc(gs * h->S));
-    GBRS_TRY(h->ahat.alloc(gs * h->S));
     GBRS_TRY(h->peprob.alloc(gs * h->S));
     GBRS_TRY(h->xsum.alloc(gs * h->S));
     GBRS_TRY(h->bhat.alloc(gs * h->S));
@@ -1575,7 +1570,7 @@ int hmm_launch(gbrs_hmm *h) {
             launch_alpha = [=](hipStream_t st) {
                 hipLaunchKernelGGL(k_alpha, wave_grid, dim3(64), pad, st, h->n_samples, h->total_genes,
                                    h->d_chroms.p, h->d_order.p, h->tprob_q.p, h->pprob.p, h->eprob.p, h->peprob.p,
-                                   h->init_vec.p, h->xsum.p, h->ahat.p, h->invz.p, h->delta.p, h->last_state.p);
+                                   h->init_vec.p, h->xsum.p, h->invz.p, h->delta.p, h->last_state.p);
             };
             launch_back = [=](hipStream_t st) {
                 hipLaunchKernelGGL(k_back, wave_grid, dim3(64), pad, st, h->n_samples, h->total_genes,
@@ -1584,24 +1579,24 @@ int hmm_launch(gbrs_hmm *h) {
             launch_delta = [=](hipStream_t st) {
                 hipLaunchKernelGGL(k_delta, wave_grid, dim3(64), pad, st, h->n_samples, h->total_genes,
                                    h->d_chroms.p, h->d_order.p, h->tprob_q.p, h->pprob.p, h->eprob.p, h->peprob.p,
-                                   h->init_vec.p, h->xsum.p, h->ahat.p, h->invz.p, h->delta.p, h->last_state.p);
+                                   h->init_vec.p, h->xsum.p, h->invz.p, h->delta.p, h->last_state.p);
             };
         } else {
             const dim3 quad_grid(h->n_samples, h->n_chrom), quad_block(threads);
             launch_alpha = [=](hipStream_t st) {
                 hipLaunchKernelGGL((group_chain_kernel<4, KMAX, 1, 1, 0>), quad_grid, quad_block, 0, st, h->total_genes,
                                    h->d_chroms.p, h->d_order.p, h->pprob.p, h->peprob.p, h->eprob.p, h->init_vec.p,
-                                   h->xsum.p, h->ahat.p, h->invz.p, h->last_state.p);
+                                   h->xsum.p, h->invz.p, h->last_state.p);
             };
             launch_back = [=](hipStream_t st) {
                 hipLaunchKernelGGL((group_chain_kernel<4, KMAX, 1, 1, 2>), quad_grid, quad_block, 0, st, h->total_genes,
                                    h->d_chroms.p, h->d_order.p, h->pprob_t.p, h->peprob.p, h->eprob.p, h->init_vec.p,
-                                   h->bhat.p, h->ahat.p, h->bscale.p, h->last_state.p);
+                                   h->bhat.p, h->bscale.p, h->last_state.p);
             };
             launch_delta = [=](hipStream_t st) {
                 hipLaunchKernelGGL((group_chain_kernel<4, KMAX, 1, 1, 1>), quad_grid, quad_block, 0, st, h->total_genes,
                                    h->d_chroms.p, h->d_order.p, h->tprob_q.p, h->eprob.p, h->eprob.p, h->init_vec.p,
-                                   h->delta.p, h->ahat.p, h->invz.p, h->last_state.p);
+                                   h->delta.p, h->invz.p, h->last_state.p);
             };
         }
         const size_t bp_lds = (size_t)S * (S + 1) * sizeof(double);
@@ -1610,7 +1605,7 @@ int hmm_launch(gbrs_hmm *h) {
         GBRS_HIP_CHECK(hipStreamWaitEvent(sc, h->ev_fork, 0));
         launch_alpha(sa);
         hipLaunchKernelGGL(hmm_outputs_kernel, out_grid, out_block, out_lds, sa, S, out_rows, rows, 1, h->eprob.p,
-                           h->xsum.p, h->ahat.p, h->invz.p, h->bhat.p, h->bcorr.p, h->alpha.p, h->scaler.p,
+                           h->xsum.p, h->peprob.p, h->invz.p, h->bhat.p, h->bcorr.p, h->alpha.p, h->scaler.p,
                            h->beta.p, h->gamma.p);
         GBRS_HIP_CHECK(hipEventRecord(h->ev[2], sa));
         launch_back(sb);
@@ -1633,7 +1628,7 @@ int hmm_launch(gbrs_hmm *h) {
         hipLaunchKernelGGL(beta_corr_kernel, dim3(h->n_samples, h->n_chrom), dim3(256), 0, sa, h->total_genes, h->d_chroms.p,
                            h->invz.p, h->bscale.p, h->bcorr.p);
         hipLaunchKernelGGL(hmm_outputs_kernel, out_grid, out_block, out_lds, sa, S, out_rows, rows, 2, h->eprob.p,
-                           h->xsum.p, h->ahat.p, h->invz.p, h->bhat.p, h->bcorr.p, h->alpha.p, h->scaler.p,
+                           h->xsum.p, h->peprob.p, h->invz.p, h->bhat.p, h->bcorr.p, h->alpha.p, h->scaler.p,
                            h->beta.p, h->gamma.p);
         GBRS_HIP_CHECK(hipEventRecord(h->ev[3], sa));
         GBRS_HIP_CHECK(hipStreamWaitEvent(sa, h->ev_c, 0));
@@ -1653,14 +1648,14 @@ int hmm_launch(gbrs_hmm *h) {
     } else {
         hipLaunchKernelGGL((forward_viterbi_kernel<KMAX, MAXT, EXACT>), dim3(h->n_chrom, h->n_samples, 2), dim3(threads),
                            2 * S * sizeof(double), sa, S, h->total_genes, h->total_bp, h->d_chroms.p,
-                           h->tprob.p, h->pprob.p, h->eprob.p, h->peprob.p, h->init_vec.p, h->xsum.p, h->ahat.p,
+                           h->tprob.p, h->pprob.p, h->eprob.p, h->peprob.p, h->init_vec.p, h->xsum.p,
                            h->invz.p, h->delta.p, h->bp.p, h->last_state.p);
         GBRS_HIP_CHECK(hipEventRecord(h->ev[2], sa));
         hipLaunchKernelGGL((backward_kernel<KMAX, MAXT, EXACT>), unit_grid, dim3(threads),
                            2 * S * sizeof(double), sa, S, h->total_genes, h->d_chroms.p, h->pprob_t.p,
                            h->peprob.p, h->invz.p, h->bhat.p);
         hipLaunchKernelGGL(hmm_outputs_kernel, out_grid, out_block, out_lds, sa, S, out_rows, rows, 3, h->eprob.p,
-                           h->xsum.p, h->ahat.p, h->invz.p, h->bhat.p, (const double *)nullptr, h->alpha.p,
+                           h->xsum.p, h->peprob.p, h->invz.p, h->bhat.p, (const double *)nullptr, h->alpha.p,
                            h->scaler.p, h->beta.p, h->gamma.p);
         GBRS_HIP_CHECK(hipEventRecord(h->ev[3], sa));
         launch_backtrace(sa);
