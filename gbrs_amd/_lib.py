@@ -36,6 +36,9 @@ GBRS_ERR_STATE = -6
 GBRS_EM_DEFAULT = 0
 GBRS_EM_MERGE_IDENTICAL_ROWS = 1
 GBRS_EM_LAYOUT_CSC = 2
+GBRS_EM_NO_INTERLEAVE = 4
+GBRS_EM_FORCE_INTERLEAVE = 8
+GBRS_EM_NO_STREAMS = 16
 
 
 class EmInfo(C.Structure):

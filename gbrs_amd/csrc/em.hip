@@ -751,14 +751,19 @@ int em_create_impl(uint64_t R, uint32_t L, uint32_t H, const uint32_t *const *in
         if (mx >= R) return fail(GBRS_ERR_INVALID, "indices hold row id %u >= num_rows", mx);
     }
     if (!(flags & GBRS_EM_LAYOUT_CSC) && H <= 16 && n < 0xFFFFFFFFull) {
+        // Row order inside a tile: the stream order (gbrs_hip.h) by default - every lane walks a
+        // contiguous piece of the tile's sorted rows, so it stays on one locus list for long stretches
+        // (E-step on C2: raw reads 0.158 -> 0.152 ms, merged distinct rows 0.110 -> 0.056 ms against
+        // the interleaved order that used to be their default).
+        int row_order = 2;
+        if (flags & GBRS_EM_FORCE_INTERLEAVE) row_order = 1;
+        else if (flags & GBRS_EM_NO_STREAMS) {
+            const bool distinct = count != nullptr || (flags & GBRS_EM_MERGE_IDENTICAL_ROWS);
+            row_order = (distinct && !(flags & GBRS_EM_NO_INTERLEAVE)) ? 1 : 0;
+        }
         GBRS_TRY(build_tile_layout(em->tl, R, L, H, n, em->ent_row.p, em->col_ptr.p,
                                    count ? em->count.p : nullptr, (flags & GBRS_EM_MERGE_IDENTICAL_ROWS) != 0,
-                                   /* interleave by default only when rows are distinct patterns (EC counts given or
-                                      rows merged): raw reads come in long runs of identical rows that the
-                                      E-step's per-lane register accumulation wants contiguous */
-                                   (flags & GBRS_EM_FORCE_INTERLEAVE) ||
-                                       (!(flags & GBRS_EM_NO_INTERLEAVE) &&
-                                        (count != nullptr || (flags & GBRS_EM_MERGE_IDENTICAL_ROWS))),
+                                   row_order,
                                    em->stream));
         em->layout = 1;
         // the CSC copy and the per-row denominators are only needed by layout 0

@@ -73,7 +73,8 @@ struct TileLayout {
 // count: device pointer or nullptr.  Returns GBRS_OK or a status with the message set.
 int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L, uint32_t H, uint64_t N,
                       const uint32_t *ent_row, const uint64_t *col_ptr, const double *count,
-                      bool merge_identical_rows, bool interleave, hipStream_t stream);
+                      bool merge_identical_rows, int row_order /* 0 sorted, 1 interleaved, 2 streams */,
+                      hipStream_t stream);
 
 // `gbrs compress`: equivalence classes of identical rows, in first-seen order.
 struct CompressResult {

@@ -276,6 +276,15 @@ __global__ void interleave_key_kernel(uint64_t m_rows, const uint32_t *__restric
     ident[m] = (uint32_t)m;
 }
 
+// stream order: inside a tile, rows by length (then in their sorted order), see tile_pad_kernel
+__global__ void stream_key_kernel(uint64_t m_rows, const uint32_t *__restrict__ tincl, const uint32_t *__restrict__ npm,
+                                  uint64_t *__restrict__ key, uint32_t *__restrict__ ident) {
+    const uint64_t m = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= m_rows) return;
+    key[m] = ((uint64_t)(tincl[m] - 1) << 40) | ((uint64_t)min(npm[m], 63u) << 32) | (uint32_t)m;
+    ident[m] = (uint32_t)m;
+}
+
 __global__ void permute_rows_kernel(uint64_t m_rows, const uint32_t *__restrict__ perm, const uint32_t *__restrict__ hrow,
                                     const uint32_t *__restrict__ npm, const double *__restrict__ weight,
                                     uint32_t *__restrict__ hrow2, uint32_t *__restrict__ npm2,
@@ -296,17 +305,35 @@ __global__ void tile_start_kernel(uint64_t m_rows, uint64_t n_tiles, const uint3
     tile_row[tincl[m] - 1] = (uint32_t)m;
 }
 
-// one thread per tile: padded offset of every row so that no row straddles a 64-word batch
-__global__ void tile_pad_kernel(uint64_t n_tiles, const uint32_t *__restrict__ tile_row, const uint32_t *__restrict__ npm,
-                                uint32_t *__restrict__ rowpad, uint32_t *__restrict__ nbatch) {
+// one thread per tile: padded offset of every row so that no row straddles a 64-word batch.
+// streams: the tile's rows arrive grouped by length; a run of n rows of length w (w | 64) takes
+// B = ceil(n / (64/w)) whole batches in which lane group g (w lanes) holds rows g*B .. g*B+B-1 of the
+// run at batches 0 .. B-1: whichever batches a wavefront owns, each of its lanes walks a
+// contiguous piece of the sorted rows.
+__global__ void tile_pad_kernel(uint64_t n_tiles, int streams, const uint32_t *__restrict__ tile_row,
+                                const uint32_t *__restrict__ npm, uint32_t *__restrict__ rowpad,
+                                uint32_t *__restrict__ nbatch) {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_tiles) return;
     uint32_t off = 0;
-    for (uint32_t m = tile_row[t]; m < tile_row[t + 1]; ++m) {
+    const uint32_t end = tile_row[t + 1];
+    uint32_t m = tile_row[t];
+    while (m < end) {
         const uint32_t cnt = npm[m];
-        if ((off & 63u) + cnt > 64u) off = (off + 63u) & ~63u;
-        rowpad[m] = off;
-        off += cnt;
+        if (streams && cnt <= 32u && (64u % cnt) == 0u) {
+            uint32_t e = m + 1;
+            while (e < end && npm[e] == cnt) ++e;
+            const uint32_t n = e - m, G = 64u / cnt, B = (n + G - 1) / G;
+            off = (off + 63u) & ~63u;
+            for (uint32_t k = 0; k < n; ++k) rowpad[m + k] = off + (k % B) * 64u + (k / B) * cnt;
+            off += B * 64u;
+            m = e;
+        } else {
+            if ((off & 63u) + cnt > 64u) off = (off + 63u) & ~63u;
+            rowpad[m] = off;
+            off += cnt;
+            ++m;
+        }
     }
     nbatch[t] = (off + 63u) >> 6;
 }
@@ -758,7 +785,8 @@ int compress_device(CompressResult &out, uint64_t R, uint32_t L, uint32_t H, uin
 
 int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L, uint32_t H, uint64_t N,
                       const uint32_t *ent_row, const uint64_t *col_ptr, const double *count,
-                      bool merge, bool interleave, hipStream_t s) {
+                      bool merge, int row_order, hipStream_t s) {
+    const bool interleave = row_order == 1, streams = row_order == 2;
     if (H > 16) return fail(GBRS_ERR_INVALID, "the tiled layout packs the haplotype mask in 16 bits (H <= 16)");
     if (N >= 0xFFFFFFFFull || L >= (1u << 27))
         return fail(GBRS_ERR_INVALID, "the tiled layout needs N < 2^32 entries and L < 2^27 loci per handle");
@@ -905,24 +933,29 @@ int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L, uint32_t H, uint6
     GBRS_TRY(tile_row.alloc(T + 1));
     hipLaunchKernelGGL(tile_start_kernel, dim3(grid_for(M)), dim3(256), 0, s, M, T, tflag.p, tincl.p, tile_row.p);
     // 7b. interleave the locus lists inside each tile (tile membership and sizes are unchanged)
-    if (interleave) {
+    if (interleave || streams) {
         DevBuf<uint32_t> gflag, gpos, gstart, gord, ident, perm, hrow2, npm2;
         DevBuf<uint64_t> ikey, ikey2;
         DevBuf<double> weight2;
-        GBRS_TRY(gflag.alloc(M)); GBRS_TRY(gpos.alloc(M)); GBRS_TRY(gstart.alloc(M)); GBRS_TRY(gord.alloc(M));
-        hipLaunchKernelGGL(group_flag_kernel, dim3(grid_for(M)), dim3(256), 0, s, M, dnew.p, tflag.p, gflag.p, gpos.p);
-        {
-            size_t bytes = 0;
-            GBRS_PRIM(rocprim::inclusive_scan(nullptr, bytes, gpos.p, gstart.p, (size_t)M, rocprim::maximum<uint32_t>(), s));
-            GBRS_TRY(sc.reserve(bytes));
-            GBRS_PRIM(rocprim::inclusive_scan(sc.buf.p, bytes, gpos.p, gstart.p, (size_t)M, rocprim::maximum<uint32_t>(), s));
+        if (interleave) {
+            GBRS_TRY(gflag.alloc(M)); GBRS_TRY(gpos.alloc(M)); GBRS_TRY(gstart.alloc(M)); GBRS_TRY(gord.alloc(M));
+            hipLaunchKernelGGL(group_flag_kernel, dim3(grid_for(M)), dim3(256), 0, s, M, dnew.p, tflag.p, gflag.p, gpos.p);
+            {
+                size_t bytes = 0;
+                GBRS_PRIM(rocprim::inclusive_scan(nullptr, bytes, gpos.p, gstart.p, (size_t)M, rocprim::maximum<uint32_t>(), s));
+                GBRS_TRY(sc.reserve(bytes));
+                GBRS_PRIM(rocprim::inclusive_scan(sc.buf.p, bytes, gpos.p, gstart.p, (size_t)M, rocprim::maximum<uint32_t>(), s));
+            }
+            GBRS_TRY(inclusive_scan(sc, gflag.p, gord.p, M, s));
+            GBRS_HIP_CHECK(hipStreamSynchronize(s));
+            gflag.release(); gpos.release();
         }
-        GBRS_TRY(inclusive_scan(sc, gflag.p, gord.p, M, s));
-        GBRS_HIP_CHECK(hipStreamSynchronize(s));
-        gflag.release(); gpos.release();
         GBRS_TRY(ikey.alloc(M)); GBRS_TRY(ikey2.alloc(M)); GBRS_TRY(ident.alloc(M)); GBRS_TRY(perm.alloc(M));
-        hipLaunchKernelGGL(interleave_key_kernel, dim3(grid_for(M)), dim3(256), 0, s, M, tincl.p, gstart.p, gord.p, ikey.p,
-                           ident.p);
+        if (interleave)
+            hipLaunchKernelGGL(interleave_key_kernel, dim3(grid_for(M)), dim3(256), 0, s, M, tincl.p, gstart.p, gord.p,
+                               ikey.p, ident.p);
+        else
+            hipLaunchKernelGGL(stream_key_kernel, dim3(grid_for(M)), dim3(256), 0, s, M, tincl.p, npm.p, ikey.p, ident.p);
         GBRS_TRY(sort_pairs<uint64_t>(sc, ikey.p, ikey2.p, ident.p, perm.p, M, 40 + bits_for(T), s));
         GBRS_HIP_CHECK(hipStreamSynchronize(s));
         ikey.release(); ikey2.release(); ident.release(); gstart.release(); gord.release();
@@ -943,7 +976,8 @@ int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L, uint32_t H, uint6
     // 8. padding so that no row straddles a batch, batch offsets
     DevBuf<uint32_t> rowpad, nbatch, batch_base;
     GBRS_TRY(rowpad.alloc(M)); GBRS_TRY(nbatch.alloc(T)); GBRS_TRY(batch_base.alloc(T));
-    hipLaunchKernelGGL(tile_pad_kernel, dim3(grid_for(T, 64)), dim3(64), 0, s, T, tile_row.p, npm.p, rowpad.p, nbatch.p);
+    hipLaunchKernelGGL(tile_pad_kernel, dim3(grid_for(T, 64)), dim3(64), 0, s, T, streams ? 1 : 0, tile_row.p, npm.p, rowpad.p,
+                       nbatch.p);
     GBRS_TRY(exclusive_scan(sc, nbatch.p, batch_base.p, T, s));
     uint32_t NB = 0;
     GBRS_TRY(fetch_last_plus(batch_base.p, nbatch.p, T, NB, s));

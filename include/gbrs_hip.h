@@ -64,11 +64,16 @@ typedef struct gbrs_em gbrs_em_t;
 /* Keep the reference's CSC arrays as the device layout (two passes with global float64 atomics).
  * The default is the packed-row-tile layout; this one is the simple cross-check. */
 #define GBRS_EM_LAYOUT_CSC 2u
-/* Tuning switches for the order of rows inside a tile.  Interleaving deals the tile's locus lists
- * round-robin across the 64 lanes of a batch (fewer LDS atomic conflicts when every row is a
- * distinct pattern); by default it is on iff `count` is given or rows are merged. */
+/* Tuning switches for the order of rows inside a tile.
+ * Stream order (default): rows are grouped by length and each group of 64/len lanes walks its own
+ * contiguous run of the tile's sorted rows over successive batches, so a lane stays on one locus
+ * list for long stretches and the per-lane register accumulation rarely spills to LDS atomics.
+ * GBRS_EM_NO_STREAMS falls back to the previous defaults: sorted order for raw reads, interleaved
+ * order (locus lists dealt round-robin across the 64 lanes of a batch) when `count` is given or
+ * rows are merged; GBRS_EM_NO_INTERLEAVE / GBRS_EM_FORCE_INTERLEAVE select among those two. */
 #define GBRS_EM_NO_INTERLEAVE 4u
 #define GBRS_EM_FORCE_INTERLEAVE 8u
+#define GBRS_EM_NO_STREAMS 16u
 
 /*
  * Replaces: AlignmentPropertyMatrix(h5file=...) as consumed by EMfactory.__init__
