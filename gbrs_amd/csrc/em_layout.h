@@ -20,7 +20,10 @@ namespace gbrs {
 
 constexpr int TILE_THREADS = 512;              // 8 waves per workgroup
 constexpr int TILE_WAVES = TILE_THREADS / 64;
-constexpr int TILE_WORDS = 8192 - 64;          // unpadded words per tile (sort capacity 8192)
+#ifndef GBRS_TILE_CAP
+#define GBRS_TILE_CAP 8192
+#endif
+constexpr int TILE_WORDS = GBRS_TILE_CAP - 64;  // unpadded words per tile (sort capacity GBRS_TILE_CAP)
 // rows with more distinct loci than this go to the long-row path
 __host__ __device__ constexpr int pos_bits(int H) { return H <= 8 ? 5 : 4; }
 __host__ __device__ constexpr int max_row_words(int H) { return 1 << pos_bits(H); }

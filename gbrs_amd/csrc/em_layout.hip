@@ -339,7 +339,7 @@ __global__ void tile_pad_kernel(uint64_t n_tiles, int streams, const uint32_t *_
 }
 
 // one workgroup per tile: sorted unique loci of the tile -> tmpdict[t * dcap ...], dcount[t]
-constexpr int SORT_CAP = 8192;
+constexpr int SORT_CAP = GBRS_TILE_CAP;
 __global__ void __launch_bounds__(512)
 tile_dict_kernel(uint32_t dcap, const uint32_t *__restrict__ tile_row, const uint32_t *__restrict__ hrow,
                  const uint32_t *__restrict__ rowstart, const uint32_t *__restrict__ ploc,
