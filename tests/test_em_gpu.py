@@ -12,7 +12,10 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-9
 
 
-LAYOUTS = {"tiles": dict(), "tiles_merged": dict(merge_identical_rows=True), "csc": dict(csc_layout=True)}
+# tiles = packed row tiles in the default stream order; the other row orders stay reachable through
+# GBRS_EM_NO_STREAMS (16: sorted order, or interleaved when rows are distinct patterns)
+LAYOUTS = {"tiles": dict(), "tiles_merged": dict(merge_identical_rows=True), "csc": dict(csc_layout=True),
+           "tiles_sorted": dict(extra_flags=16), "tiles_merged_interleaved": dict(merge_identical_rows=True, extra_flags=16)}
 
 
 def make_factory(g, layout="tiles"):
