@@ -1499,10 +1499,13 @@ int hmm_alloc_samples(gbrs_hmm *h, int n_samples) {
 #define HMM_HOIST_D 18
 #endif
 #ifndef HMM_SB
-#define HMM_SB 4          // samples per wave once n_samples >= HMM_SB
+#define HMM_SB 2          // samples per wave in large batches (n_samples >= HMM_BATCH_MIN)
+#endif
+#ifndef HMM_BATCH_MIN
+#define HMM_BATCH_MIN 24  // below this every sample gets waves of its own (measured: 16 samples 3.4 vs 3.6 ms, 32 samples 5.1 vs 4.8 ms)
 #endif
 #ifndef HMM_NSET_B
-#define HMM_NSET_B 2      // register sets of the HMM_SB-samples-per-wave recursions
+#define HMM_NSET_B 3      // register sets of the HMM_SB-samples-per-wave recursions
 #endif
 
 // SS_WAVE > 0: the single-wave chain kernels for that (even, <= 64) state count; otherwise KMAX / MAXT /
@@ -1542,10 +1545,9 @@ int hmm_launch(gbrs_hmm *h) {
         std::function<void(hipStream_t)> launch_alpha, launch_back, launch_delta;
         if constexpr (WAVE) {
             constexpr int SS = SS_WAVE;
-            // Few samples: one sample per wave and a 3-deep prefetch ring (latency).  Many samples:
-            // HMM_SB samples share each wave's transition registers and 2 sets suffice (throughput:
-            // a quarter of the block loads per sample and two waves per SIMD).
-            const bool batched = h->n_samples >= HMM_SB;
+            // Few samples: one sample per wave (latency).  Many samples: HMM_SB samples share each wave's
+            // transition registers (half the block loads per sample; measured best of 1-8 at 64 samples).
+            const bool batched = h->n_samples >= HMM_BATCH_MIN;
             const dim3 wave_grid(batched ? (h->n_samples + HMM_SB - 1) / HMM_SB : h->n_samples, h->n_chrom);
             // While every chain's wave can have a CU of its own, ask for more than half a CU's LDS per
             // workgroup: the dispatcher then cannot stack two of these single-wave workgroups on one

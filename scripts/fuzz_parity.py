@@ -59,7 +59,7 @@ def hmm_case(rng):
     H = int(rng.choice([2, 3, 4, 5, 7, 8, 8, 8, 9, 16]))
     nch = int(rng.integers(1, 6))
     lens = [int(x) for x in rng.integers(1, 90 if H == 16 else 400, size=nch)]
-    ns = int(rng.choice([1, 1, 2, 4, 5, 7]))
+    ns = int(rng.choice([1, 1, 2, 4, 5, 7, 25]))
     minus_one = bool(rng.integers(0, 2))
     seed = int(rng.integers(1, 1 << 30))
     probs = [synth.make_hmm_problem(H=H, genes_per_chrom=lens, seed=seed + s, tprob_len_minus_one=minus_one)

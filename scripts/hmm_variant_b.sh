@@ -1,0 +1,9 @@
+#!/bin/bash
+# Tuning aid (GPU box): build hmm.hip with extra -D flags and run the HMM bench with a given batch size.
+# Usage: bash scripts/hmm_variant_b.sh OUT BATCH "-DFLAG ..."
+OUT=$1; shift
+B=$1; shift
+mkdir -p $(dirname $OUT)
+GBRS_HIPCC_EXTRA="$*" python -c "import __graft_entry__ as g; g.build()" > /dev/null 2>&1
+python bench.py --rows 200000 --steps 2 --warmup 1 --no-cpu-baseline --no-merged-line --hmm-batch $B > $OUT 2>&1
+GBRS_HIPCC_EXTRA="-DGBRS_FULL" python -c "import __graft_entry__ as g; g.build()" > /dev/null 2>&1

@@ -128,7 +128,7 @@ def test_hmm_full_size_properties():
     hmm.close()
 
 
-@pytest.mark.parametrize("n_samples", [1, 4, 5, 9])
+@pytest.mark.parametrize("n_samples", [1, 4, 5, 25])
 @pytest.mark.parametrize("minus_one", [False, True], ids=["tprob_n", "tprob_n_minus_1"])
 def test_hmm_sample_batches_and_short_chromosomes(n_samples, minus_one):
     """8 founders (the single-wave kernels): distinct samples in one launch, including batch sizes
