@@ -38,8 +38,11 @@ __device__ __forceinline__ double seq_norm(const double *v, int H, int stride) {
 // 64 different lines per instruction).  The lanes of a gene split the unit-row pass by rows and the
 // diplotype pass by states; every per-gene reduction the reference does with builtin sum() is
 // still evaluated sequentially in its order (each lane repeats it), so results do not depend on
-// the split.  A 16-gene block needs 14 KB of LDS at H = 8: ~11 resident waves per CU.
-constexpr int EM_LANES = 4;
+// the split.  An 8-gene block (8 lanes per gene, measured best of 2-16) needs 7 KB of LDS at H = 8.
+#ifndef HMM_EM_LANES
+#define HMM_EM_LANES 8
+#endif
+constexpr int EM_LANES = HMM_EM_LANES;
 constexpr int EM_GENES = 64 / EM_LANES;
 
 __global__ void __launch_bounds__(64)
