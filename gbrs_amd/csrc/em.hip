@@ -432,31 +432,32 @@ int em_check_float(gbrs_em *em, EmScalars &host) {
 }
 
 // E-step over the tiled layout: tiles -> partials, long rows -> acc_extra, gather -> acc.
+ErrArgs em_err_args(gbrs_em *em, double target_err);
+int em_flush_err(gbrs_em *em);
+
 template <int HT, bool ONES>
 int em_estep_tiles_h(gbrs_em *em) {
     const TileLayout &tl = em->tl;
     if (tl.n_tiles) {
-        const dim3 grid((unsigned)tl.n_tiles), block(TILE_THREADS);
+        // a deferred error pass of the previous step rides on this launch as extra workgroups
+        ErrArgs ea = em_err_args(em, em->err_pending_target);
+        if (ONES || !em->err_pending) ea.n_err_blocks = 0;
+        em->err_pending = false;
+        const dim3 grid((unsigned)tl.n_tiles + ea.n_err_blocks), block(TILE_THREADS);
         if (tl.weighted)
             hipLaunchKernelGGL((tile_estep_kernel<HT, true, ONES>), grid, block, 0, em->stream, em->H, tl.tiles.p,
                                tl.words.p, tl.dict.p, tl.word_weight.p, em->theta.p, tl.partials.p, tl.slot_dest.p,
-                               em->acc.p, em->scalars.p);
+                               em->acc.p, em->scalars.p, (uint32_t)tl.n_tiles, ea);
         else
             hipLaunchKernelGGL((tile_estep_kernel<HT, false, ONES>), grid, block, 0, em->stream, em->H, tl.tiles.p,
                                tl.words.p, tl.dict.p, (const double *)nullptr, em->theta.p, tl.partials.p,
-                               tl.slot_dest.p, em->acc.p, em->scalars.p);
+                               tl.slot_dest.p, em->acc.p, em->scalars.p, (uint32_t)tl.n_tiles, ea);
     }
     return GBRS_OK;
 }
-
-// materialize: write the full A into em->acc (needed before an all-reduce); otherwise only the
-// heavy loci are gathered here and the M-step kernel gathers the rest itself.
-ErrArgs em_err_args(gbrs_em *em, double target_err);
-int em_flush_err(gbrs_em *em);
-
 template <bool ONES>
-int em_estep_tiles(gbrs_em *em, bool materialize) {
-    if (ONES) GBRS_TRY(em_flush_err(em));        // prepare: nothing may be pending across it
+int em_estep_tiles(gbrs_em *em, bool materialize, bool skip_gather = false) {
+    if (ONES || !em->tl.n_tiles) GBRS_TRY(em_flush_err(em));   // prepare / no tile launch to ride on
 
     TileLayout &tl = em->tl;
     switch (em->H) {
@@ -485,16 +486,13 @@ int em_estep_tiles(gbrs_em *em, bool materialize) {
     const unsigned light = (unsigned)((elems + 255) / 256);
     const unsigned heavy = (unsigned)((tl.n_heavy + 3) / 4);
     em->acc_needs_extra = !all && tl.n_long > 0;
-    // a deferred error pass of the previous step rides on this launch as extra workgroups
-    ErrArgs ea = em_err_args(em, em->err_pending_target);
-    if (ONES || !em->err_pending) ea.n_err_blocks = 0;
-    em->err_pending = false;
-    if (light + heavy + ea.n_err_blocks > 0)
-        hipLaunchKernelGGL(gather_kernel, dim3(light + heavy + ea.n_err_blocks), dim3(256), 0, em->stream, em->L, em->H,
+    if (skip_gather) return GBRS_OK;           // the fused gather + M-step kernel follows (em_one_step)
+    if (light + heavy > 0)
+        hipLaunchKernelGGL(gather_kernel, dim3(light + heavy), dim3(256), 0, em->stream, em->L, em->H,
                            HP, light, heavy, (uint32_t)tl.n_heavy, all ? 1 : 0, (uint32_t)tl.n_light, tl.light_loci.p,
                            tl.slot_ptr.p, tl.slot_list.p, tl.heavy_loci.p, tl.locus_class.p, tl.partials.p,
                            (tl.n_long && all) ? tl.acc_extra.p : (const double *)nullptr, em->acc.p, em->scalars.p,
-                           ONES ? 0 : 1, ea);
+                           ONES ? 0 : 1);
     GBRS_HIP_CHECK(hipGetLastError());
     return GBRS_OK;
 }
