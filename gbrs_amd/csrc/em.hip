@@ -517,6 +517,95 @@ int em_estep(gbrs_em *em, bool materialize = false) {
     return GBRS_OK;
 }
 
+// Gather + M-step in one launch (tile layout, H a power of two, single GPU): an element of a locus
+// with at most one slot takes A straight from `acc` (written by the tile epilogue), a locus with a
+// few slots sums them in place, and the loci with many slots get one wavefront each (the trailing
+// workgroups), which reduces the slots in fixed order and applies the M-step to that locus itself.
+// No intermediate A vector is written for the gathered loci and there is one launch less per step.
+__global__ void __launch_bounds__(RED_THREADS)
+mstep_gather_kernel(uint32_t L, uint32_t H, uint32_t HP, uint32_t heavy_blocks, uint32_t n_heavy,
+                    const uint32_t *__restrict__ slot_ptr, const uint32_t *__restrict__ slot_list,
+                    const uint32_t *__restrict__ heavy_loci, const uint8_t *__restrict__ locus_class,
+                    const double *__restrict__ slot_sums, const double *__restrict__ acc,
+                    const double *__restrict__ acc_extra, double *__restrict__ theta,
+                    const double *__restrict__ eff_len, double *__restrict__ counts, double *__restrict__ tot_prev,
+                    double *__restrict__ tot_new, double *__restrict__ partials, const EmScalars *__restrict__ sc) {
+    __shared__ double lds[16];
+    if (sc->stop) return;
+    double t = 0.0, tn = 0.0;
+    // the heavy workgroups come first in the grid: their long dependent chains (hundreds of slots per
+    // locus) start at once and overlap with the elementwise workgroups
+    if (blockIdx.x >= heavy_blocks) {
+        const uint64_t n = (uint64_t)L * H;
+        const uint64_t i = (uint64_t)(blockIdx.x - heavy_blocks) * blockDim.x + threadIdx.x;
+        if (i < n) {
+            const uint32_t l = (uint32_t)(i / H), h = (uint32_t)(i & (H - 1));
+            const uint32_t cls = locus_class[l];
+            if (cls != 3) {                               // class 3: the heavy workgroups below
+                double a;
+                if (cls == 2) {
+                    a = 0.0;
+                    const uint32_t k0 = slot_ptr[l], k1 = slot_ptr[l + 1];
+                    for (uint32_t k = k0; k < k1; ++k) a += slot_sums[(size_t)slot_list[k] * H + h];
+                } else {
+                    a = acc[i];                           // one slot: stored by its tile; none: stays 0
+                }
+                if (acc_extra) a += acc_extra[i];
+                t = theta[i];
+                const double c = t * a;
+                tn = eff_len ? c / eff_len[i] : c;
+                counts[i] = c;
+                theta[i] = tn;
+            }
+            double tp = t, tq = tn;                       // the H lanes of a locus are adjacent, same class
+            for (uint32_t off = 1; off < H; off <<= 1) {
+                tp += __shfl_xor(tp, off, WAVE);
+                tq += __shfl_xor(tq, off, WAVE);
+            }
+            if (h == 0 && cls != 3) {
+                tot_prev[l] = tp;
+                tot_new[l] = tq;
+            }
+        }
+    } else {
+        const uint32_t hv = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        if (hv < n_heavy) {
+            const uint32_t l = heavy_loci[hv];
+            const int lane = threadIdx.x & 63;
+            const uint32_t h = lane & (HP - 1), sub = lane / HP, nsub = 64 / HP;
+            const uint32_t k0 = slot_ptr[l], k1 = slot_ptr[l + 1];
+            double a = 0.0;
+            if (h < H)
+                for (uint32_t k = k0 + sub; k < k1; k += nsub) a += slot_sums[(size_t)slot_list[k] * H + h];
+            for (uint32_t off = HP; off < 64; off <<= 1) a += __shfl_xor(a, off, WAVE);
+            if (sub == 0 && h < H) {
+                const size_t i = (size_t)l * H + h;
+                if (acc_extra) a += acc_extra[i];
+                t = theta[i];
+                const double c = t * a;
+                tn = eff_len ? c / eff_len[i] : c;
+                counts[i] = c;
+                theta[i] = tn;
+            }
+            double tp = t, tq = tn;                       // lanes 0 .. H-1 hold the locus, the others 0
+            for (uint32_t off = 1; off < HP; off <<= 1) {
+                tp += __shfl_xor(tp, off, WAVE);
+                tq += __shfl_xor(tq, off, WAVE);
+            }
+            if (lane == 0) {
+                tot_prev[l] = tp;
+                tot_new[l] = tq;
+            }
+        }
+    }
+    const double a = block_sum(t, lds);
+    const double b = block_sum(tn, lds);
+    if (threadIdx.x == 0) {
+        atomicAdd(&partials[blockIdx.x % RED_BLOCKS], a);
+        atomicAdd(&partials[RED_BLOCKS + blockIdx.x % RED_BLOCKS], b);
+    }
+}
+
 // M-step launch: element-parallel when H is a power of two, thread-per-locus otherwise.
 template <int MODE>
 int em_launch_mstep(gbrs_em *em) {
@@ -565,9 +654,32 @@ int em_flush_err(gbrs_em *em) {
 
 // Everything after the E-step of one EM iteration.  `defer`: leave the error pass to the next
 // step's gather launch (em_estep_tiles) or to em_flush_err.
-int em_finish_step(gbrs_em *em, double target_err, bool defer = false) {
+// tile layout, H a power of two, A not handed out for an all-reduce: gather and M-step share a launch
+bool em_can_fuse_mstep(const gbrs_em *em) {
+    static const bool off = [] { const char *e = std::getenv("GBRS_TUNING_NO_FUSED_MSTEP"); return e && std::atoi(e) != 0; }();
+    return !off && em->layout == 1 && (em->H & (em->H - 1)) == 0 && !em->acc_external;
+}
+
+int em_launch_mstep_gather(gbrs_em *em) {
+    const TileLayout &tl = em->tl;
+    uint32_t HP = 1;
+    while (HP < em->H) HP <<= 1;
+    const uint64_t n = (uint64_t)em->L * em->H;
+    const unsigned elem_blocks = (unsigned)((n + RED_THREADS - 1) / RED_THREADS);
+    const unsigned heavy_blocks = (unsigned)((tl.n_heavy + RED_THREADS / 64 - 1) / (RED_THREADS / 64));
+    hipLaunchKernelGGL(mstep_gather_kernel, dim3(elem_blocks + heavy_blocks), dim3(RED_THREADS), 0, em->stream, em->L,
+                       em->H, HP, heavy_blocks, (uint32_t)tl.n_heavy, tl.slot_ptr.p, tl.slot_list.p, tl.heavy_loci.p,
+                       tl.locus_class.p, tl.partials.p, em->acc.p,
+                       tl.n_long ? tl.acc_extra.p : (const double *)nullptr, em->theta.p,
+                       em->has_len ? em->eff_len.p : (const double *)nullptr, em->counts.p, em->tot_prev.p,
+                       em->tot_new.p, em->partials.p, em->scalars.p);
+    return GBRS_OK;
+}
+
+int em_finish_step(gbrs_em *em, double target_err, bool defer = false, bool fused = false) {
     GBRS_TRY(em_flush_err(em));
-    GBRS_TRY(em_launch_mstep<0>(em));
+    if (fused) GBRS_TRY(em_launch_mstep_gather(em));
+    else GBRS_TRY(em_launch_mstep<0>(em));
     if (defer && em->layout == 1) {
         em->err_pending = true;
         em->err_pending_target = target_err;
@@ -588,10 +700,12 @@ int em_one_step(gbrs_em *em, double target_err, hipEvent_t *ev = nullptr, bool d
     if (timed) GBRS_HIP_CHECK(hipEventRecord(ev[0], em->stream));
     // ev[1] closes the E-step kernel itself (tile layout: before the gather; CSC layout: after the pass)
     em->ev_after_estep = timed && em->layout == 1 ? ev[1] : nullptr;
-    GBRS_TRY(em_estep<false>(em));
+    const bool fused = em_can_fuse_mstep(em);
+    if (fused) GBRS_TRY(em_estep_tiles<false>(em, false, /* skip_gather */ true));
+    else GBRS_TRY(em_estep<false>(em));
     em->ev_after_estep = nullptr;
     if (timed && em->layout != 1) GBRS_HIP_CHECK(hipEventRecord(ev[1], em->stream));
-    GBRS_TRY(em_finish_step(em, target_err, defer_err));
+    GBRS_TRY(em_finish_step(em, target_err, defer_err, fused));
     if (timed) GBRS_HIP_CHECK(hipEventRecord(ev[2], em->stream));
     return GBRS_OK;
 }
