@@ -728,6 +728,9 @@ int em_finish_prepare(gbrs_em *em, double pseudocount) {
                            (uint64_t)em->L * em->H, nb, em->theta.p, em->partials.p, em->scalars.p);
     }
     GBRS_HIP_CHECK(hipMemsetAsync(em->partials.p, 0, em->partials.bytes(), em->stream));
+    // A of the loci without any slot must read 0 in the steps (the tile path then writes only the loci
+    // it has rows for); prepare's full gather left the long rows' contribution there
+    GBRS_HIP_CHECK(hipMemsetAsync(em->acc.p, 0, em->acc.bytes(), em->stream));
     GBRS_HIP_CHECK(hipGetLastError());
     em->prepared = true;
     return GBRS_OK;
@@ -969,12 +972,19 @@ int gbrs_em_create_device(uint64_t R, uint32_t L, uint32_t H, const uint32_t *co
     return em_create_impl(R, L, H, indptr, indices, count, eff_len, device, flags, true, out);
 }
 
-int gbrs_em_prepare_partial(gbrs_em_t *em, void **partial_dev, uint64_t *n_elems) {
-    if (!em) return fail(GBRS_ERR_INVALID, "handle is NULL");
+namespace {
+// partial sums of count/nnz_row into em->acc (every element written)
+int em_prepare_partial(gbrs_em *em) {
     GBRS_TRY(select_device(em->device));
     GBRS_TRY(em_reset_scalars(em, false));
-    em->acc_external = true;
-    GBRS_TRY(em_estep<true>(em, true));
+    return em_estep<true>(em, true);
+}
+}  // namespace
+
+int gbrs_em_prepare_partial(gbrs_em_t *em, void **partial_dev, uint64_t *n_elems) {
+    if (!em) return fail(GBRS_ERR_INVALID, "handle is NULL");
+    em->acc_external = true;                  // sharded rows: the caller all-reduces the whole A vector from now on
+    GBRS_TRY(em_prepare_partial(em));
     if (partial_dev) *partial_dev = em->acc.p;
     if (n_elems) *n_elems = (uint64_t)em->L * em->H;
     return GBRS_OK;
@@ -989,7 +999,8 @@ int gbrs_em_finish_prepare(gbrs_em_t *em, double pseudocount) {
 }
 
 int gbrs_em_prepare(gbrs_em_t *em, double pseudocount) {
-    GBRS_TRY(gbrs_em_prepare_partial(em, nullptr, nullptr));
+    if (!em) return fail(GBRS_ERR_INVALID, "handle is NULL");
+    GBRS_TRY(em_prepare_partial(em));
     return gbrs_em_finish_prepare(em, pseudocount);
 }
 
