@@ -575,8 +575,22 @@ mstep_gather_kernel(uint32_t L, uint32_t H, uint32_t HP, uint32_t heavy_blocks, 
             const uint32_t h = lane & (HP - 1), sub = lane / HP, nsub = 64 / HP;
             const uint32_t k0 = slot_ptr[l], k1 = slot_ptr[l + 1];
             double a = 0.0;
-            if (h < H)
-                for (uint32_t k = k0 + sub; k < k1; k += nsub) a += slot_sums[(size_t)slot_list[k] * H + h];
+            if (h < H) {
+                // four independent slot chains per lane: the indirection slot_list -> slot_sums is two
+                // dependent loads per slot, and the largest loci have hundreds of slots
+                double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+                uint32_t k = k0 + sub;
+                for (; k + 3 * nsub < k1; k += 4 * nsub) {
+                    const uint32_t s0 = slot_list[k], s1 = slot_list[k + nsub], s2 = slot_list[k + 2 * nsub],
+                                   s3 = slot_list[k + 3 * nsub];
+                    a0 += slot_sums[(size_t)s0 * H + h];
+                    a1 += slot_sums[(size_t)s1 * H + h];
+                    a2 += slot_sums[(size_t)s2 * H + h];
+                    a3 += slot_sums[(size_t)s3 * H + h];
+                }
+                for (; k < k1; k += nsub) a0 += slot_sums[(size_t)slot_list[k] * H + h];
+                a = (a0 + a1) + (a2 + a3);
+            }
             for (uint32_t off = HP; off < 64; off <<= 1) a += __shfl_xor(a, off, WAVE);
             if (sub == 0 && h < H) {
                 const size_t i = (size_t)l * H + h;
