@@ -42,7 +42,7 @@ __global__ void __launch_bounds__(RED_THREADS)
 mstep_kernel(uint32_t L, uint32_t H, double *__restrict__ theta, const double *__restrict__ acc,
              const double *__restrict__ eff_len, double *__restrict__ counts,
              double *__restrict__ tot_prev, double *__restrict__ tot_new,
-             double *__restrict__ partials, const EmScalars *__restrict__ sc) {
+             double *__restrict__ msums, uint32_t cap, const EmScalars *__restrict__ sc) {
     __shared__ double lds[16];
     if (MODE == 0 && sc->stop) return;
     double p_prev = 0.0, p_new = 0.0;
@@ -67,8 +67,8 @@ mstep_kernel(uint32_t L, uint32_t H, double *__restrict__ theta, const double *_
     double a = block_sum(p_prev, lds);
     double b = block_sum(p_new, lds);
     if (threadIdx.x == 0) {
-        partials[blockIdx.x] = a;
-        partials[RED_BLOCKS + blockIdx.x] = b;
+        msums[blockIdx.x] = a;
+        msums[cap + blockIdx.x] = b;
     }
 }
 
@@ -87,7 +87,7 @@ __global__ void __launch_bounds__(RED_THREADS)
 mstep_elem_kernel(uint32_t L, uint32_t H, double *__restrict__ theta, const double *__restrict__ acc,
                   const double *__restrict__ acc_extra, const double *__restrict__ eff_len,
                   double *__restrict__ counts, double *__restrict__ tot_prev, double *__restrict__ tot_new,
-                  double *__restrict__ partials, const EmScalars *__restrict__ sc) {
+                  double *__restrict__ msums, uint32_t cap, const EmScalars *__restrict__ sc) {
     __shared__ double lds[16];
     if (MODE == 0 && sc->stop) return;
     const uint64_t n = (uint64_t)L * H;
@@ -114,9 +114,9 @@ mstep_elem_kernel(uint32_t L, uint32_t H, double *__restrict__ theta, const doub
     }
     double a = block_sum(t, lds);
     double b = block_sum(tn, lds);
-    if (threadIdx.x == 0) {
-        atomicAdd(&partials[blockIdx.x % RED_BLOCKS], a);
-        atomicAdd(&partials[RED_BLOCKS + blockIdx.x % RED_BLOCKS], b);
+    if (threadIdx.x == 0) {                 // one slot per workgroup: no atomics, and a fixed summation order
+        msums[blockIdx.x] = a;
+        msums[cap + blockIdx.x] = b;
     }
 }
 
@@ -129,7 +129,8 @@ constexpr int ERR_BLOCKS = 64;
 // Arguments of the error pass, as one value: gather_kernel carries them for the deferred form.
 struct ErrArgs {
     uint32_t L;
-    int nblocks;                 // M-step accumulator slots in use (RED_BLOCKS)
+    int nblocks;                 // workgroups of the M-step launch = block sums to add up
+    uint32_t cap;                // offset of the second block-sum array / of the error partials (x2)
     const double *tot_prev, *tot_new;
     double *partials;
     EmScalars *sc;
@@ -154,7 +155,7 @@ __device__ __forceinline__ void err_finish_body(const ErrArgs &ea, unsigned bid)
     __shared__ int s_last;
     if (sc->stop) return;
     double a = reduce_partials(partials, nblocks, lds);
-    double b = reduce_partials(partials + RED_BLOCKS, nblocks, lds);
+    double b = reduce_partials(partials + ea.cap, nblocks, lds);
     if (threadIdx.x == 0) {
         s_sums[0] = a;
         s_sums[1] = b;
@@ -166,7 +167,7 @@ __device__ __forceinline__ void err_finish_body(const ErrArgs &ea, unsigned bid)
         e += fabs(tot_new[l] * cn - tot_prev[l] * cp);
     e = block_sum(e, lds);
     if (threadIdx.x == 0) {
-        partials[2 * RED_BLOCKS + bid] = e;
+        partials[2 * (size_t)ea.cap + bid] = e;
         __threadfence();                                        // publish before the ticket
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (the compiler may drop the fence's own wait)
         const int ticket = atomicAdd(&sc->ticket, 1);
@@ -177,9 +178,8 @@ __device__ __forceinline__ void err_finish_body(const ErrArgs &ea, unsigned bid)
     if (!s_last) return;
     double tot = 0.0;
     for (int i = threadIdx.x; i < (int)nb; i += blockDim.x)
-        tot += __hip_atomic_load(&partials[2 * RED_BLOCKS + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        tot += __hip_atomic_load(&partials[2 * (size_t)ea.cap + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     tot = block_sum(tot, lds);
-    for (int i = threadIdx.x; i < 2 * RED_BLOCKS; i += blockDim.x) partials[i] = 0.0;   // for the next M-step
     if (threadIdx.x == 0) {
         sc->ticket = 0;
         sc->s_prev = s_sums[0];
@@ -399,7 +399,9 @@ struct gbrs_em {
     DevBuf<double> count, eff_len;                 // R ; L*H locus-major
     DevBuf<double> theta, acc, counts;             // L*H locus-major
     DevBuf<double> tot_prev, tot_new;              // L
-    DevBuf<double> partials;                       // 3 * RED_BLOCKS
+    DevBuf<double> partials;                       // 3 * RED_BLOCKS (pseudocount reductions)
+    DevBuf<double> msums;                          // M-step block sums [2][msum_cap] + ERR_BLOCKS error partials
+    uint32_t msum_cap = 0, msum_blocks = 0;        // capacity; workgroups of the last M-step launch
     DevBuf<double> scratch_hl;                     // L*H staging for host <-> device transposes
     DevBuf<double> err_hist;
     DevBuf<EmScalars> scalars;
@@ -522,6 +524,8 @@ int em_estep(gbrs_em *em, bool materialize = false) {
 // few slots sums them in place, and the loci with many slots get one wavefront each (the trailing
 // workgroups), which reduces the slots in fixed order and applies the M-step to that locus itself.
 // No intermediate A vector is written for the gathered loci and there is one launch less per step.
+constexpr int MSTEP_EPT = 4;       // elements per thread of the elementwise workgroups
+constexpr int GATHER_CHAINS = 4;   // independent loads in flight per lane of a many-slot locus
 __global__ void __launch_bounds__(RED_THREADS)
 mstep_gather_kernel(uint32_t L, uint32_t H, uint32_t HP, uint32_t heavy_blocks, uint32_t n_heavy,
                     const uint32_t *__restrict__ slot_ptr, const uint32_t *__restrict__ slot_list,
@@ -529,43 +533,64 @@ mstep_gather_kernel(uint32_t L, uint32_t H, uint32_t HP, uint32_t heavy_blocks, 
                     const double *__restrict__ slot_sums, const double *__restrict__ acc,
                     const double *__restrict__ acc_extra, double *__restrict__ theta,
                     const double *__restrict__ eff_len, double *__restrict__ counts, double *__restrict__ tot_prev,
-                    double *__restrict__ tot_new, double *__restrict__ partials, const EmScalars *__restrict__ sc) {
+                    double *__restrict__ tot_new, double *__restrict__ msums, uint32_t cap,
+                    const EmScalars *__restrict__ sc) {
     __shared__ double lds[16];
     if (sc->stop) return;
     double t = 0.0, tn = 0.0;
     // the heavy workgroups come first in the grid: their long dependent chains (hundreds of slots per
     // locus) start at once and overlap with the elementwise workgroups
     if (blockIdx.x >= heavy_blocks) {
+        // MSTEP_EPT elements per thread, all loads of the batch issued before the arithmetic: the
+        // kernel is a chain of dependent global loads per element, so the win is memory-level
+        // parallelism, not fewer instructions
         const uint64_t n = (uint64_t)L * H;
-        const uint64_t i = (uint64_t)(blockIdx.x - heavy_blocks) * blockDim.x + threadIdx.x;
-        if (i < n) {
-            const uint32_t l = (uint32_t)(i / H), h = (uint32_t)(i & (H - 1));
-            const uint32_t cls = locus_class[l];
-            if (cls != 3) {                               // class 3: the heavy workgroups below
-                double a;
-                if (cls == 2) {
-                    a = 0.0;
-                    const uint32_t k0 = slot_ptr[l], k1 = slot_ptr[l + 1];
-                    for (uint32_t k = k0; k < k1; ++k) a += slot_sums[(size_t)slot_list[k] * H + h];
-                } else {
-                    a = acc[i];                           // one slot: stored by its tile; none: stays 0
-                }
-                if (acc_extra) a += acc_extra[i];
-                t = theta[i];
-                const double c = t * a;
-                tn = eff_len ? c / eff_len[i] : c;
-                counts[i] = c;
-                theta[i] = tn;
+        const uint64_t i0 = (uint64_t)(blockIdx.x - heavy_blocks) * MSTEP_EPT * blockDim.x + threadIdx.x;
+        uint32_t cls[MSTEP_EPT];
+        double av[MSTEP_EPT], tv[MSTEP_EPT], lv[MSTEP_EPT];
+#pragma unroll
+        for (int e = 0; e < MSTEP_EPT; ++e) {
+            const uint64_t i = i0 + (uint64_t)e * blockDim.x;
+            cls[e] = 3;
+            av[e] = tv[e] = 0.0;
+            lv[e] = 1.0;
+            if (i < n) {
+                cls[e] = locus_class[(uint32_t)(i / H)];
+                tv[e] = theta[i];
+                av[e] = acc[i];                           // one slot: stored by its tile; none: stays 0
+                if (acc_extra) av[e] += acc_extra[i];
+                if (eff_len) lv[e] = eff_len[i];
             }
-            double tp = t, tq = tn;                       // the H lanes of a locus are adjacent, same class
+        }
+#pragma unroll
+        for (int e = 0; e < MSTEP_EPT; ++e) {
+            const uint64_t i = i0 + (uint64_t)e * blockDim.x;
+            const uint32_t l = (uint32_t)(i / H), h = (uint32_t)(i & (H - 1));
+            double te = 0.0, tne = 0.0;
+            if (i < n && cls[e] != 3) {                   // class 3: the heavy workgroups
+                double a = av[e];
+                if (cls[e] == 2) {                        // a few slots: summed in place
+                    a = acc_extra ? acc_extra[i] : 0.0;
+                    const uint32_t k0 = slot_ptr[l], k1 = slot_ptr[l + 1];
+                    for (uint32_t k = k0; k < k1; ++k) a += slot_sums[(size_t)k * H + h];
+                }
+                te = tv[e];
+                const double c = te * a;
+                tne = eff_len ? c / lv[e] : c;
+                counts[i] = c;
+                theta[i] = tne;
+            }
+            double tp = te, tq = tne;                     // the H lanes of a locus are adjacent, same class
             for (uint32_t off = 1; off < H; off <<= 1) {
                 tp += __shfl_xor(tp, off, WAVE);
                 tq += __shfl_xor(tq, off, WAVE);
             }
-            if (h == 0 && cls != 3) {
+            if (i < n && h == 0 && cls[e] != 3) {
                 tot_prev[l] = tp;
                 tot_new[l] = tq;
             }
+            t += te;
+            tn += tne;
         }
     } else {
         const uint32_t hv = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -576,20 +601,23 @@ mstep_gather_kernel(uint32_t L, uint32_t H, uint32_t HP, uint32_t heavy_blocks, 
             const uint32_t k0 = slot_ptr[l], k1 = slot_ptr[l + 1];
             double a = 0.0;
             if (h < H) {
-                // four independent slot chains per lane: the indirection slot_list -> slot_sums is two
-                // dependent loads per slot, and the largest loci have hundreds of slots
-                double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+                // GATHER_CHAINS independent chains per lane over the locus's consecutive slot rows: the rows
+                // were written by tiles all over the chip a moment ago, every load is a ~0.6 us miss, and
+                // the largest loci have hundreds of slots
+                double ac[GATHER_CHAINS];
+#pragma unroll
+                for (int c = 0; c < GATHER_CHAINS; ++c) ac[c] = 0.0;
                 uint32_t k = k0 + sub;
-                for (; k + 3 * nsub < k1; k += 4 * nsub) {
-                    const uint32_t s0 = slot_list[k], s1 = slot_list[k + nsub], s2 = slot_list[k + 2 * nsub],
-                                   s3 = slot_list[k + 3 * nsub];
-                    a0 += slot_sums[(size_t)s0 * H + h];
-                    a1 += slot_sums[(size_t)s1 * H + h];
-                    a2 += slot_sums[(size_t)s2 * H + h];
-                    a3 += slot_sums[(size_t)s3 * H + h];
+                for (; k + (GATHER_CHAINS - 1) * nsub < k1; k += GATHER_CHAINS * nsub) {
+#pragma unroll
+                    for (int c = 0; c < GATHER_CHAINS; ++c) ac[c] += slot_sums[(size_t)(k + c * nsub) * H + h];
                 }
-                for (; k < k1; k += nsub) a0 += slot_sums[(size_t)slot_list[k] * H + h];
-                a = (a0 + a1) + (a2 + a3);
+                for (; k < k1; k += nsub) ac[0] += slot_sums[(size_t)k * H + h];
+#pragma unroll
+                for (int w = 1; w < GATHER_CHAINS; w <<= 1)
+#pragma unroll
+                    for (int c = 0; c + w < GATHER_CHAINS; c += 2 * w) ac[c] += ac[c + w];
+                a = ac[0];
             }
             for (uint32_t off = HP; off < 64; off <<= 1) a += __shfl_xor(a, off, WAVE);
             if (sub == 0 && h < H) {
@@ -615,8 +643,8 @@ mstep_gather_kernel(uint32_t L, uint32_t H, uint32_t HP, uint32_t heavy_blocks, 
     const double a = block_sum(t, lds);
     const double b = block_sum(tn, lds);
     if (threadIdx.x == 0) {
-        atomicAdd(&partials[blockIdx.x % RED_BLOCKS], a);
-        atomicAdd(&partials[RED_BLOCKS + blockIdx.x % RED_BLOCKS], b);
+        msums[blockIdx.x] = a;
+        msums[cap + blockIdx.x] = b;
     }
 }
 
@@ -627,16 +655,18 @@ int em_launch_mstep(gbrs_em *em) {
     const double *len = em->has_len ? em->eff_len.p : nullptr;
     if (!pow2) {
         const int nb = em->red_blocks();
+        em->msum_blocks = nb;
         hipLaunchKernelGGL(mstep_kernel<MODE>, dim3(nb), dim3(RED_THREADS), 0, em->stream, em->L, em->H,
                            em->theta.p, em->acc.p, len, em->counts.p, em->tot_prev.p, em->tot_new.p,
-                           em->partials.p, em->scalars.p);
+                           em->msums.p, em->msum_cap, em->scalars.p);
         return GBRS_OK;
     }
     const uint64_t n = (uint64_t)em->L * em->H;
     const unsigned nb = (unsigned)((n + RED_THREADS - 1) / RED_THREADS);
+    em->msum_blocks = nb;
     hipLaunchKernelGGL(mstep_elem_kernel<MODE>, dim3(nb), dim3(RED_THREADS), 0, em->stream, em->L, em->H, em->theta.p,
                        em->acc.p, em->acc_needs_extra ? em->tl.acc_extra.p : (const double *)nullptr, len,
-                       em->counts.p, em->tot_prev.p, em->tot_new.p, em->partials.p, em->scalars.p);
+                       em->counts.p, em->tot_prev.p, em->tot_new.p, em->msums.p, em->msum_cap, em->scalars.p);
     return GBRS_OK;
 }
 
@@ -644,10 +674,11 @@ int em_launch_mstep(gbrs_em *em) {
 ErrArgs em_err_args(gbrs_em *em, double target_err) {
     ErrArgs ea;
     ea.L = em->L;
-    ea.nblocks = RED_BLOCKS;
+    ea.nblocks = (int)em->msum_blocks;
+    ea.cap = em->msum_cap;
     ea.tot_prev = em->tot_prev.p;
     ea.tot_new = em->tot_new.p;
-    ea.partials = em->partials.p;
+    ea.partials = em->msums.p;
     ea.sc = em->scalars.p;
     ea.target_err = target_err;
     ea.err_hist = em->err_hist.p;
@@ -679,14 +710,15 @@ int em_launch_mstep_gather(gbrs_em *em) {
     uint32_t HP = 1;
     while (HP < em->H) HP <<= 1;
     const uint64_t n = (uint64_t)em->L * em->H;
-    const unsigned elem_blocks = (unsigned)((n + RED_THREADS - 1) / RED_THREADS);
+    const unsigned elem_blocks = (unsigned)((n + (uint64_t)RED_THREADS * MSTEP_EPT - 1) / ((uint64_t)RED_THREADS * MSTEP_EPT));
     const unsigned heavy_blocks = (unsigned)((tl.n_heavy + RED_THREADS / 64 - 1) / (RED_THREADS / 64));
+    em->msum_blocks = elem_blocks + heavy_blocks;
     hipLaunchKernelGGL(mstep_gather_kernel, dim3(elem_blocks + heavy_blocks), dim3(RED_THREADS), 0, em->stream, em->L,
                        em->H, HP, heavy_blocks, (uint32_t)tl.n_heavy, tl.slot_ptr.p, tl.slot_list.p, tl.heavy_loci.p,
                        tl.locus_class.p, tl.partials.p, em->acc.p,
                        tl.n_long ? tl.acc_extra.p : (const double *)nullptr, em->theta.p,
                        em->has_len ? em->eff_len.p : (const double *)nullptr, em->counts.p, em->tot_prev.p,
-                       em->tot_new.p, em->partials.p, em->scalars.p);
+                       em->tot_new.p, em->msums.p, em->msum_cap, em->scalars.p);
     return GBRS_OK;
 }
 
@@ -851,11 +883,14 @@ int em_create_impl(uint64_t R, uint32_t L, uint32_t H, const uint32_t *const *in
     GBRS_TRY(em->tot_prev.alloc(L));
     GBRS_TRY(em->tot_new.alloc(L));
     GBRS_TRY(em->partials.alloc(3 * RED_BLOCKS));
+    em->msum_cap = (uint32_t)(((uint64_t)L * H + RED_THREADS - 1) / RED_THREADS + (L + 3) / 4 + RED_BLOCKS);
+    GBRS_TRY(em->msums.alloc(2 * (size_t)em->msum_cap + ERR_BLOCKS));
     GBRS_TRY(em->scalars.alloc(1));
     GBRS_HIP_CHECK(hipMemset(em->scalars.p, 0, sizeof(EmScalars)));
     GBRS_HIP_CHECK(hipMemset(em->theta.p, 0, em->theta.bytes()));
     GBRS_HIP_CHECK(hipMemset(em->acc.p, 0, em->acc.bytes()));
     GBRS_HIP_CHECK(hipMemset(em->partials.p, 0, em->partials.bytes()));
+    GBRS_HIP_CHECK(hipMemset(em->msums.p, 0, em->msums.bytes()));
     GBRS_HIP_CHECK(hipMemset(em->counts.p, 0, em->counts.bytes()));
     if (count) {
         GBRS_TRY(em->count.alloc(R));

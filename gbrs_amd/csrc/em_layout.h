@@ -33,7 +33,7 @@ __host__ __device__ constexpr int max_row_words(int H) { return 1 << pos_bits(H)
 constexpr int LDS_THETA_DOUBLES = GBRS_LDS_DOUBLES;        // theta of the tile: D_MAX * H doubles
 constexpr int LDS_ACC_DOUBLES = GBRS_LDS_DOUBLES + 64;     // privatised partial sums
 constexpr uint32_t SLOT_DIRECT = 0x80000000u;
-constexpr int HEAVY_SLOTS = 1;                 // loci with more slots get a whole wave in the gather
+constexpr int HEAVY_SLOTS = 16;                // loci with more slots get a whole wave in the gather (measured 1, 4, 16, 64)
 
 struct TileHdr {
     uint32_t batch_base;   // first batch of the tile in `words`

@@ -458,7 +458,12 @@ __global__ void locus_class_kernel(uint32_t L, const uint32_t *__restrict__ slot
     if (l >= L) return;
     const uint32_t k0 = slot_ptr[l], cnt = slot_ptr[l + 1] - k0;
     cls[l] = cnt == 0 ? 0 : (cnt == 1 ? 1 : (cnt <= (uint32_t)HEAVY_SLOTS ? 2 : 3));
+    // Destination of every (tile, dictionary entry) sum: straight into A for a locus that lives in one
+    // tile; otherwise row k of `partials`, k = the entry's rank in the inverted index, so that the
+    // slots of a locus are consecutive rows and the gather streams them without an indirection.
     if (cnt == 1) slot_dest[slot_list[k0]] = SLOT_DIRECT | l;
+    else
+        for (uint32_t k = k0; k < k0 + cnt; ++k) slot_dest[slot_list[k]] = k;
 }
 
 __global__ void long_rows_kernel(uint64_t n_long, uint64_t first, const uint32_t *__restrict__ srow,
