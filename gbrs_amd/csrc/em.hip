@@ -1067,7 +1067,8 @@ int gbrs_em_estep_partial(gbrs_em_t *em, void **partial_dev, uint64_t *n_elems) 
 int gbrs_em_finish_step(gbrs_em_t *em, double *err_sum_out) {
     if (!em) return fail(GBRS_ERR_INVALID, "handle is NULL");
     GBRS_TRY(select_device(em->device));
-    GBRS_TRY(em_finish_step(em, -1.0));
+    // without a request for err_sum the error pass is deferred into the next E-step launch
+    GBRS_TRY(em_finish_step(em, -1.0, /* defer */ err_sum_out == nullptr));
     if (err_sum_out) {
         EmScalars host;
         GBRS_TRY(em_check_float(em, host));
@@ -1216,6 +1217,7 @@ int gbrs_em_set_stream(gbrs_em_t *em, void *stream) {
 
 int gbrs_em_sync(gbrs_em_t *em) {
     if (!em) return fail(GBRS_ERR_INVALID, "handle is NULL");
+    GBRS_TRY(em_flush_err(em));
     GBRS_HIP_CHECK(hipStreamSynchronize(em->stream));
     return GBRS_OK;
 }
