@@ -492,7 +492,7 @@ int em_estep_tiles(gbrs_em *em, bool materialize, bool skip_gather = false) {
     if (light + heavy > 0)
         hipLaunchKernelGGL(gather_kernel, dim3(light + heavy), dim3(256), 0, em->stream, em->L, em->H,
                            HP, light, heavy, (uint32_t)tl.n_heavy, all ? 1 : 0, (uint32_t)tl.n_light, tl.light_loci.p,
-                           tl.slot_ptr.p, tl.slot_list.p, tl.heavy_loci.p, tl.locus_class.p, tl.partials.p,
+                           tl.slot_ptr.p, tl.heavy_loci.p, tl.locus_class.p, tl.partials.p,
                            (tl.n_long && all) ? tl.acc_extra.p : (const double *)nullptr, em->acc.p, em->scalars.p,
                            ONES ? 0 : 1);
     GBRS_HIP_CHECK(hipGetLastError());
@@ -528,8 +528,8 @@ constexpr int MSTEP_EPT = 4;       // elements per thread of the elementwise wor
 constexpr int GATHER_CHAINS = 4;   // independent loads in flight per lane of a many-slot locus
 __global__ void __launch_bounds__(RED_THREADS)
 mstep_gather_kernel(uint32_t L, uint32_t H, uint32_t HP, uint32_t heavy_blocks, uint32_t n_heavy,
-                    const uint32_t *__restrict__ slot_ptr, const uint32_t *__restrict__ slot_list,
-                    const uint32_t *__restrict__ heavy_loci, const uint8_t *__restrict__ locus_class,
+                    const uint32_t *__restrict__ slot_ptr, const uint32_t *__restrict__ heavy_loci,
+                    const uint8_t *__restrict__ locus_class,
                     const double *__restrict__ slot_sums, const double *__restrict__ acc,
                     const double *__restrict__ acc_extra, double *__restrict__ theta,
                     const double *__restrict__ eff_len, double *__restrict__ counts, double *__restrict__ tot_prev,
@@ -714,7 +714,7 @@ int em_launch_mstep_gather(gbrs_em *em) {
     const unsigned heavy_blocks = (unsigned)((tl.n_heavy + RED_THREADS / 64 - 1) / (RED_THREADS / 64));
     em->msum_blocks = elem_blocks + heavy_blocks;
     hipLaunchKernelGGL(mstep_gather_kernel, dim3(elem_blocks + heavy_blocks), dim3(RED_THREADS), 0, em->stream, em->L,
-                       em->H, HP, heavy_blocks, (uint32_t)tl.n_heavy, tl.slot_ptr.p, tl.slot_list.p, tl.heavy_loci.p,
+                       em->H, HP, heavy_blocks, (uint32_t)tl.n_heavy, tl.slot_ptr.p, tl.heavy_loci.p,
                        tl.locus_class.p, tl.partials.p, em->acc.p,
                        tl.n_long ? tl.acc_extra.p : (const double *)nullptr, em->theta.p,
                        em->has_len ? em->eff_len.p : (const double *)nullptr, em->counts.p, em->tot_prev.p,

@@ -10,9 +10,11 @@
 //   tile   = a run of batches processed by one workgroup with one locus dictionary of at most
 //            D_MAX loci, so that theta and the partial sums of the tile live in LDS.
 //   slot   = one (tile, dictionary entry): the tile's partial sum for that locus, H doubles in
-//            `partials`; `slot_ptr/slot_list` is the inverted index locus -> slots the gather
-//            kernel walks in fixed order (no float atomics in global memory, bit-reproducible
-//            across launches up to LDS atomic order inside a tile).
+//            `partials`.  Slots are numbered by locus (`slot_dest` maps a tile's dictionary entry to
+//            its row; `slot_ptr[l] .. slot_ptr[l+1]` are the rows of locus l), so the gather streams
+//            consecutive rows in fixed order (no float atomics in global memory, bit-reproducible
+//            across launches up to LDS atomic order inside a tile).  `slot_list` (build only) is the
+//            inverted index in the tile-major numbering.
 #pragma once
 #include "common.h"
 
