@@ -132,6 +132,9 @@ int gbrs_em_group_sums(gbrs_em_t *em, int64_t num_groups, const int64_t *group_p
  * buffer (RCCL) and then finishes the step.  partial_dev returns the DEVICE pointer of the
  * (L x H, locus-major) float64 partial-sum buffer and its element count. */
 int gbrs_em_estep_partial(gbrs_em_t *em, void **partial_dev, uint64_t *n_elems);
+/* M-step + stopping-rule bookkeeping on the all-reduced buffer.  With err_sum_out == NULL the error
+ * pass (sum |dTPM|, iteration counter) is deferred into the next E-step launch; it is completed by
+ * the next call that reports it (gbrs_em_finish_step with err_sum_out, gbrs_em_step, gbrs_em_sync). */
 int gbrs_em_finish_step(gbrs_em_t *em, double *err_sum_out);
 /* Same pair for prepare(): partial sums of count/nnz_row, then the division and pseudocount. */
 int gbrs_em_prepare_partial(gbrs_em_t *em, void **partial_dev, uint64_t *n_elems);
@@ -151,8 +154,8 @@ typedef struct gbrs_em_info {
     uint64_t num_device_words;  /* 32-bit (row, locus) words streamed per E-step            */
     uint64_t bytes_per_iter;    /* bytes the E+M step kernels move per iteration (layout)   */
     uint64_t algorithmic_bytes; /* 4N + 4(R+1) [+8R] + 8HL*2 [+8HL]             */
-    double   last_estep_ms;     /* HIP-event time of the last E-step kernel launch          */
-    double   last_step_ms;      /* HIP-event time of the last full EM step                  */
+    double   last_estep_ms;     /* HIP-event time of the E-step launch (mean of the timed    */
+    double   last_step_ms;      /* steps: every 8th of a gbrs_em_step call) / of a full step */
     uint32_t num_loci, num_haps;
     uint32_t layout;            /* 0 = csc-direct, 1 = packed row tiles                     */
     uint32_t reserved;
