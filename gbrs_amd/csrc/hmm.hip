@@ -1450,7 +1450,6 @@ struct gbrs_hmm {
     int H = 0, S = 0, n_chrom = 0, n_samples = 0;
     std::vector<ChromDesc> chroms;
     int64_t total_genes = 0, total_trans = 0, total_bp = 0, total_chunks = 0;
-    int num_cus = 0;
     int max_bp_rows = 0;                      // max over chromosomes of min(n_genes, n_trans)
     bool have_eprob = false, ran = false;
     DevBuf<ChromDesc> d_chroms;
@@ -1552,37 +1551,20 @@ int hmm_launch(gbrs_hmm *h) {
             // transition registers (half the block loads per sample; measured best of 1-8 at 64 samples).
             const bool batched = h->n_samples >= HMM_BATCH_MIN;
             const dim3 wave_grid(batched ? (h->n_samples + HMM_SB - 1) / HMM_SB : h->n_samples, h->n_chrom);
-            // While every chain's wave can have a CU of its own, ask for more than half a CU's LDS per
-            // workgroup: the dispatcher then cannot stack two of these single-wave workgroups on one
-            // CU (where they would share a SIMD's issue slots) while other CUs sit idle.
-            size_t pad = 0;
-            {
-                const char *env = std::getenv("GBRS_TUNING_HMM_SPREAD");
-                const bool spread = env ? std::atoi(env) != 0 : true;
-                if (!batched && spread && (int64_t)3 * h->n_chrom * h->n_samples <= h->num_cus) pad = 81 * 1024;
-            }
             auto k_alpha = batched ? &forward_wave_kernel<SS, HMM_NSET_B, HMM_SB, 0, 18> : &forward_wave_kernel<SS, HMM_NSET, 1, 0, HMM_HOIST_A>;
             auto k_delta = batched ? &forward_wave_kernel<SS, HMM_NSET_B, HMM_SB, 1, 18> : &forward_wave_kernel<SS, HMM_NSET, 1, 1, HMM_HOIST_D>;
             auto k_back = batched ? &backward_wave_kernel<SS, HMM_NSET_B, HMM_SB> : &backward_wave_kernel<SS, HMM_NSET, 1>;
-            if (pad) {
-                GBRS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_alpha),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad));
-                GBRS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_delta),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad));
-                GBRS_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_back),
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)pad));
-            }
             launch_alpha = [=](hipStream_t st) {
-                hipLaunchKernelGGL(k_alpha, wave_grid, dim3(64), pad, st, h->n_samples, h->total_genes,
+                hipLaunchKernelGGL(k_alpha, wave_grid, dim3(64), 0, st, h->n_samples, h->total_genes,
                                    h->d_chroms.p, h->d_order.p, h->tprob_q.p, h->pprob.p, h->eprob.p, h->peprob.p,
                                    h->init_vec.p, h->xsum.p, h->invz.p, h->delta.p, h->last_state.p);
             };
             launch_back = [=](hipStream_t st) {
-                hipLaunchKernelGGL(k_back, wave_grid, dim3(64), pad, st, h->n_samples, h->total_genes,
+                hipLaunchKernelGGL(k_back, wave_grid, dim3(64), 0, st, h->n_samples, h->total_genes,
                                    h->d_chroms.p, h->d_order.p, h->pprob_t.p, h->peprob.p, h->bhat.p, h->bscale.p);
             };
             launch_delta = [=](hipStream_t st) {
-                hipLaunchKernelGGL(k_delta, wave_grid, dim3(64), pad, st, h->n_samples, h->total_genes,
+                hipLaunchKernelGGL(k_delta, wave_grid, dim3(64), 0, st, h->n_samples, h->total_genes,
                                    h->d_chroms.p, h->d_order.p, h->tprob_q.p, h->pprob.p, h->eprob.p, h->peprob.p,
                                    h->init_vec.p, h->xsum.p, h->invz.p, h->delta.p, h->last_state.p);
             };
@@ -1714,11 +1696,6 @@ int gbrs_hmm_create(int num_haps, int n_chrom, const int32_t *n_genes, const int
         h->total_trans += n_trans[c];
         h->total_bp += std::min(n_genes[c], n_trans[c]);
         h->max_bp_rows = std::max(h->max_bp_rows, std::min(n_genes[c], n_trans[c]));
-    }
-    {
-        hipDeviceProp_t prop;
-        GBRS_HIP_CHECK(hipGetDeviceProperties(&prop, device));
-        h->num_cus = prop.multiProcessorCount;
     }
     GBRS_HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamDefault));
     GBRS_HIP_CHECK(hipStreamCreateWithFlags(&h->stream_b, hipStreamNonBlocking));
