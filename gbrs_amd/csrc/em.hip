@@ -1128,14 +1128,18 @@ int gbrs_em_run(gbrs_em_t *em, int model, double tol, int max_iters, int *n_iter
     EmScalars host;
     std::memset(&host, 0, sizeof(host));
     if (1000000.0 > target) {
-        // Steps are enqueued in small batches; a device-side stop flag turns the steps after the
-        // stopping iteration into no-ops, so theta is exactly the stopping iteration's value.
-        const int batch = 4;
+        // Steps are enqueued in batches of 8 (one host synchronisation each); a device-side stop flag
+        // turns the steps after the stopping iteration into no-ops, so theta is exactly the stopping
+        // iteration's value.
+        const int batch = 8;
+        bool first = true;
         while (done < max_iters) {
             const int nb = std::min(batch, max_iters - done);
             hipEvent_t ev[3] = {em->ev0, em->ev1, em->ev2};
-            for (int i = 0; i < nb; ++i)       // one timed step per batch; the batch's last error pass is not deferred
-                GBRS_TRY(em_one_step(em, target, i == 0 ? ev : nullptr, i + 1 < nb));
+            for (int i = 0; i < nb; ++i) {     // the run's first step is timed; a batch's last error pass is not deferred
+                GBRS_TRY(em_one_step(em, target, first ? ev : nullptr, i + 1 < nb));
+                first = false;
+            }
             GBRS_TRY(em_check_float(em, host));
             done = host.iters_done;
             if (host.stop) break;
