@@ -1,9 +1,11 @@
 // Shared host/device helpers for libgbrs_hip.so (gfx950 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <chrono>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -31,7 +33,9 @@ int fail(int status, const char *fmt, ...);
 
 int select_device(int device);
 
-// RAII device buffer (raw hipMalloc; sizes here are GBs, no pooling needed)
+// RAII device buffer (raw hipMalloc.  A stream-ordered pool - hipMallocAsync with an unbounded release
+// threshold - was measured for the layout builder's temporaries: no gain over hipMalloc once a first
+// build has run, and a second build next to a live handle took 0.4 s in the pool, so it is not used.)
 template <typename T>
 struct DevBuf {
     T *p = nullptr;
@@ -58,6 +62,27 @@ struct DevBuf {
         return GBRS_OK;
     }
     size_t bytes() const { return n * sizeof(T); }
+};
+
+// Wall-clock checkpoints of the one-off build steps, printed to stderr when GBRS_TUNING_BUILD_TIMES=1.
+struct StageTimer {
+    bool on;
+    std::chrono::steady_clock::time_point t0, last;
+    const char *what;
+    explicit StageTimer(const char *w) : on(false), what(w) {
+        const char *e = std::getenv("GBRS_TUNING_BUILD_TIMES");
+        on = e && std::atoi(e) != 0;
+        t0 = last = std::chrono::steady_clock::now();
+    }
+    void mark(const char *stage) {
+        if (!on) return;
+        (void)hipDeviceSynchronize();
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[%s] %-28s %8.2f ms (total %8.2f)\n", what, stage,
+                     std::chrono::duration<double, std::milli>(now - last).count(),
+                     std::chrono::duration<double, std::milli>(now - t0).count());
+        last = now;
+    }
 };
 
 constexpr int WAVE = 64;

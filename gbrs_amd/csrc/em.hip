@@ -839,12 +839,6 @@ int upload_csc(uint64_t R, uint32_t L, uint32_t H, const uint32_t *const *indptr
         const uint64_t cnt = hap_off[h + 1] - hap_off[h];
         if (cnt == 0) continue;
         if (!indices[h]) return fail(GBRS_ERR_INVALID, "indices[%u] is NULL", h);
-        if (!on_device) {
-            const uint32_t *ix = indices[h];
-            uint32_t mx = 0;
-            for (uint64_t k = 0; k < cnt; ++k) mx = ix[k] > mx ? ix[k] : mx;
-            if (mx >= R) return fail(GBRS_ERR_INVALID, "indices[%u] holds row id %u >= num_rows", h, mx);
-        }
         GBRS_HIP_CHECK(hipMemcpy(ent_row.p + hap_off[h], indices[h], cnt * sizeof(uint32_t), kind));
     }
     n_out = n;
@@ -872,7 +866,9 @@ int em_create_impl(uint64_t R, uint32_t L, uint32_t H, const uint32_t *const *in
     GBRS_HIP_CHECK(hipEventCreate(&em->ev2));
     const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     uint64_t n = 0;
+    StageTimer stg("create");
     GBRS_TRY(upload_csc(R, L, H, indptr, indices, on_device, em->ent_row, em->col_ptr, n));
+    stg.mark("upload csc");
     em->N = n;
     const size_t LH = (size_t)L * H;
     GBRS_TRY(em->den.alloc(R));
@@ -904,7 +900,7 @@ int em_create_impl(uint64_t R, uint32_t L, uint32_t H, const uint32_t *const *in
         GBRS_HIP_CHECK(hipStreamSynchronize(em->stream));
     }
     GBRS_HIP_CHECK(hipDeviceSynchronize());
-    if (on_device && n > 0) {
+    if (n > 0) {                               // row ids are validated on the device for host and device input alike
         DevBuf<unsigned int> d_max;
         GBRS_TRY(d_max.alloc(1));
         GBRS_HIP_CHECK(hipMemsetAsync(d_max.p, 0, sizeof(unsigned int), em->stream));
@@ -914,6 +910,7 @@ int em_create_impl(uint64_t R, uint32_t L, uint32_t H, const uint32_t *const *in
         GBRS_HIP_CHECK(hipStreamSynchronize(em->stream));
         if (mx >= R) return fail(GBRS_ERR_INVALID, "indices hold row id %u >= num_rows", mx);
     }
+    stg.mark("vectors, checks");
     if (!(flags & GBRS_EM_LAYOUT_CSC) && H <= 16 && n < 0xFFFFFFFFull) {
         // Row order inside a tile: the stream order (gbrs_hip.h) by default - every lane walks a
         // contiguous piece of the tile's sorted rows, so it stays on one locus list for long stretches
@@ -930,9 +927,11 @@ int em_create_impl(uint64_t R, uint32_t L, uint32_t H, const uint32_t *const *in
                                    row_order,
                                    em->stream));
         em->layout = 1;
+        stg.mark("build_tile_layout");
         // the CSC copy and the per-row denominators are only needed by layout 0
         em->ent_row.release();
         em->den.release();
+        stg.mark("release csc copy");
     }
     guard.p = nullptr;
     *out = em;

@@ -795,6 +795,7 @@ int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L, uint32_t H, uint6
     if (H > 16) return fail(GBRS_ERR_INVALID, "the tiled layout packs the haplotype mask in 16 bits (H <= 16)");
     if (N >= 0xFFFFFFFFull || L >= (1u << 27))
         return fail(GBRS_ERR_INVALID, "the tiled layout needs N < 2^32 entries and L < 2^27 loci per handle");
+    StageTimer stg("layout");
     Scratch sc;
     DevBuf<BuildFlags> d_flags;
     GBRS_TRY(d_flags.alloc(1));
@@ -823,6 +824,7 @@ int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L, uint32_t H, uint6
                        keys.p, d_flags.p);
     GBRS_TRY(sort_keys64(sc, keys.p, keys2.p, N, 32 + bits_for(R - 1), s));
     keys.release();
+    stg.mark("1 sort entries");
     // 2. pairs
     DevBuf<uint32_t> pflag, pidx;
     GBRS_TRY(pflag.alloc(N));
@@ -844,6 +846,7 @@ int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L, uint32_t H, uint6
                        ploc.p, pmask.p);
     GBRS_HIP_CHECK(hipStreamSynchronize(s));
     keys2.release(); pflag.release(); pidx.release();
+    stg.mark("2 pairs");
     // 3. rows
     DevBuf<uint32_t> rflag, ridx;
     GBRS_TRY(rflag.alloc(P));
@@ -860,6 +863,7 @@ int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L, uint32_t H, uint6
                        rowstart.p, row_orig.p);
     GBRS_HIP_CHECK(hipStreamSynchronize(s));
     rflag.release(); ridx.release(); prow.release();
+    stg.mark("3 rows");
     // 4. order rows so that similar rows are adjacent
     DevBuf<uint64_t> rkey, skey;
     DevBuf<uint32_t> ident, srow;
@@ -873,6 +877,7 @@ int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L, uint32_t H, uint6
     rkey.release(); ident.release();
     const uint64_t n_long = hf.n_long, n_short = R1 - n_long;
     out.n_long = n_long;
+    stg.mark("4 order rows");
     // 5. optional merge of identical adjacent rows + weights
     DevBuf<uint32_t> head, hincl, hrow;
     uint64_t M = n_short;
@@ -897,6 +902,7 @@ int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L, uint32_t H, uint6
     }
     skey.release();
     out.n_rows = M;
+    stg.mark("5 merge");
     // 6. long rows keep their pair form
     if (n_long) {
         DevBuf<uint64_t> llen;
@@ -918,6 +924,7 @@ int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L, uint32_t H, uint6
     }
     srow.release(); row_orig.release();
     if (M == 0) { GBRS_HIP_CHECK(hipStreamSynchronize(s)); return GBRS_OK; }
+    stg.mark("6 long rows");
     // 7. tiles
     DevBuf<uint32_t> npm, dnew, wordoff, dincl, tflag, tincl;
     GBRS_TRY(npm.alloc(M)); GBRS_TRY(dnew.alloc(M)); GBRS_TRY(wordoff.alloc(M)); GBRS_TRY(dincl.alloc(M));
@@ -937,6 +944,7 @@ int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L, uint32_t H, uint6
     DevBuf<uint32_t> tile_row;
     GBRS_TRY(tile_row.alloc(T + 1));
     hipLaunchKernelGGL(tile_start_kernel, dim3(grid_for(M)), dim3(256), 0, s, M, T, tflag.p, tincl.p, tile_row.p);
+    stg.mark("7 tiles");
     // 7b. interleave the locus lists inside each tile (tile membership and sizes are unchanged)
     if (interleave || streams) {
         DevBuf<uint32_t> gflag, gpos, gstart, gord, ident, perm, hrow2, npm2;
@@ -978,6 +986,7 @@ int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L, uint32_t H, uint6
     }
     dnew.release();
     tflag.release();
+    stg.mark("7b row order");
     // 8. padding so that no row straddles a batch, batch offsets
     DevBuf<uint32_t> rowpad, nbatch, batch_base;
     GBRS_TRY(rowpad.alloc(M)); GBRS_TRY(nbatch.alloc(T)); GBRS_TRY(batch_base.alloc(T));
@@ -987,6 +996,7 @@ int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L, uint32_t H, uint6
     uint32_t NB = 0;
     GBRS_TRY(fetch_last_plus(batch_base.p, nbatch.p, T, NB, s));
     out.n_batches = NB;
+    stg.mark("8 padding");
     // 9. per-tile dictionaries
     const uint32_t dcap = out.d_max;
     DevBuf<uint32_t> tmpdict, dcount, dict_base;
@@ -1003,6 +1013,7 @@ int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L, uint32_t H, uint6
     GBRS_TRY(out.dict.alloc(std::max<uint32_t>(NS, 1)));
     hipLaunchKernelGGL(tile_hdr_kernel, dim3((unsigned)T), dim3(64), 0, s, T, dcap, batch_base.p, nbatch.p, dict_base.p,
                        dcount.p, tmpdict.p, out.tiles.p, out.dict.p);
+    stg.mark("9 dictionaries");
     // 10. words
     GBRS_TRY(out.words.alloc((size_t)NB * 64));
     GBRS_HIP_CHECK(hipMemsetAsync(out.words.p, 0, out.words.bytes(), s));
@@ -1019,6 +1030,7 @@ int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L, uint32_t H, uint6
     rowpad.release(); tincl.release(); npm.release(); wordoff.release(); tile_row.release();
     hrow.release(); rowstart.release(); ploc.release(); pmask.release();
     out.row_weight.release();
+    stg.mark("10 words");
     // 11. inverted index locus -> slots (ascending slot inside a locus: radix sort is stable)
     GBRS_TRY(out.slot_list.alloc(std::max<uint32_t>(NS, 1)));
     if (NS) {
@@ -1035,6 +1047,7 @@ int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L, uint32_t H, uint6
     if (NS) hipLaunchKernelGGL(iota_kernel, dim3(grid_for(NS)), dim3(256), 0, s, (uint64_t)NS, out.slot_dest.p);
     hipLaunchKernelGGL(locus_class_kernel, dim3(grid_for(L)), dim3(256), 0, s, L, out.slot_ptr.p, out.slot_list.p,
                        out.locus_class.p, out.slot_dest.p);
+    stg.mark("11 inverted index");
     // 12. loci with many slots get a whole wave in the gather kernel
     {
         std::vector<uint32_t> sp((size_t)L + 1), heavy, lightv;
@@ -1053,6 +1066,7 @@ int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L, uint32_t H, uint6
             GBRS_HIP_CHECK(hipMemcpyAsync(out.heavy_loci.p, heavy.data(), heavy.size() * 4, hipMemcpyHostToDevice, s));
         GBRS_HIP_CHECK(hipStreamSynchronize(s));
     }
+    stg.mark("12 heavy / light lists");
     GBRS_HIP_CHECK(hipGetLastError());
     return GBRS_OK;
 }
