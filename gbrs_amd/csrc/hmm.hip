@@ -1277,9 +1277,12 @@ beta_corr_kernel(int64_t genes_per_sample, const ChromDesc *__restrict__ chroms,
     }
 }
 
-// Log-domain outputs of the reference from the probability-domain sweeps, one thread per
-// (sample, gene):  alpha = log(x) + e - log(Z), scaler = -log(Z), beta = log(bhat),
-// gamma = ahat*bhat / sum_j(ahat*bhat), ahat = x*pe/Z recomputed here  (gbrs_utils.py:515-524, :542-549, :558-560).
+// Outputs of the reference from the probability-domain sweeps, one thread per (sample, gene, state):
+//   parts & 2  gamma = ahat*bhat / sum_j(ahat*bhat), ahat = x*pe/Z recomputed here  (gbrs_utils.py:558-560)
+//              - the only array gbrs reconstruct saves; part of every run
+//   parts & 1  alpha = log(x) + e - log(Z), scaler = -log(Z)                        (gbrs_utils.py:515-524)
+//   parts & 4  beta = log(bhat) [+ log C_i of the free-running backward sweep]      (gbrs_utils.py:542-549)
+//              - the log-domain intermediates, made on the first gbrs_hmm_get() that asks for one
 __global__ void __launch_bounds__(1024)
 hmm_outputs_kernel(int S, int OUT_ROWS /* (sample, gene) rows per workgroup */, int64_t n_rows, int parts,
                    const double *__restrict__ eprob, const double *__restrict__ xsum,
@@ -1287,8 +1290,7 @@ hmm_outputs_kernel(int S, int OUT_ROWS /* (sample, gene) rows per workgroup */, 
                    const double *__restrict__ bhat, const double *__restrict__ bcorr /* nullable */,
                    double *__restrict__ alpha, double *__restrict__ scaler, double *__restrict__ beta,
                    double *__restrict__ gamma) {
-    // one thread per (row, state) element: every array is read and written as a contiguous stream.
-    // parts & 1: alpha and scaler (forward results only);  parts & 2: beta and gamma (both sweeps)
+    // every array is read and written as a contiguous stream
     extern __shared__ double lds[];               // g[OUT_ROWS * S], norm[OUT_ROWS]
     double *l_g = lds, *l_norm = lds + OUT_ROWS * S;
     const int64_t r0 = (int64_t)blockIdx.x * OUT_ROWS;
@@ -1300,6 +1302,10 @@ hmm_outputs_kernel(int S, int OUT_ROWS /* (sample, gene) rows per workgroup */, 
     if (parts & 1) {
         if (t < nr) scaler[r0 + t] = log(invz[r0 + t]);              // -log(Z)
         if (live) alpha[o] = (log(xsum[o]) + eprob[o]) + log(invz[r0 + row]);
+    }
+    if ((parts & 4) && live) {
+        const double lb = log(bhat[o]);
+        beta[o] = bcorr ? lb + bcorr[r0 + row] : lb;
     }
     if (!(parts & 2)) return;
     double ah = 0.0, bh = 0.0;
@@ -1315,10 +1321,7 @@ hmm_outputs_kernel(int S, int OUT_ROWS /* (sample, gene) rows per workgroup */, 
         l_norm[t] = norm;
     }
     __syncthreads();
-    if (live) {
-        beta[o] = bcorr ? log(bh) + bcorr[r0 + row] : log(bh);
-        gamma[o] = ah * bh / l_norm[row];
-    }
+    if (live) gamma[o] = ah * bh / l_norm[row];
 }
 
 // Backtrace (gbrs_utils.py:587-597): states[m] = argmax delta[:, n-1], states[t] = bp[t][states[t+1]]
@@ -1452,6 +1455,8 @@ struct gbrs_hmm {
     int64_t total_genes = 0, total_trans = 0, total_bp = 0, total_chunks = 0;
     int max_bp_rows = 0;                      // max over chromosomes of min(n_genes, n_trans)
     bool have_eprob = false, ran = false;
+    bool free_backward = false;               // last run used the free-running backward sweep (beta needs bcorr)
+    bool logs_ready = false;                  // alpha / beta / scaler of the last run have been made (hmm_make_logs)
     DevBuf<ChromDesc> d_chroms;
     DevBuf<int32_t> d_order;                  // chromosome indices, longest first
     DevBuf<double> tprob, pprob, pprob_t, init_vec;   // log T, exp(T), exp(T) transposed per block
@@ -1471,23 +1476,55 @@ int hmm_alloc_samples(gbrs_hmm *h, int n_samples) {
     if (n_samples == h->n_samples && h->eprob.p) return GBRS_OK;
     const size_t gs = (size_t)h->total_genes * n_samples;
     GBRS_TRY(h->eprob.alloc(gs * h->S));
-    GBRS_TRY(h->alpha.alloc(gs * h->S));
     GBRS_TRY(h->peprob.alloc(gs * h->S));
     GBRS_TRY(h->xsum.alloc(gs * h->S));
     GBRS_TRY(h->bhat.alloc(gs * h->S));
     GBRS_TRY(h->invz.alloc(gs));
     GBRS_TRY(h->bscale.alloc(gs));
-    GBRS_TRY(h->bcorr.alloc(gs));
-    GBRS_TRY(h->beta.alloc(gs * h->S));
     GBRS_TRY(h->gamma.alloc(gs * h->S));
     GBRS_TRY(h->delta.alloc(gs * h->S));
-    GBRS_TRY(h->scaler.alloc(gs));
+    h->alpha.release(); h->beta.release(); h->scaler.release(); h->bcorr.release();   // made on demand (hmm_make_logs)
     GBRS_TRY(h->bp.alloc(std::max<size_t>((size_t)h->total_bp * n_samples * h->S, 1)));
     GBRS_TRY(h->bt_exit.alloc(std::max<size_t>((size_t)h->total_chunks * n_samples * h->S, 1)));
     GBRS_TRY(h->last_state.alloc((size_t)h->n_chrom * n_samples));
     GBRS_TRY(h->states.alloc(((size_t)h->total_genes + h->n_chrom) * n_samples));
     GBRS_TRY(h->calls.alloc(gs));
     h->n_samples = n_samples;
+    return GBRS_OK;
+}
+
+// hmm_outputs_kernel over every (sample, gene) row of the handle
+void launch_outputs(gbrs_hmm *h, int parts, hipStream_t st) {
+    const int S = h->S;
+    const int64_t rows = h->total_genes * h->n_samples;
+    const int out_rows = std::max(1, 1024 / S);
+    const dim3 grid((unsigned)((rows + out_rows - 1) / out_rows)), block(((out_rows * S + 63) / 64) * 64);
+    const size_t lds = (size_t)(out_rows * S + out_rows) * sizeof(double);
+    hipLaunchKernelGGL(hmm_outputs_kernel, grid, block, lds, st, S, out_rows, rows, parts, h->eprob.p, h->xsum.p,
+                       h->peprob.p, h->invz.p, h->bhat.p, h->free_backward ? h->bcorr.p : (const double *)nullptr,
+                       h->alpha.p, h->scaler.p, h->beta.p, h->gamma.p);
+}
+
+// The log-domain intermediates of the reference (alpha, scaler, beta).  gbrs reconstruct saves none of
+// them, so a run leaves them out (three of the seven per-state arrays the outputs pass would move, and the
+// suffix sum of the backward sweep's scale constants); the first gbrs_hmm_get() that asks makes them
+// for every sample of the last run.
+int hmm_make_logs(gbrs_hmm *h) {
+    if (h->logs_ready) return GBRS_OK;
+    const size_t gs = (size_t)h->total_genes * h->n_samples;
+    if (gs == 0) { h->logs_ready = true; return GBRS_OK; }
+    if (!h->alpha.p) GBRS_TRY(h->alpha.alloc(gs * h->S));
+    if (!h->beta.p) GBRS_TRY(h->beta.alloc(gs * h->S));
+    if (!h->scaler.p) GBRS_TRY(h->scaler.alloc(gs));
+    if (h->free_backward) {
+        if (!h->bcorr.p) GBRS_TRY(h->bcorr.alloc(gs));
+        hipLaunchKernelGGL(beta_corr_kernel, dim3(h->n_samples, h->n_chrom), dim3(256), 0, h->stream, h->total_genes,
+                           h->d_chroms.p, h->invz.p, h->bscale.p, h->bcorr.p);
+    }
+    launch_outputs(h, 1 | 4, h->stream);
+    GBRS_HIP_CHECK(hipGetLastError());
+    GBRS_HIP_CHECK(hipStreamSynchronize(h->stream));
+    h->logs_ready = true;
     return GBRS_OK;
 }
 
@@ -1517,9 +1554,6 @@ int hmm_launch(gbrs_hmm *h) {
     const int S = h->S;
     const int threads = ((S * 4 + 63) / 64) * 64;
     const int64_t rows = h->total_genes * h->n_samples;
-    const int out_rows = std::max(1, 1024 / S);
-    const dim3 out_grid((unsigned)((rows + out_rows - 1) / out_rows)), out_block(((out_rows * S + 63) / 64) * 64);
-    const size_t out_lds = (size_t)(out_rows * S + out_rows) * sizeof(double);
     const int bt_chunks = std::max(1, (h->max_bp_rows + BT_B - 1) / BT_B);
     const dim3 bt_grid(bt_chunks, h->n_chrom, h->n_samples);
     const size_t bt_maps_lds = (size_t)BT_B * S * sizeof(uint16_t);
@@ -1536,6 +1570,8 @@ int hmm_launch(gbrs_hmm *h) {
     if (const char *env = std::getenv("GBRS_TUNING_HMM_SERIAL"); env && std::atoi(env)) sb = sc = sa;
     constexpr bool WAVE = SS_WAVE > 0;                // the single-wave recursions (tables in lane order)
     constexpr bool QUAD = !WAVE && EXACT && KMAX * 4 > 64 && KMAX % 2 == 0;   // S = 136: the quad chains (tables in lane order)
+    h->logs_ready = false;
+    h->free_backward = WAVE || QUAD;                  // those sweeps rescale on their own (beta_corr_kernel)
     GBRS_HIP_CHECK(hipEventRecord(h->ev[1], sa));
     hipLaunchKernelGGL(exp_emission_kernel, dim3((unsigned)((rows * S + 255) / 256)), dim3(256), 0, sa,
                        rows * S, h->eprob.p, h->peprob.p);
@@ -1591,9 +1627,6 @@ int hmm_launch(gbrs_hmm *h) {
         GBRS_HIP_CHECK(hipStreamWaitEvent(sb, h->ev_fork, 0));
         GBRS_HIP_CHECK(hipStreamWaitEvent(sc, h->ev_fork, 0));
         launch_alpha(sa);
-        hipLaunchKernelGGL(hmm_outputs_kernel, out_grid, out_block, out_lds, sa, S, out_rows, rows, 1, h->eprob.p,
-                           h->xsum.p, h->peprob.p, h->invz.p, h->bhat.p, h->bcorr.p, h->alpha.p, h->scaler.p,
-                           h->beta.p, h->gamma.p);
         GBRS_HIP_CHECK(hipEventRecord(h->ev[2], sa));
         launch_back(sb);
         GBRS_HIP_CHECK(hipEventRecord(h->ev_b, sb));
@@ -1612,11 +1645,7 @@ int hmm_launch(gbrs_hmm *h) {
         launch_backtrace(sc);
         GBRS_HIP_CHECK(hipEventRecord(h->ev_c, sc));
         GBRS_HIP_CHECK(hipStreamWaitEvent(sa, h->ev_b, 0));
-        hipLaunchKernelGGL(beta_corr_kernel, dim3(h->n_samples, h->n_chrom), dim3(256), 0, sa, h->total_genes, h->d_chroms.p,
-                           h->invz.p, h->bscale.p, h->bcorr.p);
-        hipLaunchKernelGGL(hmm_outputs_kernel, out_grid, out_block, out_lds, sa, S, out_rows, rows, 2, h->eprob.p,
-                           h->xsum.p, h->peprob.p, h->invz.p, h->bhat.p, h->bcorr.p, h->alpha.p, h->scaler.p,
-                           h->beta.p, h->gamma.p);
+        launch_outputs(h, 2, sa);                     // the posterior is scale free: no beta correction needed
         GBRS_HIP_CHECK(hipEventRecord(h->ev[3], sa));
         GBRS_HIP_CHECK(hipStreamWaitEvent(sa, h->ev_c, 0));
         GBRS_HIP_CHECK(hipEventRecord(h->ev[4], sa));
@@ -1641,9 +1670,7 @@ int hmm_launch(gbrs_hmm *h) {
         hipLaunchKernelGGL((backward_kernel<KMAX, MAXT, EXACT>), unit_grid, dim3(threads),
                            2 * S * sizeof(double), sa, S, h->total_genes, h->d_chroms.p, h->pprob_t.p,
                            h->peprob.p, h->invz.p, h->bhat.p);
-        hipLaunchKernelGGL(hmm_outputs_kernel, out_grid, out_block, out_lds, sa, S, out_rows, rows, 3, h->eprob.p,
-                           h->xsum.p, h->peprob.p, h->invz.p, h->bhat.p, (const double *)nullptr, h->alpha.p,
-                           h->scaler.p, h->beta.p, h->gamma.p);
+        launch_outputs(h, 2, sa);
         GBRS_HIP_CHECK(hipEventRecord(h->ev[3], sa));
         launch_backtrace(sa);
         GBRS_HIP_CHECK(hipEventRecord(h->ev[4], sa));
@@ -1829,6 +1856,7 @@ int gbrs_hmm_get(gbrs_hmm_t *h, int sample, int chrom, double *gamma, int32_t *s
     if (!h->ran && (gamma || states || calls || alpha || beta || delta || scaler))
         return fail(GBRS_ERR_STATE, "run() has not been called");
     GBRS_TRY(select_device(h->device));
+    if (alpha || beta || scaler) GBRS_TRY(hmm_make_logs(h));
     const ChromDesc &cd = h->chroms[chrom];
     const int S = h->S, n = cd.n_genes;
     const size_t goff = (size_t)sample * h->total_genes + cd.gene_off;

@@ -232,7 +232,9 @@ int gbrs_hmm_run(gbrs_hmm_t *hmm);
  *   states int32[n'+1]     ordered Viterbi path as saved in genotypes.npz, n' = min(n_c, n_trans)
  *   calls  int32[n_c]      state index written to genotypes.tsv per gene, -1 = no entry
  *   alpha, beta, delta  double[S][n_c];  scaler double[n_c];  eprob double[n_c][S]
- */
+ * alpha, scaler and beta are the reference's log-domain intermediates; gbrs reconstruct saves none of
+ * them, so gbrs_hmm_run leaves them out and the first get that asks for one makes them for the
+ * whole last run (one extra device pass). */
 int gbrs_hmm_get(gbrs_hmm_t *hmm, int sample, int chrom, double *gamma, int32_t *states,
                  int32_t *calls, double *alpha, double *beta, double *delta, double *scaler,
                  double *eprob);

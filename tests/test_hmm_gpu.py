@@ -230,3 +230,30 @@ def test_hmm_other_founder_counts(H):
                 np.testing.assert_allclose(r[k], res[c][k], rtol=1e-9, atol=1e-9, err_msg=f"{k} sample {s} chrom {c}")
             np.testing.assert_allclose(r["gamma"], res[c]["gamma"], rtol=1e-8, atol=1e-300)
     hmm.close()
+
+
+def test_hmm_log_intermediates_follow_the_last_run():
+    """alpha / beta / scaler are made on the first get() that asks for them; a later run with other
+    emissions (and another sample count) must not hand back the earlier run's arrays."""
+    paths = golden_files("hmm")
+    g = load_golden([p for p in paths if "h8_full" in p][0])
+    c = hmm_case_inputs(g)
+    chroms = c["chroms"]
+    hmm = build(c)
+    rng = np.random.default_rng(5)
+    other = [np.log(rng.dirichlet(np.ones(hmm.S), size=len(c["genes"][ch]))) for ch in chroms]
+    hmm.set_eprob([np.stack([e, e]) for e in other])
+    hmm.run()
+    first = hmm.get(0, sample=1, want=("alpha", "beta", "scaler"))
+    hmm.set_eprob([g[f"eprob_{ch}"] for ch in chroms])
+    hmm.run()
+    for ci, ch in enumerate(chroms):
+        r = hmm.get(ci, want=("gamma",))
+        np.testing.assert_allclose(r["gamma"], g[f"gamma_{ch}"], rtol=1e-8, atol=1e-300)
+        r = hmm.get(ci, want=("beta",))
+        np.testing.assert_allclose(r["beta"], g[f"beta_{ch}"], rtol=1e-9, atol=1e-9)
+        r = hmm.get(ci, want=("alpha", "scaler"))
+        np.testing.assert_allclose(r["alpha"], g[f"alpha_{ch}"], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(r["scaler"], g[f"scaler_{ch}"], rtol=1e-9, atol=1e-9)
+    assert not np.allclose(first["alpha"], hmm.get(0, want=("alpha",))["alpha"])
+    hmm.close()
