@@ -44,12 +44,19 @@ __device__ __forceinline__ double seq_norm(const double *v, int H, int stride) {
 #endif
 constexpr int EM_LANES = HMM_EM_LANES;
 constexpr int EM_GENES = 64 / EM_LANES;
+#ifndef HMM_EM_BATCH_MIN
+#define HMM_EM_BATCH_MIN 4      // samples from which emission_batch_kernel replaces emission_kernel
+#endif
+#ifndef HMM_EM_BATCH_SPB
+#define HMM_EM_BATCH_SPB 16     // samples walked by one workgroup of emission_batch_kernel
+#endif
+constexpr int EM_BATCH_MIN = HMM_EM_BATCH_MIN, EM_BATCH_SPB = HMM_EM_BATCH_SPB;
 
 __global__ void __launch_bounds__(64)
 emission_kernel(int H, int S, int64_t n_genes, int n_samples, const double *__restrict__ expr,
                 const double *__restrict__ avecs, const uint8_t *__restrict__ has_avec,
                 const double *__restrict__ init_vec, double expr_threshold, double sigma,
-                double *__restrict__ eprob) {
+                double *__restrict__ eprob, double *__restrict__ peprob) {
     extern __shared__ double lds[];
     const int HH = H * H, av_stride = HH + 1, ex_stride = H + 1, out_stride = S + 1;
     double *l_av = lds, *l_ex = l_av + EM_GENES * av_stride, *l_out = l_ex + EM_GENES * ex_stride;
@@ -142,8 +149,144 @@ emission_kernel(int H, int S, int64_t n_genes, int n_samples, const double *__re
         for (int s = s_lo; s < s_hi; ++s) out[s] = log(out[s] / psum + TINY);
     }
     __syncthreads();
+    // the log emissions, and pe = exp(e) for the probability-domain sweeps (exp_emission_kernel's values)
     double *dst = eprob + ((int64_t)sample * n_genes + g0) * S;
-    for (int x = tid; x < ng * S; x += 64) dst[x] = l_out[(x / S) * out_stride + x % S];
+    double *pdst = peprob + ((int64_t)sample * n_genes + g0) * S;
+    for (int x = tid; x < ng * S; x += 64) {
+        const double v = l_out[(x / S) * out_stride + x % S];
+        dst[x] = v;
+        pdst[x] = exp(v);
+    }
+}
+
+// The same emissions for many samples at once (H == EM_LANES founders).  Everything that depends on the
+// gene only - the unit specificity rows and the S unit diplotype vectors, i.e. all but 9 of the ~260
+// divisions and all the square roots but one - is computed once per workgroup and kept in registers
+// (each of a gene's 8 lanes owns ceil(S/8) states), then the workgroup walks its samples: expression
+// row in, unit profile (lane q divides element q), distances, exp, the sequential sum, log, rows out.
+// Operation for operation the arithmetic of emission_kernel, so both produce the same bits.
+template <int HT>
+__global__ void __launch_bounds__(64)
+emission_batch_kernel(int64_t n_genes, int n_samples, int samples_per_block, const double *__restrict__ expr,
+                      const double *__restrict__ avecs, const uint8_t *__restrict__ has_avec,
+                      const double *__restrict__ init_vec, double expr_threshold, double sigma,
+                      double *__restrict__ eprob, double *__restrict__ peprob) {
+    constexpr int H = HT, S = H * (H + 1) / 2, HH = H * H;
+    static_assert(HT == EM_LANES, "lane q of a gene owns specificity row q and profile element q");
+    constexpr int SPL = (S + EM_LANES - 1) / EM_LANES;
+    constexpr int av_stride = HH + 1, ex_stride = H + 1, out_stride = S + 1;
+    __shared__ double l_av[EM_GENES * av_stride], l_ex[EM_GENES * ex_stride], l_u[EM_GENES * ex_stride],
+        l_out[EM_GENES * out_stride];
+    const int64_t g0 = (int64_t)blockIdx.x * EM_GENES;
+    const int ng = (int)min((int64_t)EM_GENES, n_genes - g0);
+    const int s_begin = blockIdx.y * samples_per_block, s_end = min(n_samples, s_begin + samples_per_block);
+    const int tid = threadIdx.x;
+    for (int x = tid; x < ng * HH; x += 64) l_av[(x / HH) * av_stride + x % HH] = avecs[g0 * HH + x];
+    // one expression element per lane and sample, fetched one sample ahead
+    const bool has_e = tid < ng * H;
+    double e_next = has_e && s_begin < s_end ? expr[((int64_t)s_begin * n_genes + g0) * H + tid] : 0.0;
+    __syncthreads();
+    const int lg = tid / EM_LANES, q = tid % EM_LANES;
+    const bool in_range = lg < ng;
+    double *U = l_av + lg * av_stride;
+    const bool naive = in_range && !has_avec[g0 + lg];
+    if (in_range) {                            // unit_vector() of specificity row q, in place
+        double sm = 0.0, qq = 0.0;
+        for (int x = 0; x < H; ++x) {
+            const double a = naive ? (x == q ? 1.0 : 0.0001) : U[q * H + x];
+            sm += a;
+            qq += a * a;
+        }
+        const double rn = sm > 1e-6 ? sqrt(qq) : 0.0;
+        for (int x = 0; x < H; ++x) {
+            const double a = naive ? (x == q ? 1.0 : 0.0001) : U[q * H + x];
+            U[q * H + x] = rn != 0.0 ? a / rn : a;
+        }
+    }
+    __syncthreads();
+    const int s_lo = min(S, q * SPL), s_hi = min(S, s_lo + SPL);
+    double G[SPL][H];                          // unit diplotype vectors of this lane's states
+    {
+        int i = 0, rem = s_lo;
+        while (i < H && rem >= H - i) { rem -= H - i; ++i; }
+        int j = i + rem;
+#pragma unroll
+        for (int t = 0; t < SPL; ++t) {
+            const bool on = in_range && s_lo + t < s_hi;
+            const int ii = on ? i : 0, jj = on ? j : 0;
+            if (jj == ii) {
+#pragma unroll
+                for (int x = 0; x < H; ++x) G[t][x] = U[ii * H + x];
+            } else {
+                double gs = 0.0, gq = 0.0;
+#pragma unroll
+                for (int x = 0; x < H; ++x) {
+                    const double w = U[ii * H + x] + U[jj * H + x];
+                    gs += w;
+                    gq += w * w;
+                }
+                const bool norm = gs > 1e-6;
+                const double gn = norm ? sqrt(gq) : 1.0;
+#pragma unroll
+                for (int x = 0; x < H; ++x) {
+                    const double w = U[ii * H + x] + U[jj * H + x];
+                    G[t][x] = norm ? w / gn : w;
+                }
+            }
+            if (on && ++j == H) { ++i; j = i; }
+        }
+    }
+    const double sg = naive ? 0.450 : sigma;
+    const double denom = -2 * sg * sg;
+    const double *e = l_ex + lg * ex_stride;
+    double *out = l_out + lg * out_stride;
+    for (int sample = s_begin; sample < s_end; ++sample) {
+        if (has_e) l_ex[(tid / H) * ex_stride + tid % H] = e_next;
+        if (has_e && sample + 1 < s_end) e_next = expr[((int64_t)(sample + 1) * n_genes + g0) * H + tid];
+        __syncthreads();
+        double esum = 0.0;
+        if (in_range)
+            for (int x = 0; x < H; ++x) esum += e[x];
+        const bool live = in_range && !(esum < expr_threshold);
+        if (live) {
+            const bool norm = esum > 1e-6;
+            const double nrm = norm ? seq_norm(e, H, 1) : 1.0;
+            l_u[lg * ex_stride + q] = norm ? e[q] / nrm : e[q];
+        }
+        __syncthreads();
+        if (in_range && !live) {
+            for (int s = s_lo; s < s_hi; ++s) out[s] = init_vec[s];
+        } else if (live) {
+            double u[H];
+#pragma unroll
+            for (int x = 0; x < H; ++x) u[x] = l_u[lg * ex_stride + x];
+#pragma unroll
+            for (int t = 0; t < SPL; ++t) {
+                if (s_lo + t >= s_hi) break;
+                double d = 0.0;
+#pragma unroll
+                for (int x = 0; x < H; ++x) {
+                    const double dd = u[x] - G[t][x];
+                    d += dd * dd;
+                }
+                out[s_lo + t] = exp(d / denom);
+            }
+        }
+        __syncthreads();
+        if (live) {
+            double psum = 0.0;
+            for (int s = 0; s < S; ++s) psum += out[s];
+            for (int s = s_lo; s < s_hi; ++s) out[s] = log(out[s] / psum + TINY);
+        }
+        __syncthreads();
+        double *dst = eprob + ((int64_t)sample * n_genes + g0) * S;
+        double *pdst = peprob + ((int64_t)sample * n_genes + g0) * S;
+        for (int x = tid; x < ng * S; x += 64) {
+            const double v = l_out[(x / S) * out_stride + x % S];
+            dst[x] = v;
+            pdst[x] = exp(v);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1455,6 +1598,7 @@ struct gbrs_hmm {
     int64_t total_genes = 0, total_trans = 0, total_bp = 0, total_chunks = 0;
     int max_bp_rows = 0;                      // max over chromosomes of min(n_genes, n_trans)
     bool have_eprob = false, ran = false;
+    bool pe_ready = false;                    // peprob = exp(eprob) is current (the emission kernels write both)
     bool free_backward = false;               // last run used the free-running backward sweep (beta needs bcorr)
     bool logs_ready = false;                  // alpha / beta / scaler of the last run have been made (hmm_make_logs)
     DevBuf<ChromDesc> d_chroms;
@@ -1573,8 +1717,11 @@ int hmm_launch(gbrs_hmm *h) {
     h->logs_ready = false;
     h->free_backward = WAVE || QUAD;                  // those sweeps rescale on their own (beta_corr_kernel)
     GBRS_HIP_CHECK(hipEventRecord(h->ev[1], sa));
-    hipLaunchKernelGGL(exp_emission_kernel, dim3((unsigned)((rows * S + 255) / 256)), dim3(256), 0, sa,
-                       rows * S, h->eprob.p, h->peprob.p);
+    if (!h->pe_ready) {                               // caller-supplied emissions (gbrs_hmm_set_eprob)
+        hipLaunchKernelGGL(exp_emission_kernel, dim3((unsigned)((rows * S + 255) / 256)), dim3(256), 0, sa,
+                           rows * S, h->eprob.p, h->peprob.p);
+        h->pe_ready = true;
+    }
     if constexpr (WAVE || QUAD) {
         // Three independent chains from here, each on its own stream (a sample's 40 chromosomes
         // occupy 40 CUs per chain):  A  alpha -> [join B] beta correction + outputs
@@ -1797,15 +1944,25 @@ int gbrs_hmm_set_expression(gbrs_hmm_t *h, int n_samples, const double *const *e
     const size_t em_lds = (size_t)EM_GENES * ((H * H + 1) + (H + 1) + (h->S + 1)) * sizeof(double);
     const int64_t em_blocks = ((h->total_genes + EM_GENES - 1) / EM_GENES) * n_samples;
     (void)total;
-    hipLaunchKernelGGL(emission_kernel, dim3((unsigned)em_blocks), dim3(64), em_lds, h->stream, H, h->S,
-                       h->total_genes, n_samples, h->expr.p, h->avecs.p, h->has_avec.p, h->init_vec.p,
-                       expr_threshold, sigma, h->eprob.p);
+    if (H == EM_LANES && n_samples >= EM_BATCH_MIN) {
+        // the gene-only part of the model once per EM_BATCH_SPB samples instead of once per sample
+        const dim3 grid((unsigned)((h->total_genes + EM_GENES - 1) / EM_GENES),
+                        (unsigned)((n_samples + EM_BATCH_SPB - 1) / EM_BATCH_SPB));
+        hipLaunchKernelGGL(emission_batch_kernel<EM_LANES>, grid, dim3(64), 0, h->stream, h->total_genes, n_samples,
+                           EM_BATCH_SPB, h->expr.p, h->avecs.p, h->has_avec.p, h->init_vec.p, expr_threshold, sigma,
+                           h->eprob.p, h->peprob.p);
+    } else {
+        hipLaunchKernelGGL(emission_kernel, dim3((unsigned)em_blocks), dim3(64), em_lds, h->stream, H, h->S,
+                           h->total_genes, n_samples, h->expr.p, h->avecs.p, h->has_avec.p, h->init_vec.p,
+                           expr_threshold, sigma, h->eprob.p, h->peprob.p);
+    }
     GBRS_HIP_CHECK(hipEventRecord(h->ev[1], h->stream));
     GBRS_HIP_CHECK(hipGetLastError());
     GBRS_HIP_CHECK(hipStreamSynchronize(h->stream));
     float ms = 0.f;
     if (hipEventElapsedTime(&ms, h->ev[0], h->ev[1]) == hipSuccess) h->t_emis = ms;
     h->have_eprob = true;
+    h->pe_ready = true;
     h->ran = false;
     return GBRS_OK;
 }
@@ -1823,6 +1980,7 @@ int gbrs_hmm_set_eprob(gbrs_hmm_t *h, int n_samples, const double *const *eprob)
                                      (size_t)cd.n_genes * h->S * sizeof(double), hipMemcpyHostToDevice));
     }
     h->have_eprob = true;
+    h->pe_ready = false;
     h->ran = false;
     h->t_emis = 0;
     return GBRS_OK;

@@ -257,3 +257,36 @@ def test_hmm_log_intermediates_follow_the_last_run():
         np.testing.assert_allclose(r["scaler"], g[f"scaler_{ch}"], rtol=1e-9, atol=1e-9)
     assert not np.allclose(first["alpha"], hmm.get(0, want=("alpha",))["alpha"])
     hmm.close()
+
+
+def test_batched_emission_kernel_matches_the_single_sample_kernel_bit_for_bit():
+    """From 4 samples on the emission model runs in emission_batch_kernel (gene-only part hoisted out of
+    the sample loop); it must produce exactly the single-sample kernel's emissions, including genes
+    below the expression threshold, genes without specificity data and a partly filled sample block."""
+    from gbrs_amd import synth
+    from gbrs_amd.hmm import DiplotypeHMM
+    p0 = synth.make_hmm_problem(H=8, genes_per_chrom=[61, 130], seed=77)
+    chroms = p0.chroms
+    rng = np.random.default_rng(3)
+    ns = 19
+    ex, av, ha = [], [], []
+    for c in chroms:
+        ids = p0.gene_ids[c]
+        e0 = np.array([p0.expr[g] for g in ids])
+        e = np.stack([e0] + [rng.gamma(1.0, 5.0, size=e0.shape) * (rng.random(e0.shape) < 0.5) for _ in range(ns - 1)])
+        e[3] *= 1e-9                                   # a sample below the threshold everywhere
+        ex.append(e)
+        ha.append(np.array([g in p0.avecs for g in ids], dtype=np.uint8))
+        av.append(np.array([p0.avecs.get(g, np.zeros((8, 8))) for g in ids]))
+    args = ([len(p0.gene_ids[c]) for c in chroms], [p0.tprob[c] for c in chroms])
+    batch = DiplotypeHMM(8, chroms, *args)
+    batch.set_expression(ex, av, ha, 1.5, 0.12)
+    one = DiplotypeHMM(8, chroms, *args)
+    for s in (0, 3, 15, 16, 18):
+        one.set_expression([e[s] for e in ex], av, ha, 1.5, 0.12)
+        for ci in range(len(chroms)):
+            a = batch.get(ci, sample=s, want=("eprob",))["eprob"]
+            b = one.get(ci, want=("eprob",))["eprob"]
+            np.testing.assert_array_equal(a, b, err_msg=f"sample {s} chromosome {ci}")
+    batch.close()
+    one.close()
