@@ -443,8 +443,9 @@ __global__ void exp_emission_kernel(int64_t n, const double *__restrict__ e, dou
 // and no global load sits on the sequential critical path:
 //     x_j = (sum_k y_{i-1}[k] * P[j,k]) / Z_{i-1} + tiny        P = exp(T), precomputed
 //     y_j = x_j * pe_i[j]                Z_i = sum_j y_j         pe = exp(e), precomputed
-// The kernel stores x and 1/Z; hmm_outputs_kernel turns them into the log-domain alpha and scaler
-// of the reference (same quantities up to rounding) and alpha-hat = x*pe/Z in parallel.
+// The kernel stores x and 1/Z; posterior_kernel recomputes alpha-hat = x*pe/Z from them and
+// hmm_outputs_kernel makes the log-domain alpha and scaler of the reference (same quantities up to
+// rounding), both in parallel over genes.
 // delta stays in the log domain on T itself: additions and max only, i.e. exact.
 template <int KMAX, int MAXT, bool EXACT>
 __global__ void __launch_bounds__(MAXT)
@@ -640,7 +641,7 @@ forward_viterbi_kernel(int S, int64_t genes_per_sample, int64_t bp_per_sample,
 // Backward (gbrs_utils.py:530-550) in the probability domain:
 //     bhat_i[j] = (sum_k P_i[k,j] * bhat_{i+1}[k] * pe_{i+1}[k]) / Z_i          bhat_{n-1} = 1/Z_{n-1}
 // pprob_t holds the transposed blocks Pt[i][j][k] = exp(T[i][k][j]) so that a thread reads a row.
-// beta = log(bhat) and the posterior are produced by hmm_outputs_kernel.
+// beta = log(bhat) is produced by hmm_outputs_kernel, the posterior by posterior_kernel.
 template <int KMAX, int MAXT, bool EXACT>
 __global__ void __launch_bounds__(MAXT)
 backward_kernel(int S, int64_t genes_per_sample, const ChromDesc *__restrict__ chroms,
@@ -1420,22 +1421,63 @@ beta_corr_kernel(int64_t genes_per_sample, const ChromDesc *__restrict__ chroms,
     }
 }
 
-// Outputs of the reference from the probability-domain sweeps, one thread per (sample, gene, state):
-//   parts & 2  gamma = ahat*bhat / sum_j(ahat*bhat), ahat = x*pe/Z recomputed here  (gbrs_utils.py:558-560)
-//              - the only array gbrs reconstruct saves; part of every run
+// Posterior gamma = ahat*bhat / sum_j(ahat*bhat), ahat = x*pe/Z recomputed here (gbrs_utils.py:558-560): the
+// only per-state array gbrs reconstruct saves, part of every run.  One thread per (sample, gene, state)
+// element and POST_GROUPS groups of OUT_ROWS rows per workgroup: a pure stream (four arrays in, one
+// out), so every thread puts all its 4*POST_GROUPS loads in flight before the first barrier
+// (one group per workgroup ran at 2.2 TB/s, latency-bound).
+constexpr int POST_GROUPS = 4;
+__global__ void __launch_bounds__(1024)
+posterior_kernel(int S, int OUT_ROWS, int64_t n_rows, const double *__restrict__ xsum,
+                 const double *__restrict__ peprob, const double *__restrict__ invz,
+                 const double *__restrict__ bhat, double *__restrict__ gamma) {
+    extern __shared__ double lds[];               // g[POST_GROUPS][OUT_ROWS * S], norm[POST_GROUPS * OUT_ROWS]
+    const int per = OUT_ROWS * S;
+    double *l_g = lds, *l_norm = lds + POST_GROUPS * per;
+    const int64_t r0 = (int64_t)blockIdx.x * OUT_ROWS * POST_GROUPS;
+    const int t = threadIdx.x;
+    const int row = t / S;
+    double ah[POST_GROUPS], bh[POST_GROUPS];
+    bool live[POST_GROUPS];
+#pragma unroll
+    for (int q = 0; q < POST_GROUPS; ++q) {
+        const int64_t rq = r0 + (int64_t)q * OUT_ROWS;
+        const int nr = (int)max((int64_t)0, min((int64_t)OUT_ROWS, n_rows - rq));
+        live[q] = t < nr * S;
+        ah[q] = bh[q] = 0.0;
+        if (live[q]) {
+            const int64_t o = rq * S + t;
+            ah[q] = (xsum[o] * peprob[o]) * invz[rq + row];      // alpha-hat = y / Z, y = x * pe as in the sweep
+            bh[q] = bhat[o];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < POST_GROUPS; ++q)
+        if (live[q]) l_g[q * per + t] = ah[q] * bh[q];
+    __syncthreads();
+    for (int rr = t; rr < POST_GROUPS * OUT_ROWS; rr += blockDim.x) {
+        if (r0 + rr >= n_rows) continue;
+        const double *g = l_g + (rr / OUT_ROWS) * per + (rr % OUT_ROWS) * S;
+        double norm = 0.0;
+        for (int s = 0; s < S; ++s) norm += g[s];               // sequential over states, as ndarray.sum(axis=0)
+        l_norm[rr] = norm;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < POST_GROUPS; ++q)
+        if (live[q]) gamma[(r0 + (int64_t)q * OUT_ROWS) * S + t] = ah[q] * bh[q] / l_norm[q * OUT_ROWS + row];
+}
+
+// The reference's log-domain intermediates, one thread per (sample, gene, state); made on the first
+// gbrs_hmm_get() that asks for one:
 //   parts & 1  alpha = log(x) + e - log(Z), scaler = -log(Z)                        (gbrs_utils.py:515-524)
 //   parts & 4  beta = log(bhat) [+ log C_i of the free-running backward sweep]      (gbrs_utils.py:542-549)
-//              - the log-domain intermediates, made on the first gbrs_hmm_get() that asks for one
 __global__ void __launch_bounds__(1024)
 hmm_outputs_kernel(int S, int OUT_ROWS /* (sample, gene) rows per workgroup */, int64_t n_rows, int parts,
                    const double *__restrict__ eprob, const double *__restrict__ xsum,
-                   const double *__restrict__ peprob, const double *__restrict__ invz,
-                   const double *__restrict__ bhat, const double *__restrict__ bcorr /* nullable */,
-                   double *__restrict__ alpha, double *__restrict__ scaler, double *__restrict__ beta,
-                   double *__restrict__ gamma) {
-    // every array is read and written as a contiguous stream
-    extern __shared__ double lds[];               // g[OUT_ROWS * S], norm[OUT_ROWS]
-    double *l_g = lds, *l_norm = lds + OUT_ROWS * S;
+                   const double *__restrict__ invz, const double *__restrict__ bhat,
+                   const double *__restrict__ bcorr /* nullable */, double *__restrict__ alpha,
+                   double *__restrict__ scaler, double *__restrict__ beta) {
     const int64_t r0 = (int64_t)blockIdx.x * OUT_ROWS;
     const int nr = (int)min((int64_t)OUT_ROWS, n_rows - r0);
     const int t = threadIdx.x;
@@ -1450,21 +1492,6 @@ hmm_outputs_kernel(int S, int OUT_ROWS /* (sample, gene) rows per workgroup */, 
         const double lb = log(bhat[o]);
         beta[o] = bcorr ? lb + bcorr[r0 + row] : lb;
     }
-    if (!(parts & 2)) return;
-    double ah = 0.0, bh = 0.0;
-    if (live) {
-        ah = (xsum[o] * peprob[o]) * invz[r0 + row];      // alpha-hat = y / Z, y = x * pe as in the sweep
-        bh = bhat[o];
-        l_g[t] = ah * bh;
-    }
-    __syncthreads();
-    if (t < nr) {
-        double norm = 0.0;
-        for (int s = 0; s < S; ++s) norm += l_g[t * S + s];      // sequential over states, as ndarray.sum(axis=0)
-        l_norm[t] = norm;
-    }
-    __syncthreads();
-    if (live) gamma[o] = ah * bh / l_norm[row];
 }
 
 // Backtrace (gbrs_utils.py:587-597): states[m] = argmax delta[:, n-1], states[t] = bp[t][states[t+1]]
@@ -1637,16 +1664,25 @@ int hmm_alloc_samples(gbrs_hmm *h, int n_samples) {
     return GBRS_OK;
 }
 
-// hmm_outputs_kernel over every (sample, gene) row of the handle
-void launch_outputs(gbrs_hmm *h, int parts, hipStream_t st) {
+// posterior_kernel / hmm_outputs_kernel over every (sample, gene) row of the handle
+void launch_posterior(gbrs_hmm *h, hipStream_t st) {
+    const int S = h->S;
+    const int64_t rows = h->total_genes * h->n_samples;
+    const int out_rows = std::max(1, 1024 / S), per_block = out_rows * POST_GROUPS;
+    const dim3 grid((unsigned)((rows + per_block - 1) / per_block)), block(((out_rows * S + 63) / 64) * 64);
+    const size_t lds = (size_t)POST_GROUPS * (out_rows * S + out_rows) * sizeof(double);
+    hipLaunchKernelGGL(posterior_kernel, grid, block, lds, st, S, out_rows, rows, h->xsum.p, h->peprob.p, h->invz.p,
+                       h->bhat.p, h->gamma.p);
+}
+
+void launch_logs(gbrs_hmm *h, int parts, hipStream_t st) {
     const int S = h->S;
     const int64_t rows = h->total_genes * h->n_samples;
     const int out_rows = std::max(1, 1024 / S);
     const dim3 grid((unsigned)((rows + out_rows - 1) / out_rows)), block(((out_rows * S + 63) / 64) * 64);
-    const size_t lds = (size_t)(out_rows * S + out_rows) * sizeof(double);
-    hipLaunchKernelGGL(hmm_outputs_kernel, grid, block, lds, st, S, out_rows, rows, parts, h->eprob.p, h->xsum.p,
-                       h->peprob.p, h->invz.p, h->bhat.p, h->free_backward ? h->bcorr.p : (const double *)nullptr,
-                       h->alpha.p, h->scaler.p, h->beta.p, h->gamma.p);
+    hipLaunchKernelGGL(hmm_outputs_kernel, grid, block, 0, st, S, out_rows, rows, parts, h->eprob.p, h->xsum.p,
+                       h->invz.p, h->bhat.p, h->free_backward ? h->bcorr.p : (const double *)nullptr,
+                       h->alpha.p, h->scaler.p, h->beta.p);
 }
 
 // The log-domain intermediates of the reference (alpha, scaler, beta).  gbrs reconstruct saves none of
@@ -1665,7 +1701,7 @@ int hmm_make_logs(gbrs_hmm *h) {
         hipLaunchKernelGGL(beta_corr_kernel, dim3(h->n_samples, h->n_chrom), dim3(256), 0, h->stream, h->total_genes,
                            h->d_chroms.p, h->invz.p, h->bscale.p, h->bcorr.p);
     }
-    launch_outputs(h, 1 | 4, h->stream);
+    launch_logs(h, 1 | 4, h->stream);
     GBRS_HIP_CHECK(hipGetLastError());
     GBRS_HIP_CHECK(hipStreamSynchronize(h->stream));
     h->logs_ready = true;
@@ -1792,7 +1828,7 @@ int hmm_launch(gbrs_hmm *h) {
         launch_backtrace(sc);
         GBRS_HIP_CHECK(hipEventRecord(h->ev_c, sc));
         GBRS_HIP_CHECK(hipStreamWaitEvent(sa, h->ev_b, 0));
-        launch_outputs(h, 2, sa);                     // the posterior is scale free: no beta correction needed
+        launch_posterior(h, sa);                      // the posterior is scale free: no beta correction needed
         GBRS_HIP_CHECK(hipEventRecord(h->ev[3], sa));
         GBRS_HIP_CHECK(hipStreamWaitEvent(sa, h->ev_c, 0));
         GBRS_HIP_CHECK(hipEventRecord(h->ev[4], sa));
@@ -1817,7 +1853,7 @@ int hmm_launch(gbrs_hmm *h) {
         hipLaunchKernelGGL((backward_kernel<KMAX, MAXT, EXACT>), unit_grid, dim3(threads),
                            2 * S * sizeof(double), sa, S, h->total_genes, h->d_chroms.p, h->pprob_t.p,
                            h->peprob.p, h->invz.p, h->bhat.p);
-        launch_outputs(h, 2, sa);
+        launch_posterior(h, sa);
         GBRS_HIP_CHECK(hipEventRecord(h->ev[3], sa));
         launch_backtrace(sa);
         GBRS_HIP_CHECK(hipEventRecord(h->ev[4], sa));
