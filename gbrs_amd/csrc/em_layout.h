@@ -108,6 +108,19 @@ __device__ __forceinline__ uint32_t find_column(const uint64_t *__restrict__ col
     return lo;
 }
 
+// the same, searching upwards from a column c0 known to be at or before the answer (col_ptr[c0] <= k):
+// doubling steps, then bisection; one or two probes when the answer is c0 or close to it
+__device__ __forceinline__ uint32_t find_column_from(const uint64_t *__restrict__ col_ptr, uint32_t c0,
+                                                     uint32_t ncols, uint64_t k) {
+    uint32_t lo = c0, step = 1;
+    while (lo + step < ncols && col_ptr[lo + step] <= k) {
+        lo += step;
+        step <<= 1;
+    }
+    const uint32_t hi = min(lo + step, ncols) - 1;        // col_ptr[hi + 1] > k or hi is the last column
+    return find_column(col_ptr, lo, hi, k);
+}
+
 __device__ __forceinline__ uint32_t entry_column(const uint64_t *__restrict__ col_ptr, uint32_t ncols,
                                                  uint64_t k, uint64_t n) {
     // the wave's entries are consecutive: search the wave's first and last entry, then only

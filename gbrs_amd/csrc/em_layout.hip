@@ -100,18 +100,37 @@ struct BuildFlags {
     unsigned int n_long;         // rows with more than max_row_words(H) loci
 };
 
+// Every wavefront takes a contiguous span of KEY_SPAN entries: one full search for the column of its
+// first entry, after that columns only move forward (a column holds some hundreds of entries, so most
+// 64-entry steps stay inside the current one).  A full search per 64 entries made this the slowest
+// kernel of the build: two chains of ~20 dependent loads for every 64 keys.
+constexpr int KEY_ITERS = 32, KEY_SPAN = 64 * KEY_ITERS;
 __global__ void __launch_bounds__(256)
-make_keys_kernel(uint64_t n, uint32_t ncols, uint32_t L, uint64_t R, const uint64_t *__restrict__ col_ptr,
-                 const uint32_t *__restrict__ ent_row, uint64_t *__restrict__ keys, BuildFlags *flags) {
-    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k - (threadIdx.x & 63) >= n) return;
-    const bool live = k < n;
-    const uint32_t c = entry_column(col_ptr, ncols, live ? k : n - 1, n);
-    if (!live) return;
-    const uint32_t h = c / L, l = c - h * L;
-    const uint32_t r = ent_row[k];
-    if (r >= R) flags->bad_row = 1;
-    keys[k] = ((uint64_t)r << 32) | ((uint64_t)l << 5) | h;
+make_keys_kernel(uint64_t n, uint32_t ncols, uint32_t L, uint64_t R, unsigned row_shift,
+                 const uint64_t *__restrict__ col_ptr, const uint32_t *__restrict__ ent_row,
+                 uint64_t *__restrict__ keys, BuildFlags *flags) {
+    // key = row << row_shift | locus << 5 | haplotype; row_shift = 32, or 5 + the locus bits so that a
+    // radix sort of the used bits has no all-zero digit to pass over
+    const int lane = threadIdx.x & 63;
+    const uint64_t base = ((uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * KEY_SPAN;
+    if (base >= n) return;
+    uint32_t c = 0;
+    if (lane == 0) c = find_column(col_ptr, 0, ncols - 1, base);
+    c = __shfl(c, 0, WAVE);
+    bool bad = false;
+    for (int it = 0; it < KEY_ITERS; ++it) {
+        const uint64_t kb = base + (uint64_t)it * 64;
+        if (kb >= n) break;
+        c = find_column_from(col_ptr, c, ncols, kb);              // uniform: the column of the step's first entry
+        const uint64_t k = kb + lane;
+        if (k >= n) continue;
+        const uint32_t mine = col_ptr[c + 1] > min(kb + 63, n - 1) ? c : find_column_from(col_ptr, c, ncols, k);
+        const uint32_t h = mine / L, l = mine - h * L;
+        const uint32_t r = ent_row[k];
+        bad |= r >= R;
+        keys[k] = ((uint64_t)r << row_shift) | ((uint64_t)l << 5) | h;
+    }
+    if (bad) flags->bad_row = 1;
 }
 
 __global__ void pair_flag_kernel(uint64_t n, const uint64_t *__restrict__ keys, uint32_t *__restrict__ flag,
@@ -128,16 +147,17 @@ __global__ void pair_flag_kernel(uint64_t n, const uint64_t *__restrict__ keys, 
 }
 
 __global__ void emit_pairs_kernel(uint64_t n, const uint64_t *__restrict__ keys, const uint32_t *__restrict__ flag,
-                                  const uint32_t *__restrict__ pidx, uint32_t *__restrict__ prow,
-                                  uint32_t *__restrict__ ploc, uint32_t *__restrict__ pmask) {
+                                  const uint32_t *__restrict__ pidx, unsigned row_shift,
+                                  uint32_t *__restrict__ prow, uint32_t *__restrict__ ploc,
+                                  uint32_t *__restrict__ pmask) {
     const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n || !flag[k]) return;
     const uint64_t key = keys[k];
     uint32_t mask = 0;
     for (uint64_t j = k; j < n && (keys[j] >> 5) == (key >> 5); ++j) mask |= 1u << (uint32_t)(keys[j] & 31);
     const uint32_t p = pidx[k];
-    prow[p] = (uint32_t)(key >> 32);
-    ploc[p] = (uint32_t)((key >> 5) & 0x7FFFFFFu);
+    prow[p] = (uint32_t)(key >> row_shift);
+    ploc[p] = (uint32_t)((key >> 5) & ((1u << (row_shift - 5)) - 1u));
     pmask[p] = mask;
 }
 
@@ -683,7 +703,7 @@ int compress_device(CompressResult &out, uint64_t R, uint32_t L, uint32_t H, uin
     if (N) {
         DevBuf<uint64_t> keys, keys2;
         GBRS_TRY(keys.alloc(N)); GBRS_TRY(keys2.alloc(N));
-        hipLaunchKernelGGL(make_keys_kernel, dim3(grid_for(N)), dim3(256), 0, s, N, H * L, L, R, col_ptr, ent_row, keys.p,
+        hipLaunchKernelGGL(make_keys_kernel, dim3(grid_for(N, 4 * KEY_SPAN)), dim3(256), 0, s, N, H * L, L, R, 32u, col_ptr, ent_row, keys.p,
                            d_flags.p);
         GBRS_TRY(sort_keys64(sc, keys.p, keys2.p, N, 32 + bits_for(R - 1), s));
         keys.release();
@@ -699,7 +719,7 @@ int compress_device(CompressResult &out, uint64_t R, uint32_t L, uint32_t H, uin
         if (hf.duplicate) return fail(GBRS_ERR_INVALID, "duplicate (row, locus, haplotype) entry: the CSC arrays must be canonical");
         P = P32;
         GBRS_TRY(prow.alloc(P)); GBRS_TRY(ploc.alloc(P)); GBRS_TRY(pmask.alloc(P));
-        hipLaunchKernelGGL(emit_pairs_kernel, dim3(grid_for(N)), dim3(256), 0, s, N, keys2.p, pflag.p, pidx.p, prow.p, ploc.p,
+        hipLaunchKernelGGL(emit_pairs_kernel, dim3(grid_for(N)), dim3(256), 0, s, N, keys2.p, pflag.p, pidx.p, 32u, prow.p, ploc.p,
                            pmask.p);
         GBRS_HIP_CHECK(hipStreamSynchronize(s));
         keys2.release(); pflag.release(); pidx.release();
@@ -818,13 +838,18 @@ int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L, uint32_t H, uint6
 
     // 1. entries -> sorted (row, locus, hap) keys
     DevBuf<uint64_t> keys, keys2;
+    stg.mark("0 setup");
     GBRS_TRY(keys.alloc(N));
     GBRS_TRY(keys2.alloc(N));
-    hipLaunchKernelGGL(make_keys_kernel, dim3(grid_for(N)), dim3(256), 0, s, N, H * L, L, R, col_ptr, ent_row,
-                       keys.p, d_flags.p);
-    GBRS_TRY(sort_keys64(sc, keys.p, keys2.p, N, 32 + bits_for(R - 1), s));
+    stg.mark("1a key buffers");
+    const unsigned row_shift = 5 + bits_for(L - 1);           // <= 32 (L < 2^27 checked above)
+    hipLaunchKernelGGL(make_keys_kernel, dim3(grid_for(N, 4 * KEY_SPAN)), dim3(256), 0, s, N, H * L, L, R, row_shift,
+                       col_ptr, ent_row, keys.p, d_flags.p);
+    stg.mark("1b make keys");
+    GBRS_TRY(sort_keys64(sc, keys.p, keys2.p, N, row_shift + bits_for(R - 1), s));
+    stg.mark("1c sort entries");
     keys.release();
-    stg.mark("1 sort entries");
+    stg.mark("1d release");
     // 2. pairs
     DevBuf<uint32_t> pflag, pidx;
     GBRS_TRY(pflag.alloc(N));
@@ -842,8 +867,8 @@ int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L, uint32_t H, uint6
     GBRS_TRY(prow.alloc(P));
     GBRS_TRY(ploc.alloc(P));
     GBRS_TRY(pmask.alloc(P));
-    hipLaunchKernelGGL(emit_pairs_kernel, dim3(grid_for(N)), dim3(256), 0, s, N, keys2.p, pflag.p, pidx.p, prow.p,
-                       ploc.p, pmask.p);
+    hipLaunchKernelGGL(emit_pairs_kernel, dim3(grid_for(N)), dim3(256), 0, s, N, keys2.p, pflag.p, pidx.p, row_shift,
+                       prow.p, ploc.p, pmask.p);
     GBRS_HIP_CHECK(hipStreamSynchronize(s));
     keys2.release(); pflag.release(); pidx.release();
     stg.mark("2 pairs");
