@@ -46,7 +46,7 @@ def parse():
     ap.add_argument("--no-merged-line", action="store_true")
     ap.add_argument("--from-host", action="store_true", help="also time gbrs_em_create from host (numpy) arrays: PCIe copy + layout build")
     ap.add_argument("--cpu-rows", type=int, default=2_000_000)
-    ap.add_argument("--cpu-iters", type=int, default=10)
+    ap.add_argument("--cpu-iters", type=int, default=60, help="oracle iterations timed for cpu_baseline (stops at 25 s)")
     ap.add_argument("--hmm-samples", type=int, default=1)
     ap.add_argument("--hmm-batch", type=int, default=64, help="second HMM measurement with this many samples in one launch (0 = skip)")
     ap.add_argument("--hmm-reps", type=int, default=5)
@@ -232,12 +232,15 @@ def hmm_bench(args, torch, ns=None, with_cpu=True):
         out["batched"] = {k: b[k] for k in ("value", "unit", "ms_per_pass", "n_samples", "kernels_ms", "roofline")}
     if with_cpu and not args.no_cpu_baseline:
         from oracle import hmm_oracle
-        sub = synth.make_hmm_problem(H=8, genes_per_chrom=[1500, 1500], seed=synth.SEED_HMM)
+        # the whole single-sample workload when it has 8 founders (about 10 s of oracle time), else a slice
+        sub = prob if HH == 8 else synth.make_hmm_problem(H=8, genes_per_chrom=[1500, 1500], seed=synth.SEED_HMM)
         t0 = time.perf_counter()
         hmm_oracle.reconstruct_arrays(sub.hap_names, sub.chroms, sub.gene_ids, sub.tprob, sub.expr, sub.avecs)
         dt = time.perf_counter() - t0
         out["cpu_baseline"] = dict(value=sub.num_genes / dt, unit="genes/s", cores=1, kind="port",
-                                   sample=f"numpy oracle on 2 chromosomes x 1500 genes ({dt:.1f} s)")
+                                   sample=f"numpy oracle on {len(sub.chroms)} chromosomes, {sub.num_genes} genes, "
+                                          f"1 sample ({dt:.1f} s); host has {os.cpu_count()} cores, reference is "
+                                          f"single-threaded")
     return out
 
 
