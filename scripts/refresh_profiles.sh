@@ -1,6 +1,7 @@
 set -e
 mkdir -p gpurun_out/final
 python -m pytest tests -m gpu -x -q > gpurun_out/final/pytest.log 2>&1
+python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/final/smoke.log 2>&1
 python bench.py --from-host > gpurun_out/final/bench_default.log 2>&1
 python bench.py --rows 200000 --steps 2 --warmup 1 --no-cpu-baseline --no-merged-line --hmm-haps 16 --hmm-batch 8 > gpurun_out/final/bench_h16.log 2>&1
 export TMPDIR=/tmp R=$PWD; cd /tmp
