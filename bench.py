@@ -51,6 +51,7 @@ def parse():
     ap.add_argument("--hmm-batch", type=int, default=64, help="second HMM measurement with this many samples in one launch (0 = skip)")
     ap.add_argument("--hmm-reps", type=int, default=5)
     ap.add_argument("--hmm-haps", type=int, default=8, help="founder haplotypes of the HMM measurement (16 = config 5's 136 states)")
+    ap.add_argument("--no-overlap", action="store_true", help="N > 1: one engine per GPU, all-reduce not overlapped with the E-step")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo only to rehearse N>1 on one GPU)")
     return ap.parse_args()
 
@@ -66,9 +67,9 @@ def em_bench(args, rank, world, torch, dist):
     from gbrs_amd import _lib, synth, synth_torch
     from gbrs_amd.engine import EmEngine
     dev = f"cuda:{torch.cuda.current_device()}"
-    seed = synth.SEED_BASE_EM + 1 + rank
     t0 = time.perf_counter()
-    prob = synth_torch.make_em_problem_device(args.rows, args.haps, args.loci, seed, dev)
+    prob = synth_torch.make_em_problem_device(args.rows, args.haps, args.loci, synth.SEED_BASE_EM + 1, dev,
+                                              row_seed=synth.SEED_BASE_EM + 1 + rank)
     t_gen = time.perf_counter() - t0
     t0 = time.perf_counter()
     eng = EmEngine.from_device(
@@ -151,6 +152,115 @@ def em_bench(args, rank, world, torch, dist):
         res["step_ms"] = inf.last_step_ms
     eng.close()
     return res
+
+
+def balanced_gene_boundary_device(prob, torch):
+    """The gene start closest to the locus that halves this rank's entry count (0 if there is none)."""
+    L = prob["L"]
+    cum = torch.zeros(L + 1, dtype=torch.int64, device=prob["indptr"][0].device)
+    for ip in prob["indptr"]:
+        cum += ip.to(torch.int64)
+    l_half = int(torch.searchsorted(cum, cum[-1:] // 2)[0])
+    gs = prob["gene_starts"]
+    k = int(gs.searchsorted(l_half))
+    cands = [int(gs[i]) for i in (k - 1, k) if 0 <= i < len(gs) and 0 < int(gs[i]) < L]
+    return min(cands, key=lambda l: abs(l - l_half)) if cands else 0
+
+
+def split_problem_device(prob, l_split, torch):
+    """Cut the sample's loci at l_split (device tensors, views of the originals).  Returns
+    (half_a, half_b), or None when some row has entries on both sides or a side is empty."""
+    R = prob["R"]
+    dev = prob["indptr"][0].device
+    a_ip, a_ix, b_ip, b_ix = [], [], [], []
+    in_a = torch.zeros(R, dtype=torch.bool, device=dev)
+    in_b = torch.zeros(R, dtype=torch.bool, device=dev)
+    for ip, ix in zip(prob["indptr"], prob["indices"]):
+        cut = int(ip[l_split])
+        a_ip.append(torch.clamp(ip, max=cut).contiguous())
+        b_ip.append((torch.clamp(ip, min=cut) - cut).contiguous())
+        a_ix.append(ix[:cut])
+        b_ix.append(ix[cut:])
+        in_a[a_ix[-1].long()] = True
+        in_b[b_ix[-1].long()] = True
+    if bool((in_a & in_b).any()) or not (bool(in_a.any()) and bool(in_b.any())):
+        return None
+    return (a_ip, a_ix), (b_ip, b_ix)
+
+
+def em_bench_pipelined(args, rank, world, torch, dist):
+    """N > 1: every rank holds one shard of rows, cut into two locus ranges with an engine each, so that
+    the RCCL all-reduce of one range overlaps the E-step of the other (gbrs_amd.dist.PipelinedShardedEM).
+    Returns None when the sample cannot be cut (the caller falls back to one engine per rank)."""
+    from gbrs_amd import synth, synth_torch
+    from gbrs_amd.dist import PipelinedShardedEM
+    from gbrs_amd.engine import EmEngine
+    devno = torch.cuda.current_device()
+    dev = f"cuda:{devno}"
+    t0 = time.perf_counter()
+    prob = synth_torch.make_em_problem_device(args.rows, args.haps, args.loci, synth.SEED_BASE_EM + 1, dev,
+                                              row_seed=synth.SEED_BASE_EM + 1 + rank)
+    t_gen = time.perf_counter() - t0
+    # one cut for all ranks (the all-reduce is over a locus range): rank 0's balanced gene boundary
+    ls = torch.tensor([balanced_gene_boundary_device(prob, torch)], dtype=torch.int64, device=dev)
+    dist.broadcast(ls, src=0)
+    l_split = int(ls.item())
+    cut = split_problem_device(prob, l_split, torch) if 0 < l_split < prob["L"] else None
+    ok = torch.tensor([1 if cut is not None else 0], device=dev)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)              # every rank takes the same path
+    if int(ok.item()) == 0:
+        return None
+    half_a, half_b = cut
+    t0 = time.perf_counter()
+    engs = [EmEngine.from_device(prob["R"], prob["L"], prob["H"], [t.data_ptr() for t in ip],
+                                 [t.data_ptr() for t in ix], None, prob["eff_len"].data_ptr(), device=devno,
+                                 flags=args.flags)
+            for ip, ix in (half_a, half_b)]
+    t_create = time.perf_counter() - t0
+    n_entries, H = prob["N"], prob["H"]
+    L = prob["L"]
+    del prob, half_a, half_b, cut
+    torch.cuda.empty_cache()
+    stream = torch.cuda.current_stream().cuda_stream
+    for e in engs:
+        e.set_stream(stream)
+    views = {}
+
+    def start_allreduce(ptr, n, lo, hi):
+        if ptr not in views:
+            views[ptr] = torch.as_tensor(DevArray(ptr, n), device=dev)
+        return dist.all_reduce(views[ptr][lo * H:hi * H], async_op=True)
+
+    drv = PipelinedShardedEM(engs[0], engs[1], l_split, L, start_allreduce)
+    drv.prepare(0.0)
+    drv.step(args.warmup)
+    for e in engs:
+        e.sync()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    drv.step(args.steps)
+    for e in engs:
+        e.sync()
+    dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt = float(tt.item())
+    # per-launch E-step time of the two halves: local steps without the collective
+    estep_ms = step_ms = 0.0
+    infos = []
+    for e in engs:
+        e.step(min(args.steps, 10))
+        inf = e.info()
+        estep_ms += inf.last_estep_ms
+        step_ms += inf.last_step_ms
+        infos.append(inf)
+    for e in engs:
+        e.close()
+    return dict(dt=dt, t_gen=t_gen, t_create=t_create, t_create_host=None, N=n_entries, info=infos[0], infos=infos,
+                estep_ms=estep_ms, step_ms=step_ms, l_split=l_split)
 
 
 def em_cpu_baseline(args):
@@ -266,12 +376,17 @@ def main():
     if world > 1:
         dist.barrier()
 
-    em = em_bench(args, rank, world, torch, dist)
+    em = None
+    if world > 1 and not args.no_overlap and not args.merge:
+        em = em_bench_pipelined(args, rank, world, torch, dist)
+    if em is None:
+        em = em_bench(args, rank, world, torch, dist)
     inf = em["info"]
+    infos = em.get("infos", [inf])
     ms_per_step = em["dt"] / args.steps * 1e3
     value = world * args.steps / em["dt"]
-    algo = int(inf.algorithmic_bytes)
-    moved = int(inf.bytes_per_iter)
+    algo = sum(int(i.algorithmic_bytes) for i in infos)
+    moved = sum(int(i.bytes_per_iter) for i in infos)
     priced = min(algo, moved)
     estep_s = em["estep_ms"] * 1e-3
     line = {
@@ -282,10 +397,15 @@ def main():
         "config": {"workload": f"configs[1]: single DO sample, R={args.rows} reads x H={args.haps} x "
                                f"L={args.loci} isoforms, N={em['N']} alignment entries, quantify Model 4, "
                                f"tol=0 fixed iterations" + (", rows sharded one 40M-read shard per GPU + "
-                               "RCCL all-reduce of the H*L vector per iteration" if world > 1 else ""),
+                               "RCCL all-reduce of the H*L vector per iteration" if world > 1 else "")
+                               + (f"; loci cut at gene boundary {em['l_split']} into two engines per GPU, the "
+                                  "all-reduce of one range overlapped with the E-step of the other"
+                                  if "l_split" in em else ""),
                    "layout": int(inf.layout), "merge_identical_rows": bool(args.merge),
-                   "device_rows": int(inf.num_device_rows), "device_words": int(inf.num_device_words),
-                   "tiles": int(inf.num_tiles), "slots": int(inf.num_slots), "long_rows": int(inf.num_long_rows)},
+                   "device_rows": sum(int(i.num_device_rows) for i in infos),
+                   "device_words": sum(int(i.num_device_words) for i in infos),
+                   "tiles": sum(int(i.num_tiles) for i in infos), "slots": sum(int(i.num_slots) for i in infos),
+                   "long_rows": sum(int(i.num_long_rows) for i in infos)},
         "roofline": {"bound": "hbm", "achieved": priced / estep_s / 1e9 if estep_s > 0 else None,
                      "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": priced / estep_s / 1e9 / HBM_PEAK_GBS if estep_s > 0 else None,

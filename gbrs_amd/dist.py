@@ -6,6 +6,10 @@ its rows into the (L x H) partial-sum vector, the ranks exchange that vector wit
 the identical M-step and stopping rule redundantly.  There is no other
 collective on the data path.
 
+PipelinedShardedEM hides that all-reduce behind compute: the loci are cut into two ranges that no row
+straddles (a gene boundary), each range gets its own engine on the rank, and the all-reduce of one
+range's vector slice runs while the E-step of the other range is on the GPU.
+
 The engine is injected: the product passes gbrs_amd.engine.EmEngine (HIP); the CPU tests pass a
 numpy stand-in with the same five methods to check that sharding + all-reduce reproduce the
 unsharded result without a GPU.
@@ -92,3 +96,125 @@ def torch_allreduce(dist, torch, device):
         dist.all_reduce(cache[key])
         torch.cuda.synchronize(device)
     return allreduce
+
+
+# ---- overlap of the all-reduce with the E-step --------------------------------------------------
+
+def split_at_locus(indptr, indices, l_split):
+    """CSC arrays of the column ranges [0, l_split) and [l_split, L): full-length indptr (the other
+    range's columns are empty), original row ids.  Returns ((indptr_a, indices_a), (indptr_b, indices_b))."""
+    a_ip, a_ix, b_ip, b_ix = [], [], [], []
+    for ip, ix in zip(indptr, indices):
+        ip = np.asarray(ip)
+        cut = ip[l_split]
+        a_ip.append(np.minimum(ip, cut).astype(np.uint32))
+        a_ix.append(np.ascontiguousarray(ix[:int(cut)], dtype=np.uint32))
+        b_ip.append((np.maximum(ip, cut) - cut).astype(np.uint32))
+        b_ix.append(np.ascontiguousarray(ix[int(cut):], dtype=np.uint32))
+    return (a_ip, a_ix), (b_ip, b_ix)
+
+
+def rows_are_disjoint(indices_a, indices_b, num_rows):
+    """True when no row has entries in both column ranges (the condition for PipelinedShardedEM)."""
+    in_a = np.zeros(num_rows, dtype=bool)
+    in_b = np.zeros(num_rows, dtype=bool)
+    for ix in indices_a:
+        in_a[np.asarray(ix, dtype=np.int64)] = True
+    for ix in indices_b:
+        in_b[np.asarray(ix, dtype=np.int64)] = True
+    return not bool((in_a & in_b).any())
+
+
+def balanced_gene_boundary(indptr, gene_starts):
+    """The gene start closest to the locus that halves the entry count."""
+    cum = np.zeros(len(indptr[0]), dtype=np.int64)
+    for ip in indptr:
+        cum += np.asarray(ip, dtype=np.int64)
+    l_half = int(np.searchsorted(cum, cum[-1] / 2))
+    gs = np.asarray(gene_starts, dtype=np.int64)
+    k = int(np.searchsorted(gs, l_half))
+    cands = [int(gs[i]) for i in (k - 1, k) if 0 <= i < len(gs)]
+    return min(cands, key=lambda l: abs(l - l_half)) if cands else 0
+
+
+class PipelinedShardedEM:
+    """Two engines per rank over locus ranges [0, l_split) and [l_split, L) that no row straddles, so
+    the two halves are independent EM problems that only share the convergence test.  Per iteration
+    and half: E-step over the rank's rows -> all-reduce of that half's slice of the (L x H) vector ->
+    M-step; the halves are interleaved so that the all-reduce of one is in flight (RCCL's own stream)
+    while the E-step of the other occupies the GPU:
+
+        E_a  AR_a | E_b  AR_b | wait AR_a  M_a  E_a'  AR_a' | wait AR_b  M_b  E_b'  AR_b' | ...
+
+    `start_allreduce(buffer, n, l_lo, l_hi)` starts the in-place sum of loci [l_lo, l_hi) of the
+    engine's partial buffer across ranks and returns an object whose wait() orders the engine's
+    stream after it.  pseudocount must be 0 (its renormalisation couples the halves); the stopping
+    rule is evaluated on the host every `check_every` iterations, so a run may go up to
+    check_every - 1 iterations past the reference's stopping point - use ShardedEM when the iteration
+    count has to match."""
+
+    def __init__(self, engine_a, engine_b, l_split, num_loci, start_allreduce):
+        self.eng = (engine_a, engine_b)
+        self.rng = ((0, l_split), (l_split, num_loci))
+        self.start = start_allreduce
+        self.num_iters = 0
+        self.err_history = []
+
+    def prepare(self, pseudocount=0.0):
+        if pseudocount != 0.0:
+            raise RuntimeError('PipelinedShardedEM needs pseudocount 0 (the pseudocount renormalisation couples the halves)')
+        pend = []
+        for e, (lo, hi) in zip(self.eng, self.rng):
+            p, n = e.prepare_partial()
+            pend.append(self.start(p, n, lo, hi))
+        for e, w in zip(self.eng, pend):
+            w.wait()
+            e.finish_prepare(0.0)
+
+    def step(self, k=1):
+        """k EM iterations (no error report)."""
+        if k <= 0:
+            return
+        pend = []
+        for e, (lo, hi) in zip(self.eng, self.rng):
+            p, n = e.estep_partial()
+            pend.append(self.start(p, n, lo, hi))
+        for _ in range(k - 1):
+            for i, (e, (lo, hi)) in enumerate(zip(self.eng, self.rng)):
+                pend[i].wait()
+                e.finish_step(want_err=False)
+                p, n = e.estep_partial()
+                pend[i] = self.start(p, n, lo, hi)
+        for e, w in zip(self.eng, pend):
+            w.wait()
+            e.finish_step(want_err=False)
+        self.num_iters += k
+
+    def theta(self):
+        """(H x L): each engine's theta is zero outside its own locus range."""
+        parts = [e.theta() if callable(e.theta) else e.theta for e in self.eng]
+        return np.asarray(parts[0]) + np.asarray(parts[1])
+
+    @staticmethod
+    def _err_sum(prev, cur):        # EMfactory.py:268-278
+        a = prev.sum(axis=0)
+        b = cur.sum(axis=0)
+        return float(np.abs(b * (1e6 / b.sum()) - a * (1e6 / a.sum())).sum())
+
+    def run(self, model=4, tol=0.001, max_iters=999, check_every=8):
+        if model != 4:
+            raise RuntimeError('The read normalization model should be 1, 2, 3, or 4.' if model not in (1, 2, 3)
+                               else f'Multiread model {model} is not implemented by the MI355X path')
+        self.num_iters = 0
+        self.err_history = []
+        target = 1000000.0 * tol
+        while self.num_iters < max_iters:
+            k = min(check_every, max_iters - self.num_iters)
+            self.step(k - 1)
+            prev = self.theta()
+            self.step(1)
+            err = self._err_sum(prev, self.theta())
+            self.err_history.append(err)
+            if err <= target:
+                break
+        return self.num_iters

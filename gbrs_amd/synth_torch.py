@@ -12,10 +12,12 @@ import torch
 from . import synth
 
 
-def make_em_problem_device(R, H, L, seed, device="cuda:0"):
+def make_em_problem_device(R, H, L, seed, device="cuda:0", row_seed=None):
     """Returns dict(indptr=[H int32 tensors L+1], indices=[H int32 tensors], eff_len (H x L) float64
     tensor, N, groups info) with every array resident on `device`.  int32 tensors carry the
-    uint32 bit patterns the C ABI expects (all values < 2^31 at these sizes)."""
+    uint32 bit patterns the C ABI expects (all values < 2^31 at these sizes).  `seed` fixes the sample
+    model (genes, abundances, lengths); `row_seed` (default: seed) the reads drawn from it, so the ranks
+    of a sharded run draw different reads of one sample."""
     assert R < 2**31 and L < 2**24
     rng = np.random.default_rng(seed)
     sizes, starts, gene_of = synth._gene_layout(rng, L)
@@ -24,7 +26,7 @@ def make_em_problem_device(R, H, L, seed, device="cuda:0"):
     raw_len = np.round(rng.lognormal(7.3, 0.6, size=L))
     dev = torch.device(device)
     g = torch.Generator(device=dev)
-    g.manual_seed(int(seed))
+    g.manual_seed(int(seed if row_seed is None else row_seed))
     cdf = torch.from_numpy(np.cumsum(p)).to(dev)
     cdf[-1] = 1.0
     t = torch.searchsorted(cdf, torch.rand(R, generator=g, device=dev, dtype=torch.float64), right=True)
@@ -60,4 +62,4 @@ def make_em_problem_device(R, H, L, seed, device="cuda:0"):
     eff_len = torch.from_numpy(np.ascontiguousarray(np.tile(eff, (H, 1)))).to(dev)
     torch.cuda.synchronize(dev)
     return dict(indptr=indptr, indices=indices, eff_len=eff_len, N=n_total, R=R, H=H, L=L,
-                num_groups=len(sizes))
+                num_groups=len(sizes), gene_starts=np.asarray(starts, dtype=np.int64))

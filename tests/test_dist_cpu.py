@@ -77,3 +77,81 @@ def test_shard_rows_balances_entries():
         for h in range(4):
             assert int(ip[h][-1]) == len(ix[h]) and (ix[h] < (r1 - r0)).all()
     assert tot == inc.nnz
+
+
+def _pipelined_worker(rank, world, port, path, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    from conftest import em_case_inputs as inputs, load_golden as load
+    from cpu_engine import NumpyEngine
+    from gbrs_amd.dist import (PipelinedShardedEM, balanced_gene_boundary, rows_are_disjoint, shard_rows,
+                               split_at_locus)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = load(path)
+    R, L, H, indptr, indices, count, eff_len, groups, gtmask = inputs(g)
+    l_split = balanced_gene_boundary(indptr, sorted(min(m) for m in groups))
+    r0, r1, ip, ix, cnt = shard_rows(indptr, indices, count, R, rank, world)
+    (a_ip, a_ix), (b_ip, b_ix) = split_at_locus(ip, ix, l_split)
+    assert 0 < l_split < L and rows_are_disjoint(a_ix, b_ix, r1 - r0)
+    eng_a = NumpyEngine(r1 - r0, L, H, a_ip, a_ix, cnt, eff_len)
+    eng_b = NumpyEngine(r1 - r0, L, H, b_ip, b_ix, cnt, eff_len)
+
+    class Done:
+        def wait(self):
+            pass
+
+    def start_allreduce(arr, n, lo, hi):       # the numpy stand-in's buffer is (H x L)
+        t = torch.from_numpy(np.ascontiguousarray(arr[:, lo:hi]))
+        dist.all_reduce(t)
+        arr[:, lo:hi] = t.numpy()
+        return Done()
+    drv = PipelinedShardedEM(eng_a, eng_b, l_split, L, start_allreduce)
+    drv.prepare(0.0)
+    drv.step(int(g["num_iters"]))              # exactly the reference's iteration count
+    theta_fixed = drv.theta()
+    drv.prepare(0.0)                           # and again under the driver's own stopping rule
+    n = drv.run(model=4, tol=float(g["tol"]), max_iters=int(g["max_iters"]), check_every=4)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), theta=theta_fixed, n=n, l_split=l_split,
+             err=np.array(drv.err_history))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("name", ["h8_count_len", "h2_len"])
+def test_two_rank_pipelined_halves_match_reference(tmp_path, name):
+    """Rows sharded over 2 ranks AND loci cut at a gene boundary into two engines per rank whose
+    all-reduces interleave: after the reference's number of iterations theta is the reference's; under
+    the driver's own stopping rule (checked every 4 iterations) the run ends within 3 iterations after
+    the reference's."""
+    import torch.multiprocessing as mp
+    path = [p for p in golden_files("em") if p.endswith(f"em_{name}.npz")][0]
+    g = load_golden(path)
+    port = _free_port()
+    mp.spawn(_pipelined_worker, args=(2, port, path, str(tmp_path)), nprocs=2, join=True)
+    a = np.load(tmp_path / "rank0.npz")
+    b = np.load(tmp_path / "rank1.npz")
+    np.testing.assert_array_equal(a["theta"], b["theta"])
+    n_ref = int(g["num_iters"])
+    assert n_ref <= int(a["n"]) == int(b["n"]) <= min(n_ref + 3, int(g["max_iters"]))
+    assert float(a["err"][-1]) <= 1e6 * float(g["tol"]) or int(a["n"]) == int(g["max_iters"])
+    np.testing.assert_allclose(a["theta"], g["theta_final"], rtol=1e-9, atol=1e-300)
+
+
+def test_split_at_locus_partitions_entries():
+    from gbrs_amd import synth
+    from gbrs_amd.dist import rows_are_disjoint, split_at_locus
+    inc = synth.make_em_problem(R=3000, H=4, L=120, seed=3)
+    (a_ip, a_ix), (b_ip, b_ix) = split_at_locus(inc.indptr, inc.indices, 50)
+    for h in range(4):
+        assert int(a_ip[h][-1]) == len(a_ix[h]) and int(b_ip[h][-1]) == len(b_ix[h])
+        assert len(a_ix[h]) + len(b_ix[h]) == len(inc.indices[h])
+        assert (np.diff(a_ip[h].astype(np.int64))[50:] == 0).all() and (np.diff(b_ip[h].astype(np.int64))[:50] == 0).all()
+        np.testing.assert_array_equal(np.diff(a_ip[h].astype(np.int64))[:50], np.diff(inc.indptr[h].astype(np.int64))[:50])
+        np.testing.assert_array_equal(np.diff(b_ip[h].astype(np.int64))[50:], np.diff(inc.indptr[h].astype(np.int64))[50:])
+    # rows_are_disjoint: a row with entries on both sides of the cut is reported
+    assert rows_are_disjoint([np.array([0, 1], dtype=np.uint32)], [np.array([2, 3], dtype=np.uint32)], 4)
+    assert not rows_are_disjoint([np.array([0, 1], dtype=np.uint32)], [np.array([1, 3], dtype=np.uint32)], 4)

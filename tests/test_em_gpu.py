@@ -279,6 +279,62 @@ def test_two_rank_sharded_hip_engines(tmp_path):
     np.testing.assert_allclose(a["err"], g["err_history"], rtol=1e-7)
 
 
+def _pipelined_worker(rank, world, port, path, out_dir):
+    import os, sys
+    from conftest import ROOT
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from gbrs_amd.dist import (PipelinedShardedEM, balanced_gene_boundary, rows_are_disjoint, shard_rows,
+                               split_at_locus)
+    from gbrs_amd.engine import EmEngine
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = load_golden(path)
+    R, L, H, indptr, indices, count, eff_len, groups, gtmask = em_case_inputs(g)
+    l_split = balanced_gene_boundary(indptr, sorted(min(m) for m in groups))
+    r0, r1, ip, ix, cnt = shard_rows(indptr, indices, count, R, rank, world)
+    (a_ip, a_ix), (b_ip, b_ix) = split_at_locus(ip, ix, l_split)
+    assert rows_are_disjoint(a_ix, b_ix, r1 - r0)
+    engs = [EmEngine.from_host(r1 - r0, L, H, p, x, cnt, eff_len, device=0) for p, x in ((a_ip, a_ix), (b_ip, b_ix))]
+    stream = torch.cuda.current_stream().cuda_stream
+    for e in engs:
+        e.set_stream(stream)
+
+    class Dev:
+        def __init__(self, ptr, n):
+            self.__cuda_array_interface__ = dict(shape=(n,), typestr="<f8", data=(ptr, False), version=2)
+
+    def start_allreduce(ptr, n, lo, hi):     # the HIP engine's buffer is (L x H), locus-major
+        t = torch.as_tensor(Dev(ptr, n), device="cuda:0")[lo * H:hi * H]
+        return dist.all_reduce(t, async_op=True)
+    drv = PipelinedShardedEM(engs[0], engs[1], l_split, L, start_allreduce)
+    drv.prepare(0.0)
+    drv.step(int(g["num_iters"]))
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), theta=drv.theta(), l_split=l_split)
+    for e in engs:
+        e.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_pipelined_hip_engines(tmp_path):
+    """Rows sharded over two processes, loci cut at a gene boundary into two HIP engines per process whose
+    (gloo) all-reduces are started asynchronously and interleaved with the other half's E-step: after
+    the reference's number of iterations theta is the reference's."""
+    import socket
+    import torch.multiprocessing as mp
+    path = [p for p in golden_files("em") if p.endswith("em_h8_count_len.npz")][0]
+    g = load_golden(path)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_pipelined_worker, args=(2, port, path, str(tmp_path)), nprocs=2, join=True)
+    a, b = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    np.testing.assert_array_equal(a["theta"], b["theta"])
+    assert 0 < int(a["l_split"]) < int(g["num_loci"])
+    close(a["theta"], g["theta_final"])
+
+
 def _random_rows_problem(R, H, L, seed, min_loci, max_loci, with_count):
     """Rows with many loci each and no repetition structure: exercises cold tiles (dictionary cuts),
     multi-word row sums and, above 32 loci (16 for H > 8), the long-row kernel."""
