@@ -52,6 +52,7 @@ def parse():
     ap.add_argument("--hmm-reps", type=int, default=5)
     ap.add_argument("--hmm-haps", type=int, default=8, help="founder haplotypes of the HMM measurement (16 = config 5's 136 states)")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: one engine per GPU, all-reduce not overlapped with the E-step")
+    ap.add_argument("--force-overlap-path", action="store_true", help="N = 1: run the two-engine form anyway (its compute-side cost without any exchange)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo only to rehearse N>1 on one GPU)")
     return ap.parse_args()
 
@@ -168,8 +169,9 @@ def balanced_gene_boundary_device(prob, torch):
 
 
 def split_problem_device(prob, l_split, torch):
-    """Cut the sample's loci at l_split (device tensors, views of the originals).  Returns
-    (half_a, half_b), or None when some row has entries on both sides or a side is empty."""
+    """Cut the sample's loci at l_split into two problems of l_split and L - l_split loci (device
+    tensors; columns re-based, original row ids).  Returns (half_a, half_b), each (indptr, indices,
+    eff_len, num_loci), or None when some row has entries on both sides or a side is empty."""
     R = prob["R"]
     dev = prob["indptr"][0].device
     a_ip, a_ix, b_ip, b_ix = [], [], [], []
@@ -177,15 +179,17 @@ def split_problem_device(prob, l_split, torch):
     in_b = torch.zeros(R, dtype=torch.bool, device=dev)
     for ip, ix in zip(prob["indptr"], prob["indices"]):
         cut = int(ip[l_split])
-        a_ip.append(torch.clamp(ip, max=cut).contiguous())
-        b_ip.append((torch.clamp(ip, min=cut) - cut).contiguous())
+        a_ip.append(ip[:l_split + 1].contiguous())
+        b_ip.append((ip[l_split:] - cut).contiguous())
         a_ix.append(ix[:cut])
         b_ix.append(ix[cut:])
         in_a[a_ix[-1].long()] = True
         in_b[b_ix[-1].long()] = True
     if bool((in_a & in_b).any()) or not (bool(in_a.any()) and bool(in_b.any())):
         return None
-    return (a_ip, a_ix), (b_ip, b_ix)
+    el = prob["eff_len"]
+    return ((a_ip, a_ix, el[:, :l_split].contiguous(), l_split),
+            (b_ip, b_ix, el[:, l_split:].contiguous(), prob["L"] - l_split))
 
 
 def em_bench_pipelined(args, rank, world, torch, dist):
@@ -203,19 +207,20 @@ def em_bench_pipelined(args, rank, world, torch, dist):
     t_gen = time.perf_counter() - t0
     # one cut for all ranks (the all-reduce is over a locus range): rank 0's balanced gene boundary
     ls = torch.tensor([balanced_gene_boundary_device(prob, torch)], dtype=torch.int64, device=dev)
-    dist.broadcast(ls, src=0)
+    if world > 1:
+        dist.broadcast(ls, src=0)
     l_split = int(ls.item())
     cut = split_problem_device(prob, l_split, torch) if 0 < l_split < prob["L"] else None
     ok = torch.tensor([1 if cut is not None else 0], device=dev)
-    dist.all_reduce(ok, op=dist.ReduceOp.MIN)              # every rank takes the same path
+    if world > 1:
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)          # every rank takes the same path
     if int(ok.item()) == 0:
         return None
     half_a, half_b = cut
     t0 = time.perf_counter()
-    engs = [EmEngine.from_device(prob["R"], prob["L"], prob["H"], [t.data_ptr() for t in ip],
-                                 [t.data_ptr() for t in ix], None, prob["eff_len"].data_ptr(), device=devno,
-                                 flags=args.flags)
-            for ip, ix in (half_a, half_b)]
+    engs = [EmEngine.from_device(prob["R"], nl, prob["H"], [t.data_ptr() for t in ip],
+                                 [t.data_ptr() for t in ix], None, el.data_ptr(), device=devno, flags=args.flags)
+            for ip, ix, el, nl in (half_a, half_b)]
     t_create = time.perf_counter() - t0
     n_entries, H = prob["N"], prob["H"]
     L = prob["L"]
@@ -226,28 +231,36 @@ def em_bench_pipelined(args, rank, world, torch, dist):
         e.set_stream(stream)
     views = {}
 
-    def start_allreduce(ptr, n, lo, hi):
+    class _Done:                                   # world == 1 (--force-overlap-path): nothing to exchange
+        def wait(self):
+            pass
+
+    def start_allreduce(ptr, n):
+        if world == 1:
+            return _Done()
         if ptr not in views:
             views[ptr] = torch.as_tensor(DevArray(ptr, n), device=dev)
-        return dist.all_reduce(views[ptr][lo * H:hi * H], async_op=True)
+        return dist.all_reduce(views[ptr], async_op=True)
 
-    drv = PipelinedShardedEM(engs[0], engs[1], l_split, L, start_allreduce)
+    drv = PipelinedShardedEM(engs[0], engs[1], start_allreduce)
     drv.prepare(0.0)
+    def barrier():
+        for e in engs:
+            e.sync()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
     drv.step(args.warmup)
-    for e in engs:
-        e.sync()
-    dist.barrier()
-    torch.cuda.synchronize()
+    barrier()
     t0 = time.perf_counter()
     drv.step(args.steps)
-    for e in engs:
-        e.sync()
-    dist.barrier()
-    torch.cuda.synchronize()
+    barrier()
     dt = time.perf_counter() - t0
-    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    dt = float(tt.item())
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
     # per-launch E-step time of the two halves: local steps without the collective
     estep_ms = step_ms = 0.0
     infos = []
@@ -377,7 +390,7 @@ def main():
         dist.barrier()
 
     em = None
-    if world > 1 and not args.no_overlap and not args.merge:
+    if (world > 1 or args.force_overlap_path) and not args.no_overlap and not args.merge:
         em = em_bench_pipelined(args, rank, world, torch, dist)
     if em is None:
         em = em_bench(args, rank, world, torch, dist)

@@ -8,7 +8,7 @@ collective on the data path.
 
 PipelinedShardedEM hides that all-reduce behind compute: the loci are cut into two ranges that no row
 straddles (a gene boundary), each range gets its own engine on the rank, and the all-reduce of one
-range's vector slice runs while the E-step of the other range is on the GPU.
+range's vector runs while the E-step of the other range is on the GPU.
 
 The engine is injected: the product passes gbrs_amd.engine.EmEngine (HIP); the CPU tests pass a
 numpy stand-in with the same five methods to check that sharding + all-reduce reproduce the
@@ -101,16 +101,16 @@ def torch_allreduce(dist, torch, device):
 # ---- overlap of the all-reduce with the E-step --------------------------------------------------
 
 def split_at_locus(indptr, indices, l_split):
-    """CSC arrays of the column ranges [0, l_split) and [l_split, L): full-length indptr (the other
-    range's columns are empty), original row ids.  Returns ((indptr_a, indices_a), (indptr_b, indices_b))."""
+    """The column ranges [0, l_split) and [l_split, L) as two CSC problems of l_split and L - l_split
+    loci (columns re-based to 0, original row ids).  Returns ((indptr_a, indices_a), (indptr_b, indices_b))."""
     a_ip, a_ix, b_ip, b_ix = [], [], [], []
     for ip, ix in zip(indptr, indices):
         ip = np.asarray(ip)
-        cut = ip[l_split]
-        a_ip.append(np.minimum(ip, cut).astype(np.uint32))
-        a_ix.append(np.ascontiguousarray(ix[:int(cut)], dtype=np.uint32))
-        b_ip.append((np.maximum(ip, cut) - cut).astype(np.uint32))
-        b_ix.append(np.ascontiguousarray(ix[int(cut):], dtype=np.uint32))
+        cut = int(ip[l_split])
+        a_ip.append(np.ascontiguousarray(ip[:l_split + 1], dtype=np.uint32))
+        a_ix.append(np.ascontiguousarray(ix[:cut], dtype=np.uint32))
+        b_ip.append((ip[l_split:].astype(np.int64) - cut).astype(np.uint32))
+        b_ix.append(np.ascontiguousarray(ix[cut:], dtype=np.uint32))
     return (a_ip, a_ix), (b_ip, b_ix)
 
 
@@ -138,35 +138,30 @@ def balanced_gene_boundary(indptr, gene_starts):
 
 
 class PipelinedShardedEM:
-    """Two engines per rank over locus ranges [0, l_split) and [l_split, L) that no row straddles, so
-    the two halves are independent EM problems that only share the convergence test.  Per iteration
-    and half: E-step over the rank's rows -> all-reduce of that half's slice of the (L x H) vector ->
-    M-step; the halves are interleaved so that the all-reduce of one is in flight (RCCL's own stream)
-    while the E-step of the other occupies the GPU:
+    """Two engines per rank over the locus ranges [0, l_split) and [l_split, L) (split_at_locus) that no
+    row straddles, so the two ranges are independent EM problems that only share the convergence test.
+    Per iteration and range: E-step over the rank's rows -> all-reduce of that engine's partial vector
+    -> M-step; the ranges are interleaved so that the all-reduce of one is in flight (RCCL's own
+    stream) while the E-step of the other occupies the GPU:
 
         E_a  AR_a | E_b  AR_b | wait AR_a  M_a  E_a'  AR_a' | wait AR_b  M_b  E_b'  AR_b' | ...
 
-    `start_allreduce(buffer, n, l_lo, l_hi)` starts the in-place sum of loci [l_lo, l_hi) of the
-    engine's partial buffer across ranks and returns an object whose wait() orders the engine's
-    stream after it.  pseudocount must be 0 (its renormalisation couples the halves); the stopping
-    rule is evaluated on the host every `check_every` iterations, so a run may go up to
-    check_every - 1 iterations past the reference's stopping point - use ShardedEM when the iteration
-    count has to match."""
+    `start_allreduce(buffer, n)` starts the in-place sum of the engine's partial buffer across ranks
+    and returns an object whose wait() orders the engine's stream after it.  pseudocount must be 0
+    (its renormalisation couples the ranges); the stopping rule is evaluated on the host every
+    `check_every` iterations, so a run may go up to check_every - 1 iterations past the reference's
+    stopping point - use ShardedEM when the iteration count has to match."""
 
-    def __init__(self, engine_a, engine_b, l_split, num_loci, start_allreduce):
+    def __init__(self, engine_a, engine_b, start_allreduce):
         self.eng = (engine_a, engine_b)
-        self.rng = ((0, l_split), (l_split, num_loci))
         self.start = start_allreduce
         self.num_iters = 0
         self.err_history = []
 
     def prepare(self, pseudocount=0.0):
         if pseudocount != 0.0:
-            raise RuntimeError('PipelinedShardedEM needs pseudocount 0 (the pseudocount renormalisation couples the halves)')
-        pend = []
-        for e, (lo, hi) in zip(self.eng, self.rng):
-            p, n = e.prepare_partial()
-            pend.append(self.start(p, n, lo, hi))
+            raise RuntimeError('PipelinedShardedEM needs pseudocount 0 (the pseudocount renormalisation couples the ranges)')
+        pend = [self.start(*e.prepare_partial()) for e in self.eng]
         for e, w in zip(self.eng, pend):
             w.wait()
             e.finish_prepare(0.0)
@@ -175,25 +170,21 @@ class PipelinedShardedEM:
         """k EM iterations (no error report)."""
         if k <= 0:
             return
-        pend = []
-        for e, (lo, hi) in zip(self.eng, self.rng):
-            p, n = e.estep_partial()
-            pend.append(self.start(p, n, lo, hi))
+        pend = [self.start(*e.estep_partial()) for e in self.eng]
         for _ in range(k - 1):
-            for i, (e, (lo, hi)) in enumerate(zip(self.eng, self.rng)):
+            for i, e in enumerate(self.eng):
                 pend[i].wait()
                 e.finish_step(want_err=False)
-                p, n = e.estep_partial()
-                pend[i] = self.start(p, n, lo, hi)
+                pend[i] = self.start(*e.estep_partial())
         for e, w in zip(self.eng, pend):
             w.wait()
             e.finish_step(want_err=False)
         self.num_iters += k
 
     def theta(self):
-        """(H x L): each engine's theta is zero outside its own locus range."""
+        """(H x L): the two ranges side by side."""
         parts = [e.theta() if callable(e.theta) else e.theta for e in self.eng]
-        return np.asarray(parts[0]) + np.asarray(parts[1])
+        return np.concatenate([np.asarray(parts[0]), np.asarray(parts[1])], axis=1)
 
     @staticmethod
     def _err_sum(prev, cur):        # EMfactory.py:268-278

@@ -97,19 +97,17 @@ def _pipelined_worker(rank, world, port, path, out_dir):
     r0, r1, ip, ix, cnt = shard_rows(indptr, indices, count, R, rank, world)
     (a_ip, a_ix), (b_ip, b_ix) = split_at_locus(ip, ix, l_split)
     assert 0 < l_split < L and rows_are_disjoint(a_ix, b_ix, r1 - r0)
-    eng_a = NumpyEngine(r1 - r0, L, H, a_ip, a_ix, cnt, eff_len)
-    eng_b = NumpyEngine(r1 - r0, L, H, b_ip, b_ix, cnt, eff_len)
+    eng_a = NumpyEngine(r1 - r0, l_split, H, a_ip, a_ix, cnt, None if eff_len is None else eff_len[:, :l_split])
+    eng_b = NumpyEngine(r1 - r0, L - l_split, H, b_ip, b_ix, cnt, None if eff_len is None else eff_len[:, l_split:])
 
     class Done:
         def wait(self):
             pass
 
-    def start_allreduce(arr, n, lo, hi):       # the numpy stand-in's buffer is (H x L)
-        t = torch.from_numpy(np.ascontiguousarray(arr[:, lo:hi]))
-        dist.all_reduce(t)
-        arr[:, lo:hi] = t.numpy()
+    def start_allreduce(arr, n):
+        dist.all_reduce(torch.from_numpy(arr))      # shares memory with the engine's partial buffer
         return Done()
-    drv = PipelinedShardedEM(eng_a, eng_b, l_split, L, start_allreduce)
+    drv = PipelinedShardedEM(eng_a, eng_b, start_allreduce)
     drv.prepare(0.0)
     drv.step(int(g["num_iters"]))              # exactly the reference's iteration count
     theta_fixed = drv.theta()
@@ -147,11 +145,12 @@ def test_split_at_locus_partitions_entries():
     inc = synth.make_em_problem(R=3000, H=4, L=120, seed=3)
     (a_ip, a_ix), (b_ip, b_ix) = split_at_locus(inc.indptr, inc.indices, 50)
     for h in range(4):
+        assert len(a_ip[h]) == 51 and len(b_ip[h]) == 71 and a_ip[h][0] == 0 and b_ip[h][0] == 0
         assert int(a_ip[h][-1]) == len(a_ix[h]) and int(b_ip[h][-1]) == len(b_ix[h])
         assert len(a_ix[h]) + len(b_ix[h]) == len(inc.indices[h])
-        assert (np.diff(a_ip[h].astype(np.int64))[50:] == 0).all() and (np.diff(b_ip[h].astype(np.int64))[:50] == 0).all()
-        np.testing.assert_array_equal(np.diff(a_ip[h].astype(np.int64))[:50], np.diff(inc.indptr[h].astype(np.int64))[:50])
-        np.testing.assert_array_equal(np.diff(b_ip[h].astype(np.int64))[50:], np.diff(inc.indptr[h].astype(np.int64))[50:])
+        np.testing.assert_array_equal(np.diff(a_ip[h].astype(np.int64)), np.diff(inc.indptr[h].astype(np.int64))[:50])
+        np.testing.assert_array_equal(np.diff(b_ip[h].astype(np.int64)), np.diff(inc.indptr[h].astype(np.int64))[50:])
+        np.testing.assert_array_equal(np.concatenate([a_ix[h], b_ix[h]]), inc.indices[h])
     # rows_are_disjoint: a row with entries on both sides of the cut is reported
     assert rows_are_disjoint([np.array([0, 1], dtype=np.uint32)], [np.array([2, 3], dtype=np.uint32)], 4)
     assert not rows_are_disjoint([np.array([0, 1], dtype=np.uint32)], [np.array([1, 3], dtype=np.uint32)], 4)

@@ -297,7 +297,10 @@ def _pipelined_worker(rank, world, port, path, out_dir):
     r0, r1, ip, ix, cnt = shard_rows(indptr, indices, count, R, rank, world)
     (a_ip, a_ix), (b_ip, b_ix) = split_at_locus(ip, ix, l_split)
     assert rows_are_disjoint(a_ix, b_ix, r1 - r0)
-    engs = [EmEngine.from_host(r1 - r0, L, H, p, x, cnt, eff_len, device=0) for p, x in ((a_ip, a_ix), (b_ip, b_ix))]
+    lens = (None, None) if eff_len is None else (np.ascontiguousarray(eff_len[:, :l_split]),
+                                                 np.ascontiguousarray(eff_len[:, l_split:]))
+    engs = [EmEngine.from_host(r1 - r0, nl, H, p, x, cnt, el, device=0)
+            for nl, p, x, el in ((l_split, a_ip, a_ix, lens[0]), (L - l_split, b_ip, b_ix, lens[1]))]
     stream = torch.cuda.current_stream().cuda_stream
     for e in engs:
         e.set_stream(stream)
@@ -306,10 +309,9 @@ def _pipelined_worker(rank, world, port, path, out_dir):
         def __init__(self, ptr, n):
             self.__cuda_array_interface__ = dict(shape=(n,), typestr="<f8", data=(ptr, False), version=2)
 
-    def start_allreduce(ptr, n, lo, hi):     # the HIP engine's buffer is (L x H), locus-major
-        t = torch.as_tensor(Dev(ptr, n), device="cuda:0")[lo * H:hi * H]
-        return dist.all_reduce(t, async_op=True)
-    drv = PipelinedShardedEM(engs[0], engs[1], l_split, L, start_allreduce)
+    def start_allreduce(ptr, n):
+        return dist.all_reduce(torch.as_tensor(Dev(ptr, n), device="cuda:0"), async_op=True)
+    drv = PipelinedShardedEM(engs[0], engs[1], start_allreduce)
     drv.prepare(0.0)
     drv.step(int(g["num_iters"]))
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), theta=drv.theta(), l_split=l_split)
