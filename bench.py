@@ -391,7 +391,18 @@ def main():
 
     em = None
     if (world > 1 or args.force_overlap_path) and not args.no_overlap and not args.merge:
-        em = em_bench_pipelined(args, rank, world, torch, dist)
+        try:
+            em = em_bench_pipelined(args, rank, world, torch, dist)
+        except Exception as ex:                        # keep the run alive on the single-engine path
+            print(f"[bench] rank {rank}: overlapped path failed ({type(ex).__name__}: {ex}); "
+                  "falling back to one engine per GPU", file=sys.stderr, flush=True)
+            em = None
+        if world > 1:                                  # all ranks take the same path
+            ok = torch.tensor([1 if em is not None else 0], device=f"cuda:{local}")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                em = None
+                torch.cuda.empty_cache()
     if em is None:
         em = em_bench(args, rank, world, torch, dist)
     inf = em["info"]
