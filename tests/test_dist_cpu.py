@@ -154,3 +154,12 @@ def test_split_at_locus_partitions_entries():
     # rows_are_disjoint: a row with entries on both sides of the cut is reported
     assert rows_are_disjoint([np.array([0, 1], dtype=np.uint32)], [np.array([2, 3], dtype=np.uint32)], 4)
     assert not rows_are_disjoint([np.array([0, 1], dtype=np.uint32)], [np.array([1, 3], dtype=np.uint32)], 4)
+
+
+def test_balanced_gene_boundary_picks_the_gene_start_nearest_to_half_the_entries():
+    from gbrs_amd.dist import balanced_gene_boundary
+    # 10 loci, 1 haplotype: entries per locus 5,5,5,5,0,0,10,10,0,0 -> half (20 entries) is reached at locus 4
+    ip = [np.array([0, 5, 10, 15, 20, 20, 20, 30, 40, 40, 40], dtype=np.uint32)]
+    assert balanced_gene_boundary(ip, [0, 3, 6, 8]) == 3
+    assert balanced_gene_boundary(ip, [0, 5, 9]) == 5
+    assert balanced_gene_boundary(ip, [0]) == 0            # a single gene: no cut (callers fall back)
