@@ -29,6 +29,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+F64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X_MICROARCH.md: FP64 vector peak
 
 
 def parse():
@@ -44,6 +45,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-hmm", action="store_true")
     ap.add_argument("--no-merged-line", action="store_true")
+    ap.add_argument("--no-check", action="store_true", help="skip the post-run tiles-vs-CSC theta comparison")
     ap.add_argument("--from-host", action="store_true", help="also time gbrs_em_create from host (numpy) arrays: PCIe copy + layout build")
     ap.add_argument("--cpu-rows", type=int, default=2_000_000)
     ap.add_argument("--cpu-iters", type=int, default=60, help="oracle iterations timed for cpu_baseline (stops at 25 s)")
@@ -92,8 +94,6 @@ def em_bench(args, rank, world, torch, dist):
         t_host = time.perf_counter() - t1
         e2.close()
         del ip, ix
-    del prob
-    torch.cuda.empty_cache()
 
     def barrier():
         if world > 1:
@@ -134,6 +134,30 @@ def em_bench(args, rank, world, torch, dist):
         dt = float(tt.item())
     inf = eng.info()
     res = dict(dt=dt, t_gen=t_gen, t_create=t_create, t_create_host=t_host, N=n_entries, info=inf)
+    # ---- outside the timed region: is the state the timed steps produced a valid EM state? ----------
+    res["check"] = em_state_check(torch, [eng.expected_counts()], float(args.rows) * world)
+    if world == 1 and not args.no_check:
+        # the same sample through the plain CSC kernels (two passes, global atomics: a different code
+        # path with a different summation order) must give the same theta after 3 iterations
+        import numpy as np
+        eng.prepare(0.0)
+        eng.step(3)
+        th = eng.theta()
+        ec = EmEngine.from_device(
+            prob["R"], prob["L"], prob["H"], [t.data_ptr() for t in prob["indptr"]],
+            [t.data_ptr() for t in prob["indices"]], None, prob["eff_len"].data_ptr(),
+            device=torch.cuda.current_device(), flags=_lib.GBRS_EM_LAYOUT_CSC)
+        ec.prepare(0.0)
+        ec.step(3)
+        th_c = ec.theta()
+        ec.close()
+        denom = np.maximum(np.abs(th_c), 1e-300)
+        rel = float(np.max(np.abs(th - th_c) / denom))
+        res["check"]["theta_vs_csc_layout_3_iters_max_rel"] = rel
+        res["check"]["ok"] = bool(res["check"]["ok"] and rel < 1e-9)
+        # put the engine back where the timed steps left off is not needed: what follows re-prepares
+    del prob
+    torch.cuda.empty_cache()
     if world == 1 and not args.merge:
         # time to solution with the reference's default stopping rule (tol = 1e-4 TPM units)
         eng.prepare(0.0)
@@ -192,12 +216,12 @@ def split_problem_device(prob, l_split, torch):
             (b_ip, b_ix, el[:, l_split:].contiguous(), prob["L"] - l_split))
 
 
-def em_bench_pipelined(args, rank, world, torch, dist):
-    """N > 1: every rank holds one shard of rows, cut into two locus ranges with an engine each, so that
-    the RCCL all-reduce of one range overlaps the E-step of the other (gbrs_amd.dist.PipelinedShardedEM).
-    Returns None when the sample cannot be cut (the caller falls back to one engine per rank)."""
+def pipelined_setup(args, rank, world, torch, dist):
+    """Fallible part of the two-engine path: generate the shard, cut it at a gene boundary, build the two
+    engines.  Touches no data-path collective (only the cut broadcast, which every rank reaches before
+    anything can fail locally); any local failure is reported through the returned (state, error) pair and
+    agreed on by the caller with one MIN all-reduce before the first data collective."""
     from gbrs_amd import synth, synth_torch
-    from gbrs_amd.dist import PipelinedShardedEM
     from gbrs_amd.engine import EmEngine
     devno = torch.cuda.current_device()
     dev = f"cuda:{devno}"
@@ -210,22 +234,33 @@ def em_bench_pipelined(args, rank, world, torch, dist):
     if world > 1:
         dist.broadcast(ls, src=0)
     l_split = int(ls.item())
-    cut = split_problem_device(prob, l_split, torch) if 0 < l_split < prob["L"] else None
-    ok = torch.tensor([1 if cut is not None else 0], device=dev)
-    if world > 1:
-        dist.all_reduce(ok, op=dist.ReduceOp.MIN)          # every rank takes the same path
-    if int(ok.item()) == 0:
-        return None
-    half_a, half_b = cut
-    t0 = time.perf_counter()
-    engs = [EmEngine.from_device(prob["R"], nl, prob["H"], [t.data_ptr() for t in ip],
-                                 [t.data_ptr() for t in ix], None, el.data_ptr(), device=devno, flags=args.flags)
-            for ip, ix, el, nl in (half_a, half_b)]
-    t_create = time.perf_counter() - t0
-    n_entries, H = prob["N"], prob["H"]
-    L = prob["L"]
-    del prob, half_a, half_b, cut
+    state, err = None, None
+    try:
+        cut = split_problem_device(prob, l_split, torch) if 0 < l_split < prob["L"] else None
+        if cut is None:
+            err = "no gene boundary that no row straddles"
+        else:
+            half_a, half_b = cut
+            t0 = time.perf_counter()
+            engs = [EmEngine.from_device(prob["R"], nl, prob["H"], [t.data_ptr() for t in ip],
+                                         [t.data_ptr() for t in ix], None, el.data_ptr(), device=devno,
+                                         flags=args.flags)
+                    for ip, ix, el, nl in (half_a, half_b)]
+            state = dict(engs=engs, t_gen=t_gen, t_create=time.perf_counter() - t0, N=prob["N"], l_split=l_split)
+    except Exception as ex:                           # noqa: BLE001 - reported, then agreed on by all ranks
+        err = f"{type(ex).__name__}: {ex}"
+    del prob
     torch.cuda.empty_cache()
+    return state, err
+
+
+def em_bench_pipelined(args, rank, world, torch, dist, state):
+    """N > 1: every rank holds one shard of rows, cut into two locus ranges with an engine each, so that
+    the RCCL all-reduce of one range overlaps the E-step of the other (gbrs_amd.dist.PipelinedShardedEM).
+    Runs after all ranks agreed that their setup succeeded: a failure from here on is fatal."""
+    from gbrs_amd.dist import PipelinedShardedEM
+    dev = f"cuda:{torch.cuda.current_device()}"
+    engs = state["engs"]
     stream = torch.cuda.current_stream().cuda_stream
     for e in engs:
         e.set_stream(stream)
@@ -244,6 +279,7 @@ def em_bench_pipelined(args, rank, world, torch, dist):
 
     drv = PipelinedShardedEM(engs[0], engs[1], start_allreduce)
     drv.prepare(0.0)
+
     def barrier():
         for e in engs:
             e.sync()
@@ -261,6 +297,7 @@ def em_bench_pipelined(args, rank, world, torch, dist):
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    check = em_state_check(torch, [e.expected_counts() for e in engs], float(args.rows) * world)
     # per-launch E-step time of the two halves: local steps without the collective
     estep_ms = step_ms = 0.0
     infos = []
@@ -272,8 +309,24 @@ def em_bench_pipelined(args, rank, world, torch, dist):
         infos.append(inf)
     for e in engs:
         e.close()
-    return dict(dt=dt, t_gen=t_gen, t_create=t_create, t_create_host=None, N=n_entries, info=infos[0], infos=infos,
-                estep_ms=estep_ms, step_ms=step_ms, l_split=l_split)
+    return dict(dt=dt, t_gen=state["t_gen"], t_create=state["t_create"], t_create_host=None, N=state["N"],
+                info=infos[0], infos=infos, estep_ms=estep_ms, step_ms=step_ms, l_split=state["l_split"],
+                check=check)
+
+
+def em_state_check(torch, counts_list, expect_total):
+    """Outside the timed region: the expected read counts of the last E-step must be finite, non-negative
+    and add up to the number of reads (every read's posterior sums to 1, EMfactory.py:302 /
+    AlignmentPropertyMatrix.py:335-342)."""
+    import numpy as np
+    tot = float(sum(np.asarray(c, dtype=np.float64).sum() for c in counts_list))
+    ok = all(bool(np.isfinite(c).all()) and bool((np.asarray(c) >= 0).all()) for c in counts_list)
+    out = dict(sum_expected_counts=tot, finite_nonnegative=ok)
+    if expect_total is not None:
+        out["expected"] = float(expect_total)
+        out["rel_err"] = abs(tot - expect_total) / max(expect_total, 1.0)
+        out["ok"] = bool(ok and out["rel_err"] < 1e-9)
+    return out
 
 
 def em_cpu_baseline(args):
@@ -367,16 +420,62 @@ def hmm_bench(args, torch, ns=None, with_cpu=True):
     return out
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no torchrun environment: start N fresh ranks as child
+    processes (torch.distributed.run) BEFORE this process imports torch or touches a GPU, relay their
+    output and exit with their status.  Nothing is ever exec'ed from a process that initialised HIP."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("[bench] launching " + " ".join(cmd), file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    lines = []
+    for ln in proc.stdout:
+        sys.stdout.write(ln)
+        sys.stdout.flush()
+        lines.append(ln)
+    rc = proc.wait()
+    if rc != 0:
+        raise SystemExit(rc)
+    recs = []
+    for ln in lines:
+        ln = ln.strip()
+        if ln.startswith("{"):
+            try:
+                recs.append(json.loads(ln))
+            except ValueError:
+                pass
+    if len(recs) != 1 or recs[0].get("n_gpus") != args.gpus:
+        print(f"[bench] expected one JSON line with n_gpus={args.gpus}, got {[r.get('n_gpus') for r in recs]}",
+              file=sys.stderr, flush=True)
+        raise SystemExit(3)
+    raise SystemExit(0)
+
+
 def main():
     args = parse()
-    import torch
-    import torch.distributed as dist
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_launch(args)                             # never returns
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    import torch
+    import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: gbrs_amd has no CPU path")
-    local = local % torch.cuda.device_count()
+    ndev = torch.cuda.device_count()
+    if world > 1 and args.backend == "nccl" and ndev < world:
+        raise SystemExit(f"bench.py: --gpus {world} over RCCL needs {world} GPUs, {ndev} visible "
+                         "(--backend gloo rehearses the multi-rank path on fewer)")
+    local = local % ndev
     torch.cuda.set_device(local)
     if world > 1:
         if args.backend == "nccl":
@@ -390,19 +489,24 @@ def main():
         dist.barrier()
 
     em = None
+    path = "single-engine"
+    path_note = None
     if (world > 1 or args.force_overlap_path) and not args.no_overlap and not args.merge:
-        try:
-            em = em_bench_pipelined(args, rank, world, torch, dist)
-        except Exception as ex:                        # keep the run alive on the single-engine path
-            print(f"[bench] rank {rank}: overlapped path failed ({type(ex).__name__}: {ex}); "
-                  "falling back to one engine per GPU", file=sys.stderr, flush=True)
-            em = None
-        if world > 1:                                  # all ranks take the same path
-            ok = torch.tensor([1 if em is not None else 0], device=f"cuda:{local}")
+        state, err = pipelined_setup(args, rank, world, torch, dist)
+        ok = torch.tensor([1 if state is not None else 0], device=f"cuda:{local}")
+        if world > 1:                                  # go / no-go agreed before any data-path collective
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if int(ok.item()) == 0:
-                em = None
-                torch.cuda.empty_cache()
+        if int(ok.item()) == 1:
+            path = "pipelined"
+            em = em_bench_pipelined(args, rank, world, torch, dist, state)   # a failure here is fatal
+        else:
+            if state is not None:
+                for e in state["engs"]:
+                    e.close()
+            del state
+            torch.cuda.empty_cache()
+            path_note = f"two-engine setup declined on some rank (this rank: {err}); one engine per GPU"
+            print(f"[bench] rank {rank}: {path_note}", file=sys.stderr, flush=True)
     if em is None:
         em = em_bench(args, rank, world, torch, dist)
     inf = em["info"]
@@ -411,13 +515,21 @@ def main():
     value = world * args.steps / em["dt"]
     algo = sum(int(i.algorithmic_bytes) for i in infos)
     moved = sum(int(i.bytes_per_iter) for i in infos)
-    priced = min(algo, moved)
+    estep_bytes = sum(int(i.estep_bytes) for i in infos)
+    words = sum(int(i.num_device_words) for i in infos)
     estep_s = em["estep_ms"] * 1e-3
+    # price on min(B_iter, bytes actually moved) so a smaller device format never inflates the fraction
+    priced_estep = min(algo, estep_bytes)
+    priced_step = min(algo, moved)
+    achieved = priced_estep / estep_s / 1e9 if estep_s > 0 else None
+    useful_flop = 4.0 * em["N"]                         # per stored entry: one FMA into den, one into A
     line = {
         "metric": "EM iterations/s (EMASE Model 4, 40M reads x 8 haplotypes x 120k isoforms per GPU)",
         "value": value, "unit": "iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
+        "path": path, "rccl_ranks": world if (world > 1 and args.backend == "nccl") else 0,
+        "backend": args.backend if world > 1 else None,
         "config": {"workload": f"configs[1]: single DO sample, R={args.rows} reads x H={args.haps} x "
                                f"L={args.loci} isoforms, N={em['N']} alignment entries, quantify Model 4, "
                                f"tol=0 fixed iterations" + (", rows sharded one 40M-read shard per GPU + "
@@ -427,30 +539,57 @@ def main():
                                   if "l_split" in em else ""),
                    "layout": int(inf.layout), "merge_identical_rows": bool(args.merge),
                    "device_rows": sum(int(i.num_device_rows) for i in infos),
-                   "device_words": sum(int(i.num_device_words) for i in infos),
+                   "device_words": words,
+                   "words_per_read": words / max(sum(int(i.num_rows) for i in infos) / len(infos), 1),
+                   "entries_per_read": em["N"] / args.rows,
                    "tiles": sum(int(i.num_tiles) for i in infos), "slots": sum(int(i.num_slots) for i in infos),
+                   "heavy_loci": sum(int(i.num_heavy_loci) for i in infos),
+                   "light_loci": sum(int(i.num_light_loci) for i in infos),
                    "long_rows": sum(int(i.num_long_rows) for i in infos)},
-        "roofline": {"bound": "hbm", "achieved": priced / estep_s / 1e9 if estep_s > 0 else None,
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": priced / estep_s / 1e9 / HBM_PEAK_GBS if estep_s > 0 else None,
-                     "traffic": None, "kernel": "E-step", "kernel_ms": em["estep_ms"],
-                     "step_ms_events": em["step_ms"], "algorithmic_bytes": algo, "layout_bytes": moved,
-                     "priced_bytes": priced},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS if achieved else None,
+                     "traffic": None, "kernel": "tile_estep_kernel (E-step)", "kernel_ms": em["estep_ms"],
+                     "kernel_bytes": estep_bytes, "priced_bytes": priced_estep,
+                     "algorithmic_bytes": algo,
+                     "note": "achieved = E-step bytes (word stream, tile headers, dictionary, theta gather, slot "
+                             "stores) / E-step launch time from HIP events on the library's stream; the device "
+                             "format is a re-encoding of the CSC input (one 32-bit word per (read, locus) pair "
+                             "with the haplotype mask inside), so it moves fewer bytes than SURVEY 8d's B_iter "
+                             "(algorithmic_bytes); words_per_read depends on the generator (<= 2 loci per read)",
+                     "whole_step": {"bytes": moved, "priced_bytes": priced_step, "ms": ms_per_step,
+                                    "achieved": priced_step / (ms_per_step * 1e-3) / 1e9,
+                                    "frac": priced_step / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                    "vs_survey_B_iter": {"achieved": algo / (ms_per_step * 1e-3) / 1e9,
+                                                         "frac": algo / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS}},
+                     "compute": {"useful_f64_flop_per_launch": useful_flop,
+                                 "achieved_tflops": useful_flop / estep_s / 1e12 if estep_s > 0 else None,
+                                 "peak_tflops": F64_VECTOR_PEAK_TFLOPS,
+                                 "frac": useful_flop / estep_s / 1e12 / F64_VECTOR_PEAK_TFLOPS if estep_s > 0 else None,
+                                 "note": "2 FMAs per stored alignment entry (row sum and column sum); the kernel "
+                                         "is bound by vector issue, not by HBM (see valu_util)"}},
         "setup_s": {"generate": em["t_gen"], "create_layout": em["t_create"],
                     "create_from_host_arrays": em["t_create_host"]},
+        "state_check": em.get("check"),
     }
+    if path_note:
+        line["path_note"] = path_note
     if "solve" in em:
         line["time_to_solution"] = dict(em["solve"], rule="err_sum <= 1e6*tol, tol=1e-4 (gbrs quantify default)")
-    # HBM traffic of the E-step kernel from the committed rocprofv3 PMC passes (separate runs of this
-    # same command, scripts/profile_estep.sh): FETCH_SIZE x2 (gfx950 correction, MI355X_MICROARCH.md)
-    # + WRITE_SIZE, per launch.  Only quoted for the exact workload it was measured on.
+    # Counter figures of the E-step kernel from the committed rocprofv3 PMC passes (separate runs of this
+    # same command, scripts/profile_estep.sh): HBM traffic = FETCH_SIZE x2 (gfx950 correction,
+    # MI355X_MICROARCH.md) + WRITE_SIZE per launch; VALU issue utilisation = SQ_INSTS_VALU x 4 cycles /
+    # (1024 SIMDs x launch duration x measured shader clock).  Only quoted for the exact workload measured.
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
             pt = json.load(fh)
         key = f"R{args.rows}_H{args.haps}_L{args.loci}_merge{int(args.merge)}"
-        if key in pt:
+        if key in pt and path == "single-engine":
             line["roofline"]["traffic"] = pt[key]["bytes_per_launch"]
             line["roofline"]["traffic_source"] = pt[key]["source"]
+            for k in ("valu_insts_per_launch", "valu_util", "shader_clock_mhz", "lds_bank_conflict_cycles",
+                      "valu_insts_per_word", "pmc_round"):
+                if k in pt[key]:
+                    line["roofline"][k] = pt[key][k]
     except (OSError, ValueError):
         pass
     if rank == 0:
@@ -461,19 +600,24 @@ def main():
             import copy
             a2 = copy.copy(args)
             a2.merge = True
+            a2.no_check = True
             m = em_bench(a2, rank, world, torch, dist)
             line["merged_rows_variant"] = {
                 "note": "same sample with identical reads merged into weighted rows while building the device "
                         "layout (GBRS_EM_MERGE_IDENTICAL_ROWS, what `gbrs compress` does first); not the headline",
                 "value": args.steps / m["dt"], "unit": "iters/s", "ms_per_step": m["dt"] / args.steps * 1e3,
                 "estep_kernel_ms": m["estep_ms"], "device_rows": int(m["info"].num_device_rows),
-                "device_words": int(m["info"].num_device_words), "layout_bytes": int(m["info"].bytes_per_iter)}
-        if not args.no_hmm:
+                "device_words": int(m["info"].num_device_words), "layout_bytes": int(m["info"].bytes_per_iter),
+                "state_check": m.get("check")}
+        if not args.no_hmm and world == 1:
             line["hmm"] = hmm_bench(args, torch)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    chk = em.get("check") or {}
+    if chk.get("ok") is False:
+        raise SystemExit("bench.py: the post-run state check failed: " + json.dumps(chk))
 
 
 if __name__ == "__main__":

@@ -49,6 +49,7 @@ class EmInfo(C.Structure):
         ("last_step_ms", C.c_double), ("num_loci", C.c_uint32), ("num_haps", C.c_uint32),
         ("layout", C.c_uint32), ("reserved", C.c_uint32),
         ("num_tiles", C.c_uint64), ("num_slots", C.c_uint64), ("num_long_rows", C.c_uint64),
+        ("num_heavy_loci", C.c_uint64), ("num_light_loci", C.c_uint64), ("estep_bytes", C.c_uint64),
     ]
 
 
@@ -93,7 +94,7 @@ def load():
         "gbrs_em_create_device": [u64, u32, u32, pp, pp, vp, vp, i32, u32, pp],
         "gbrs_em_prepare": [vp, dbl],
         "gbrs_em_step": [vp, i32, C.POINTER(dbl)],
-        "gbrs_em_run": [vp, i32, dbl, i32, C.POINTER(i32), vp, i32],
+        "gbrs_em_run": [vp, i32, dbl, i32, C.POINTER(i32), vp, i32, vp],
         "gbrs_em_get": [vp, vp, vp],
         "gbrs_em_set_theta": [vp, vp],
         "gbrs_em_group_sums": [vp, i64, vp, vp, i32, vp],
@@ -125,7 +126,7 @@ def load():
         fn.argtypes = args
     lib.gbrs_em_stream.restype = vp
     lib.gbrs_em_stream.argtypes = [vp]
-    if lib.gbrs_abi_version() != 1:
+    if lib.gbrs_abi_version() != 2:
         raise ImportError("libgbrs_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -18,23 +18,23 @@ def alignment_counts(apm, grp_wise=False, device=0):
     if grp_wise:
         if not apm.num_groups:
             raise RuntimeError('No group information is available for bundling.')
+        # locus -> gene map; -1 = in no gene: its entries vanish from the bundled matrix, exactly as the
+        # product with grp_conv_mat drops them (AlignmentPropertyMatrix.py:155-188)
         group = np.full(L, -1, dtype=np.int32)
         for g, members in enumerate(apm.groups):
-            group[np.asarray(members, dtype=np.int64)] = g
-        if (group < 0).any():
-            # loci outside every gene vanish from the bundled matrix; park them in a scratch column
-            group = np.where(group < 0, apm.num_groups, group).astype(np.int32)
-            Lo = apm.num_groups + 1
-        else:
-            Lo = apm.num_groups
+            m = np.asarray(members, dtype=np.int64)
+            if (group[m] >= 0).any():
+                shared = apm.lname[int(m[group[m] >= 0][0])] if apm.lname is not None else int(m[group[m] >= 0][0])
+                raise RuntimeError(f'Locus {shared} is listed in more than one group; the MI355X alignment-count '
+                                   'path needs every locus in at most one group.')
+            group[m] = g
+        Lo = apm.num_groups
         names = list(apm.gname)
     aln = np.empty((H, Lo)); uniq = np.empty((H, Lo)); lu = np.empty(Lo)
     cnt = None if apm.count is None else np.ascontiguousarray(apm.count, dtype=np.float64)
     _lib.check(lib.gbrs_alignment_counts(R, L, H, _lib.ptr_table(apm.indptr), _lib.ptr_table(apm.indices),
                                          _lib.ptr(cnt), _lib.ptr(group), Lo, device,
                                          _lib.ptr(aln), _lib.ptr(uniq), _lib.ptr(lu)))
-    if grp_wise and Lo != apm.num_groups:
-        aln, uniq, lu = aln[:, :-1], uniq[:, :-1], lu[:-1]
     return aln, uniq, lu, names
 
 

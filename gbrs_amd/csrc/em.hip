@@ -11,6 +11,7 @@
 #include "em_layout.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 
@@ -845,6 +846,21 @@ int upload_csc(uint64_t R, uint32_t L, uint32_t H, const uint32_t *const *indptr
     return GBRS_OK;
 }
 
+// Row ids of uploaded CSC arrays are range-checked on the device before any kernel indexes per-row
+// storage with them (host and device inputs alike).
+int check_row_ids(uint64_t n, const uint32_t *ent_row, uint64_t R, hipStream_t stream) {
+    if (n == 0) return GBRS_OK;
+    DevBuf<unsigned int> d_max;
+    GBRS_TRY(d_max.alloc(1));
+    GBRS_HIP_CHECK(hipMemsetAsync(d_max.p, 0, sizeof(unsigned int), stream));
+    hipLaunchKernelGGL(max_row_kernel, dim3(1024), dim3(256), 0, stream, n, ent_row, d_max.p);
+    unsigned int mx = 0;
+    GBRS_HIP_CHECK(hipMemcpyAsync(&mx, d_max.p, sizeof(mx), hipMemcpyDeviceToHost, stream));
+    GBRS_HIP_CHECK(hipStreamSynchronize(stream));
+    if (mx >= R) return fail(GBRS_ERR_INVALID, "indices hold row id %u >= num_rows", mx);
+    return GBRS_OK;
+}
+
 int em_create_impl(uint64_t R, uint32_t L, uint32_t H, const uint32_t *const *indptr,
                    const uint32_t *const *indices, const double *count, const double *eff_len,
                    int device, uint32_t flags, bool on_device, gbrs_em_t **out) {
@@ -900,16 +916,7 @@ int em_create_impl(uint64_t R, uint32_t L, uint32_t H, const uint32_t *const *in
         GBRS_HIP_CHECK(hipStreamSynchronize(em->stream));
     }
     GBRS_HIP_CHECK(hipDeviceSynchronize());
-    if (n > 0) {                               // row ids are validated on the device for host and device input alike
-        DevBuf<unsigned int> d_max;
-        GBRS_TRY(d_max.alloc(1));
-        GBRS_HIP_CHECK(hipMemsetAsync(d_max.p, 0, sizeof(unsigned int), em->stream));
-        hipLaunchKernelGGL(max_row_kernel, dim3(1024), dim3(256), 0, em->stream, n, em->ent_row.p, d_max.p);
-        unsigned int mx = 0;
-        GBRS_HIP_CHECK(hipMemcpyAsync(&mx, d_max.p, sizeof(mx), hipMemcpyDeviceToHost, em->stream));
-        GBRS_HIP_CHECK(hipStreamSynchronize(em->stream));
-        if (mx >= R) return fail(GBRS_ERR_INVALID, "indices hold row id %u >= num_rows", mx);
-    }
+    GBRS_TRY(check_row_ids(n, em->ent_row.p, R, em->stream));
     stg.mark("vectors, checks");
     if (!(flags & GBRS_EM_LAYOUT_CSC) && H <= 16 && n < 0xFFFFFFFFull) {
         // Row order inside a tile: the stream order (gbrs_hip.h) by default - every lane walks a
@@ -969,6 +976,7 @@ int gbrs_compress_create(uint64_t R, uint32_t L, uint32_t H, const uint32_t *con
         GBRS_HIP_CHECK(hipMemcpy(d_count.p, count, R * sizeof(double), hipMemcpyHostToDevice));
     }
     GBRS_HIP_CHECK(hipDeviceSynchronize());
+    GBRS_TRY(check_row_ids(n, ent_row.p, R, s));
     gbrs_compress *c = new gbrs_compress();
     c->device = device; c->L = L; c->H = H;
     const int st = compress_device(c->res, R, L, H, n, ent_row.p, col_ptr.p, count ? d_count.p : nullptr, s);
@@ -1110,7 +1118,7 @@ int gbrs_em_step(gbrs_em_t *em, int n_iters, double *err_sum_out) {
 }
 
 int gbrs_em_run(gbrs_em_t *em, int model, double tol, int max_iters, int *n_iters_out,
-                double *err_hist, int err_hist_cap) {
+                double *err_hist, int err_hist_cap, double *elapsed_s) {
     if (!em) return fail(GBRS_ERR_INVALID, "handle is NULL");
     if (model < 1 || model > 4)
         return fail(GBRS_ERR_INVALID, "The read normalization model should be 1, 2, 3, or 4.");
@@ -1132,6 +1140,7 @@ int gbrs_em_run(gbrs_em_t *em, int model, double tol, int max_iters, int *n_iter
         // iteration's value.
         const int batch = 8;
         bool first = true;
+        const auto t_start = std::chrono::steady_clock::now();
         while (done < max_iters) {
             const int nb = std::min(batch, max_iters - done);
             hipEvent_t ev[3] = {em->ev0, em->ev1, em->ev2};
@@ -1140,6 +1149,10 @@ int gbrs_em_run(gbrs_em_t *em, int model, double tol, int max_iters, int *n_iter
                 first = false;
             }
             GBRS_TRY(em_check_float(em, host));
+            if (elapsed_s) {       // the host sees a batch at a time: its iterations share the batch's completion time
+                const double t = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+                for (int i = done; i < host.iters_done && i < err_hist_cap; ++i) elapsed_s[i] = t;
+            }
             done = host.iters_done;
             if (host.stop) break;
         }
@@ -1237,6 +1250,7 @@ int gbrs_em_info(gbrs_em_t *em, gbrs_em_info_t *info) {
                               16 * HL + (em->has_len ? 8 * HL : 0);
     // layout 0: two passes over the row ids + den zero/atomic/read + theta/acc traffic
     info->bytes_per_iter = 8 * em->N + 8 * em->R * 3 + 8 * HL * 4;
+    info->estep_bytes = 8 * em->N + 8 * em->R * 3 + 8 * HL * 2;
     if (em->layout == 1) {
         const TileLayout &tl = em->tl;
         info->num_device_rows = tl.n_rows + tl.n_long;
@@ -1249,6 +1263,12 @@ int gbrs_em_info(gbrs_em_t *em, gbrs_em_info_t *info) {
         info->bytes_per_iter = 4 * tl.n_batches * 64 + 16 * tl.n_tiles + 4 * tl.n_slots +
                                8 * tl.n_slots * em->H * 3 + 4 * tl.n_slots + 4 * ((uint64_t)em->L + 1) +
                                (tl.weighted ? 8 * tl.n_batches * 64 : 0) + 8 * HL * 6;
+        info->num_heavy_loci = tl.n_heavy;
+        info->num_light_loci = tl.n_light;
+        // the E-step launch alone: words, tile headers, dictionary + slot destinations, theta gathered
+        // once per slot, one partial-sum row stored per slot [, the per-word row weights]
+        info->estep_bytes = 4 * tl.n_batches * 64 + 16 * tl.n_tiles + 8 * tl.n_slots +
+                            8 * tl.n_slots * em->H * 2 + (tl.weighted ? 8 * tl.n_batches * 64 : 0);
     }
     info->last_estep_ms = em->last_estep_ms;
     info->last_step_ms = em->last_step_ms;
@@ -1268,7 +1288,7 @@ int gbrs_alignment_counts(uint64_t R, uint32_t L, uint32_t H, const uint32_t *co
     if (Lout < 1 || Lout >= (1u << 27)) return fail(GBRS_ERR_INVALID, "bad number of output loci");
     if (locus_group)
         for (uint32_t l = 0; l < L; ++l)
-            if (locus_group[l] < 0 || (uint32_t)locus_group[l] >= Lout)
+            if (locus_group[l] < -1 || (locus_group[l] >= 0 && (uint32_t)locus_group[l] >= Lout))
                 return fail(GBRS_ERR_INVALID, "locus_group[%u] out of range", l);
     GBRS_TRY(select_device(device));
     hipStream_t s = nullptr;
@@ -1292,6 +1312,7 @@ int gbrs_alignment_counts(uint64_t R, uint32_t L, uint32_t H, const uint32_t *co
     GBRS_TRY(d_uniq.alloc((size_t)H * Lout));
     GBRS_TRY(d_lu.alloc(Lout));
     GBRS_HIP_CHECK(hipDeviceSynchronize());
+    GBRS_TRY(check_row_ids(n, ent_row.p, R, s));
     GBRS_TRY(alignment_counts_device(R, L, H, n, ent_row.p, col_ptr.p, count ? d_count.p : nullptr,
                                      locus_group ? d_group.p : nullptr, Lout, d_aln.p, d_uniq.p, d_lu.p, s));
     if (aln_counts) GBRS_HIP_CHECK(hipMemcpy(aln_counts, d_aln.p, d_aln.bytes(), hipMemcpyDeviceToHost));

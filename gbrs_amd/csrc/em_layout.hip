@@ -514,6 +514,7 @@ __global__ void long_copy_kernel(uint64_t n_long, uint64_t first, const uint32_t
 }  // namespace
 
 // ---- `--report-alignment-counts` (AlignmentPropertyMatrix.py:389-459) -------------------------
+constexpr uint64_t COUNT_KEY_DROPPED = ~0ull;
 __global__ void __launch_bounds__(256)
 count_keys_kernel(uint64_t n, uint32_t ncols, uint32_t L, uint64_t R, const uint64_t *__restrict__ col_ptr,
                   const uint32_t *__restrict__ ent_row, const int32_t *__restrict__ locus_group,
@@ -525,9 +526,12 @@ count_keys_kernel(uint64_t n, uint32_t ncols, uint32_t L, uint64_t R, const uint
     if (!live) return;
     const uint32_t h = c / L, l = c - h * L;
     const uint32_t r = ent_row[k];
+    const int32_t lo = locus_group ? locus_group[l] : (int32_t)l;
     if (r >= R) flags->bad_row = 1;
-    const uint32_t lo = locus_group ? (uint32_t)locus_group[l] : l;
-    keys[k] = ((uint64_t)r << 32) | ((uint64_t)lo << 5) | h;
+    // an entry of a locus outside every group disappears from the bundled matrix
+    // (AlignmentPropertyMatrix.py:155-188: the product with grp_conv_mat has no column for it); such
+    // entries, like out-of-range row ids, get the all-ones key, which sorts last and is skipped below
+    keys[k] = (r >= R || lo < 0) ? COUNT_KEY_DROPPED : (((uint64_t)r << 32) | ((uint64_t)(uint32_t)lo << 5) | h);
 }
 
 // per unique (row, locus', hap) entry: bump the row's entry counter; per unique (row, locus')
@@ -537,6 +541,7 @@ __global__ void count_rowstat_kernel(uint64_t n, const uint64_t *__restrict__ ke
     const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     const uint64_t key = keys[k];
+    if (key == COUNT_KEY_DROPPED) return;
     const bool new_entry = k == 0 || keys[k - 1] != key;
     const bool new_pair = k == 0 || (keys[k - 1] >> 5) != (key >> 5);
     const uint32_t r = (uint32_t)(key >> 32);
@@ -551,6 +556,7 @@ __global__ void count_accum_kernel(uint64_t n, uint32_t Lout, const uint64_t *__
     const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     const uint64_t key = keys[k];
+    if (key == COUNT_KEY_DROPPED) return;
     const bool new_entry = k == 0 || keys[k - 1] != key;
     if (!new_entry) return;
     const bool new_pair = k == 0 || (keys[k - 1] >> 5) != (key >> 5);
@@ -579,6 +585,8 @@ int alignment_counts_device(uint64_t R, uint32_t L, uint32_t H, uint64_t N, cons
     GBRS_HIP_CHECK(hipMemsetAsync(nloc_row.p, 0, nloc_row.bytes(), s));
     hipLaunchKernelGGL(count_keys_kernel, dim3(grid_for(N)), dim3(256), 0, s, N, H * L, L, R, col_ptr, ent_row,
                        locus_group, keys.p, d_flags.p);
+    // the dropped key is all ones: within the compared bits it is larger than every real key (Lout < 2^27),
+    // so dropped entries end up behind all real ones
     GBRS_TRY(sort_keys64(sc, keys.p, keys2.p, N, 32 + bits_for(R - 1), s));
     hipLaunchKernelGGL(count_rowstat_kernel, dim3(grid_for(N)), dim3(256), 0, s, N, keys2.p, nnz_row.p, nloc_row.p);
     hipLaunchKernelGGL(count_accum_kernel, dim3(grid_for(N)), dim3(256), 0, s, N, Lout, keys2.p, nnz_row.p, nloc_row.p,

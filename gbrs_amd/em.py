@@ -9,7 +9,6 @@ no CPU fallback.
 from __future__ import annotations
 
 import ctypes as C
-import time
 
 import numpy as np
 
@@ -151,62 +150,48 @@ class EMfactory:
                                '(only Model 4: Gene*Isoform*Allele).')
 
     def run(self, model: int, tol: float = 0.001, max_iters: int = 999, verbose: bool = True) -> None:
-        """Runs EM iterations (EMfactory.py:234-287)."""
-        # the reference leaves numpy in this error state after run() (SURVEY §9.11)
-        np.seterr(all='raise')
-        np.seterr(under='ignore')
+        """Runs EM iterations (EMfactory.py:234-287): the whole loop, stopping rule included, executes
+        on the device (gbrs_em_run); the host sees it once per batch of 8 iterations."""
+        np.seterr(all='raise', under='ignore')      # the state the reference leaves numpy in (SURVEY 9.11)
         self._check_model(model)
         self._require()
         self._push()
-        lib = _lib.load()
-        if verbose:
-            print('')
-            print('Iter No  Time (hh:mm:ss)    Total change (TPM)  ')
-            print('-------  ---------------  ----------------------')
-        time0 = time.time()
-        n_it = C.c_int(0)
         cap = max(int(max_iters), 1)
         hist = np.zeros(cap, dtype=np.float64)
-        _lib.check(lib.gbrs_em_run(self._h, int(model), float(tol), int(max_iters), C.byref(n_it),
-                                   _lib.ptr(hist), cap))
+        stamps = np.zeros(cap, dtype=np.float64)
+        n_it = C.c_int(0)
+        _lib.check(_lib.load().gbrs_em_run(self._h, int(model), float(tol), int(max_iters), C.byref(n_it),
+                                           _lib.ptr(hist), cap, _lib.ptr(stamps)))
         self.num_iters = int(n_it.value)
-        self.err_history = [float(x) for x in hist[:self.num_iters]]
+        self.err_history = hist[:self.num_iters].tolist()
         self._theta = None
         if verbose:
-            # the device loop does not hand control back per iteration; elapsed time is the run's
-            delmin, s = divmod(int(time.time() - time0), 60)
-            h, m = divmod(delmin, 60)
-            for i, err_sum in enumerate(self.err_history):
-                print(' %5d      %4d:%02d:%02d     %9.1f / 1000000' % (i + 1, h, m, s, err_sum))
+            _print_progress(self.err_history, stamps[:self.num_iters])
 
     # ------------------------------------------------------------------ reports
-    def report_read_counts(self, filename, grp_wise=False, reorder='as-is', notes=None):
-        """Export read counts (EMfactory.py:289-331)."""
+    def _level(self, grp_wise, which):
+        """(row names, H x n values) of theta (which=0) or of the expected read counts (which=1) at
+        isoform or gene level."""
+        apm = self.probability
         if grp_wise:
-            lname = self.probability.gname
-            expected_read_counts = self._group_sums(1)
-        else:
-            lname = self.probability.lname
-            expected_read_counts = self.expected_read_counts()
-        total_read_counts = expected_read_counts.sum(axis=0)
-        _write_report(filename, self.probability.hname, lname, expected_read_counts, total_read_counts,
-                      reorder, notes)
+            return apm.gname, self._group_sums(which)
+        return apm.lname, (self.allelic_expression if which == 0 else self.expected_read_counts())
+
+    def report_read_counts(self, filename, grp_wise=False, reorder='as-is', notes=None):
+        """Expected read counts of the last E-step as a TSV table (file format of EMfactory.py:289-331)."""
+        names, values = self._level(grp_wise, 1)
+        write_locus_table(filename, self.probability.hname, names, values, reorder, notes)
 
     def report_depths(self, filename, tpm=True, grp_wise=False, reorder='as-is', notes=None) -> None:
-        """Exports expected depths (EMfactory.py:333-380).  As in the reference, tpm=True at the
-        isoform level rescales allelic_expression itself."""
-        if grp_wise:
-            lname = self.probability.gname
-            depths = self._group_sums(0)
-        else:
-            lname = self.probability.lname
-            depths = self.allelic_expression
+        """Depths (theta) as a TSV table, scaled to TPM on request (file format of EMfactory.py:333-380).
+        Reference behaviour kept: at isoform level the TPM scaling is applied to allelic_expression
+        itself, so it carries over to whatever is reported next (:352-354)."""
+        names, values = self._level(grp_wise, 0)
         if tpm:
-            depths *= 1000000.0 / depths.sum()
+            values *= 1000000.0 / values.sum()
             if not grp_wise:
                 self._theta_dirty = True
-        total_depths = depths.sum(axis=0)
-        _write_report(filename, self.probability.hname, lname, depths, total_depths, reorder, notes)
+        write_locus_table(filename, self.probability.hname, names, values, reorder, notes)
 
     def export_posterior_probability(self, filename: str, title: str = 'Posterior Probability') -> None:
         """The reference saves with incidence_only=True (EMfactory.py:392 ->
@@ -214,42 +199,59 @@ class EMfactory:
         self.probability.save(filename, title=title)
 
 
+def _print_progress(err_history, stamps):
+    """The reference's progress table (EMfactory.py:259-262, :284-287); the time column holds the
+    moment the host learned of the iteration (one stamp per device batch of 8)."""
+    print('')
+    print('Iter No  Time (hh:mm:ss)    Total change (TPM)  ')
+    print('-------  ---------------  ----------------------')
+    for k, (err, t) in enumerate(zip(err_history, stamps), start=1):
+        secs = int(t)
+        print(' %5d      %4d:%02d:%02d     %9.1f / 1000000' % (k, secs // 3600, secs // 60 % 60, secs % 60, err))
+
+
 def read_length_file(apm, lenfile, read_length=100):
-    """target_lengths (H x L) as EMfactory.prepare builds it (EMfactory.py:60-94)."""
-    hid = dict(zip(apm.hname, np.arange(len(apm.hname))))
-    tl = np.zeros((apm.num_loci, apm.num_haplotypes))
-    if apm.num_haplotypes > 1:
-        with open(lenfile) as fh:
-            for curline in fh:
-                item = curline.rstrip().split('\t')
-                locus, hap = item[0].split('_')
-                tl[apm.lid[locus], hid[hap]] = max(float(item[1]) - read_length + 1.0, 1.0)
-    elif apm.num_haplotypes > 0:
-        with open(lenfile) as fh:
-            for curline in fh:
-                item = curline.rstrip().split('\t')
-                tl[apm.lid[item[0]], 0] = max(float(item[1]) - read_length + 1.0, 1.0)
-    else:
+    """Effective lengths (H x L) from a `<locus>_<haplotype>TAB<length>` table (plain `<locus>` ids when
+    there is one haplotype): max(length - read_length + 1, 1), what EMfactory.prepare builds at
+    EMfactory.py:60-94.  As there, an id is cut at its underscore into exactly two parts, so a locus id
+    that itself contains '_' is an error."""
+    L, H = apm.num_loci, apm.num_haplotypes
+    if H < 1:
         raise RuntimeError('There is something wrong with your emase-format alignment file.')
-    return np.ascontiguousarray(tl.transpose())
+    eff = np.zeros((H, L))
+    hap_row = {name: k for k, name in enumerate(apm.hname)}
+    with open(lenfile) as fh:
+        for line in fh:
+            key, value = line.rstrip().split('\t')[:2]
+            if H > 1:
+                locus, hap = key.split('_')           # ValueError on a second underscore, as in the reference
+                row = hap_row[hap]
+            else:
+                locus, row = key, 0
+            eff[row, apm.lid[locus]] = max(float(value) - read_length + 1.0, 1.0)
+    return eff
 
 
-def _write_report(filename, hname, lname, values, totals, reorder, notes):
-    if reorder == 'decreasing':
-        report_order = np.argsort(totals.flatten())[::-1]
-    elif reorder == 'increasing':
-        report_order = np.argsort(totals.flatten())
-    elif reorder == 'as-is':
-        report_order = np.arange(len(lname))
-    cntdata = np.vstack((values, totals))
-    with open(filename, 'w') as fhout:
-        fhout.write('locus\t' + '\t'.join(hname) + '\ttotal')
-        if notes is not None:
-            fhout.write('\tnotes')
-        fhout.write('\n')
-        for locus_id in report_order:
-            lname_cur = lname[locus_id]
-            fhout.write('\t'.join([lname_cur] + list(map(str, cntdata[:, locus_id].ravel()))))
+def write_locus_table(filename, hap_names, row_names, values, reorder='as-is', notes=None):
+    """`locus <haplotypes...> total [notes]` table: one line per locus (or gene) with the per-haplotype
+    values, their sum and, when `notes` maps names to text, that text.  Numbers are written in their
+    shortest round-trip form, which is what str(numpy.float64) gives in the reference's writers."""
+    values = np.asarray(values)
+    totals = values.sum(axis=0)
+    order = range(values.shape[1])
+    if reorder in ('increasing', 'decreasing'):
+        order = np.argsort(totals.ravel())
+        if reorder == 'decreasing':
+            order = order[::-1]
+    elif reorder != 'as-is':
+        raise ValueError(f'unknown reorder option: {reorder}')
+    columns = np.vstack((values, totals)).T.tolist()              # python floats: repr == str(np.float64)
+    head = ['locus', *hap_names, 'total'] + (['notes'] if notes is not None else [])
+    with open(filename, 'w') as out:
+        out.write('\t'.join(head) + '\n')
+        for k in order:
+            name = row_names[k]
+            cells = [name, *map(repr, columns[k])]
             if notes is not None:
-                fhout.write(f'\t{notes[lname_cur]}')
-            fhout.write('\n')
+                cells.append(str(notes[name]))
+            out.write('\t'.join(cells) + '\n')

@@ -70,7 +70,7 @@ class EmEngine:
         cap = max(int(max_iters), 1)
         hist = np.zeros(cap, dtype=np.float64)
         _lib.check(_lib.load().gbrs_em_run(self._h, int(model), float(tol), int(max_iters), C.byref(n_it),
-                                           _lib.ptr(hist), cap))
+                                           _lib.ptr(hist), cap, None))
         return int(n_it.value), hist[:n_it.value].copy()
 
     def theta(self):

@@ -8,6 +8,7 @@ from __future__ import annotations
 import ctypes as C
 import logging
 import os
+import time
 from collections import OrderedDict
 from itertools import combinations_with_replacement
 
@@ -114,115 +115,125 @@ class DiplotypeHMM:
 
 
 def get_chromosome_info(data_dir=None):
-    """Chromosome order from $GBRS_DATA/ref.fa.fai (gbrs_utils.py:24-38)."""
+    """Chromosome names (cut to 8 characters) -> lengths, in the order of $GBRS_DATA/ref.fa.fai: the
+    order in which `gbrs reconstruct` walks the genome (gbrs_utils.py:24-38)."""
     data_dir = os.getenv('GBRS_DATA', '.') if data_dir is None else data_dir
-    fai_file = os.path.join(data_dir, 'ref.fa.fai')
-    chr_lens = OrderedDict()
-    try:
-        with open(fai_file) as fh:
-            for line in fh:
-                item = line.rstrip('\n').split()
-                if len(item) >= 2:
-                    chr_lens[item[0][:8]] = int(item[1])
-    except FileNotFoundError:
+    fai = os.path.join(data_dir, 'ref.fa.fai')
+    if not os.path.isfile(fai):
         raise ValueError('Make sure if $GBRS_DATA is set correctly, and that "ref.fa.fai" is in that '
                          f'directory. Currently it is: {data_dir}')
-    return chr_lens
+    lengths = OrderedDict()
+    with open(fai) as fh:
+        for fields in map(str.split, fh):
+            if len(fields) >= 2:
+                lengths[fields[0][:8]] = int(fields[1])
+    return lengths
+
+
+def read_gene_tpm(expression_file):
+    """(haplotype letters, {gene id: TPM per haplotype}) from a `.genes.tpm` report.  The first column
+    is the gene id and the last the total; `gbrs reconstruct` assumes there is no notes column, i.e.
+    the multiway report (gbrs_utils.py:450-459)."""
+    with open(expression_file) as fh:
+        haplotypes = fh.readline().rstrip().split('\t')[1:-1]
+        table = {}
+        for line in fh:
+            fields = line.rstrip().split('\t')
+            table[fields[0]] = np.array(fields[1:-1], dtype=np.float64)
+    return haplotypes, table
+
+
+def read_gene_order(gpos_file):
+    """{chromosome: [gene ids in genome order]} from `ref.gene_pos.ordered.npz`, whose arrays hold
+    (gene id, position) records with the id as bytes or str (gbrs_utils.py:437-447)."""
+    order = {}
+    with np.load(gpos_file) as z:
+        for c in z.files:
+            order[c] = [gid.decode() if isinstance(gid, bytes) else str(gid) for gid, *_ in z[c]]
+    return order
+
+
+def chromosome_inputs(gene_ids, expr, avecs, avec_ids, num_haps):
+    """Device inputs of one chromosome: expression rows (n x H), specificity blocks (n x H x H, zero
+    where the gene has none) and the has-block flags."""
+    n = len(gene_ids)
+    rows = np.empty((n, num_haps), dtype=np.float64)
+    blocks = np.zeros((n, num_haps, num_haps), dtype=np.float64)
+    present = np.zeros(n, dtype=np.uint8)
+    for k, gid in enumerate(gene_ids):
+        rows[k] = expr[gid]                                   # KeyError for a gene without TPM, as in the reference
+        if gid in avec_ids:
+            blocks[k] = avecs[gid]
+            present[k] = 1
+    return rows, blocks, present
 
 
 def reconstruct(expression_file: str, tprob_file: str, avec_file: str = None, gpos_file: str = None,
                 expr_threshold: float = 1.5, sigma: float = 0.12, outbase: str = None,
-                device: int = 0) -> None:
-    """Reconstruct the genome based upon gene-level TPM quantities."""
+                device: int = 0, stage_times: dict = None) -> None:
+    """`gbrs reconstruct`: diplotype posteriors and Viterbi calls along every chromosome from
+    gene-level TPMs.  Same inputs, defaults and three output files as gbrs_utils.reconstruct
+    (gbrs_utils.py:382-609); the emission model and the three recursions run on the device.
+    `stage_times` (optional dict) receives wall-clock seconds per stage."""
+    clock = time.perf_counter
+    marks = stage_times if stage_times is not None else {}
     data_dir = os.getenv('GBRS_DATA', '.')
-    if outbase is None:
-        out_gtype = 'gbrs.reconstructed.genotypes.tsv'
-        out_gprob = 'gbrs.reconstructed.genoprobs.npz'
-    else:
-        out_gtype = f'{outbase}.genotypes.tsv'
-        out_gprob = f'{outbase}.genoprobs.npz'
-    out_gtype_ordered = f'{os.path.splitext(out_gtype)[0]}.npz'
-    if avec_file is None:
-        avec_file = os.path.join(data_dir, 'avecs.npz')
-    if gpos_file is None:
-        gpos_file = os.path.join(data_dir, 'ref.gene_pos.ordered.npz')
+    stem = 'gbrs.reconstructed' if outbase is None else outbase
+    out_calls, out_post, out_path = f'{stem}.genotypes.tsv', f'{stem}.genoprobs.npz', f'{stem}.genotypes.npz'
+    avec_file = avec_file or os.path.join(data_dir, 'avecs.npz')
+    gpos_file = gpos_file or os.path.join(data_dir, 'ref.gene_pos.ordered.npz')
+    for label, value in (('Expression File', expression_file), ('Transition Probabilities File', tprob_file),
+                         ('Alignment Specificity File', avec_file), ('Gene Position File', gpos_file),
+                         ('Expression Threshold', expr_threshold), ('Sigma', sigma), ('Outbase', outbase)):
+        logger.info(f'{label}: {value}')
 
-    logger.info(f'Expression File: {expression_file}')
-    logger.info(f'Transition Probabilities File: {tprob_file}')
-    logger.info(f'Alignment Specificity File: {avec_file}')
-    logger.info(f'Gene Position File: {gpos_file}')
-    logger.info(f'Expression Threshold: {expr_threshold}')
-    logger.info(f'Sigma: {sigma}')
-    logger.info(f'Outbase: {outbase}')
-
+    t0 = clock()
     logger.info('Loading chromosome information')
-    chrs = list(get_chromosome_info(data_dir).keys())
-
+    genome = list(get_chromosome_info(data_dir))
     logger.info(f'Loading alignment specificity: {avec_file}')
     avecs = np.load(avec_file)
-    avec_keys = set(avecs.files)
-
+    avec_ids = frozenset(avecs.files)
     logger.info(f'Loading gene meta data: {gpos_file}')
-    gene_pos = np.load(gpos_file)
-    gid_genome_order = {}
-    for c in gene_pos.files:
-        arr = gene_pos[c]
-        ids = [row[0] for row in arr]
-        gid_genome_order[c] = [g.decode() if isinstance(g, bytes) else str(g) for g in ids]
-
+    gene_order = read_gene_order(gpos_file)
     logger.info(f'Loading expression level data: {expression_file}')
-    expr = {}
-    with open(expression_file) as fh:
-        haplotypes = fh.readline().rstrip().split('\t')[1:-1]
-        for curline in fh:
-            item = curline.rstrip().split('\t')
-            expr[item[0]] = np.array(list(map(float, item[1:-1])))
+    haplotypes, expr = read_gene_tpm(expression_file)
     num_haps = len(haplotypes)
-    genotypes = [h1 + h2 for h1, h2 in combinations_with_replacement(haplotypes, 2)]
-
+    diplotypes = [a + b for a, b in combinations_with_replacement(haplotypes, 2)]
     logger.info(f'Loading transition probabilities: {tprob_file}')
     tprob = np.load(tprob_file)
-    tprob_keys = set(tprob.files)
-    use = [c for c in chrs if c in tprob_keys]
+    chroms = [c for c in genome if c in tprob.files]            # chromosomes without a table are skipped (:495)
+    per_chrom = [chromosome_inputs(gene_order[c], expr, avecs, avec_ids, num_haps) for c in chroms]
+    tables = [tprob[c] for c in chroms]
+    marks['load'] = clock() - t0
 
-    ex, av, ha, ng, tp = [], [], [], [], []
-    for c in use:
-        ids = gid_genome_order[c]
-        ex.append(np.array([expr[g] for g in ids], dtype=np.float64).reshape(len(ids), num_haps))
-        has = np.array([g in avec_keys for g in ids], dtype=np.uint8)
-        a = np.zeros((len(ids), num_haps, num_haps))
-        for i, g in enumerate(ids):
-            if has[i]:
-                a[i] = avecs[g]
-        av.append(a)
-        ha.append(has)
-        ng.append(len(ids))
-        tp.append(tprob[c])
-
-    gamma, viterbi_states, gtcall_g = {}, {}, {}
-    if use:
-        hmm = DiplotypeHMM(num_haps, use, ng, tp, device=device)
+    posterior, path_names, calls = {}, {}, {}
+    if chroms:
+        t0 = clock()
+        hmm = DiplotypeHMM(num_haps, chroms, [len(gene_order[c]) for c in chroms], tables, device=device)
+        marks['tables_to_device'] = clock() - t0
+        t0 = clock()
         logger.info('Getting forward probability')
-        hmm.set_expression(ex, av, ha, expr_threshold, sigma)
+        hmm.set_expression([x[0] for x in per_chrom], [x[1] for x in per_chrom], [x[2] for x in per_chrom],
+                           expr_threshold, sigma)
         logger.info('Getting backward probability')
         hmm.run()
         logger.info('Getting forward-backward probability')
-        for ci, c in enumerate(use):
-            res = hmm.get(ci)
-            gamma[c] = res['gamma']
-            viterbi_states[c] = [genotypes[s] for s in res['states']]
-            for g, s in zip(gid_genome_order[c], res['calls']):
-                if s >= 0:
-                    gtcall_g[g] = genotypes[s]
+        for k, c in enumerate(chroms):
+            res = hmm.get(k)
+            posterior[c] = res['gamma']
+            path_names[c] = [diplotypes[s] for s in res['states']]
+            calls.update((gid, diplotypes[s]) for gid, s in zip(gene_order[c], res['calls']) if s >= 0)
         hmm.close()
+        marks['hmm'] = clock() - t0
 
-    logger.info(f'Saving Reconstructed Genotype Probabilities: {out_gprob}')
-    np.savez_compressed(out_gprob, **gamma)
-    logger.info(f'Saving Reconstructed Genotypes: {out_gtype}')
-    with open(out_gtype, 'w') as fhout:
-        fhout.write('#Gene_ID\tDiplotype\n')
-        for g in sorted(gtcall_g.keys()):
-            fhout.write(f'{g}\t{gtcall_g[g]}\n')
-    logger.info(f'Saving Reconstructed Ordered Genotypes: {out_gtype_ordered}')
-    np.savez_compressed(out_gtype_ordered, **viterbi_states)
+    t0 = clock()
+    logger.info(f'Saving Reconstructed Genotype Probabilities: {out_post}')
+    np.savez_compressed(out_post, **posterior)
+    logger.info(f'Saving Reconstructed Genotypes: {out_calls}')
+    with open(out_calls, 'w') as out:
+        out.write('#Gene_ID\tDiplotype\n')
+        out.writelines(f'{gid}\t{calls[gid]}\n' for gid in sorted(calls))
+    logger.info(f'Saving Reconstructed Ordered Genotypes: {out_path}')
+    np.savez_compressed(out_path, **path_names)
+    marks['save'] = clock() - t0
     logger.info('Done')

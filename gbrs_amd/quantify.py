@@ -1,11 +1,15 @@
-"""`gbrs quantify` workflow on the MI355X path: same arguments, defaults, log lines and output
-files as gbrs/emase_utils.py:180-332 (load alignment file + groups, optional genotype mask,
-EMASE EM, 2-6 report files).  The EM runs through gbrs_amd.em.EMfactory (HIP kernels)."""
+"""`gbrs quantify` on the MI355X path.
+
+Drop-in for the workflow of gbrs/emase_utils.py:180-332 - same arguments and defaults, same output
+files (`<outbase>.multiway.*` or, with a genotype file, `<outbase>.diploid.*`), same log vocabulary -
+organised here as: resolve the support files, load the alignment tensor, optionally restrict it to the
+called diplotypes, run the EM on the device (gbrs_amd.em.EMfactory -> libgbrs_hip), write the reports.
+"""
 from __future__ import annotations
 
 import logging
 import os
-from itertools import dropwhile
+import time
 
 import numpy as np
 
@@ -14,101 +18,141 @@ from .em import EMfactory
 
 logger = logging.getLogger('gbrs')
 
+# support files looked up under $GBRS_DATA when the caller names none (gbrs/emase_utils.py:206-219)
+DEFAULT_GROUP_FILE = 'ref.gene2transcripts.tsv'
+DEFAULT_LENGTH_FILE = 'gbrs.hybridized.targets.info'
 
-def is_comment(s: str) -> bool:
-    return s.startswith('#')
+
+def _default_support_file(given, default_name, what_is_lost):
+    if given is not None:
+        return given
+    path = os.path.join(os.getenv('GBRS_DATA', '.'), default_name)
+    if not os.path.exists(path):
+        logger.warning(what_is_lost)
+    return path
 
 
-def genotype_mask(aln_mat, genotype_file):
-    """(gtmask H x L, gene calls, transcript calls) from a genotypes.tsv
-    (gbrs/emase_utils.py:245-269)."""
-    hid = dict(zip(aln_mat.hname, np.arange(aln_mat.num_haplotypes)))
-    gid = dict(zip(aln_mat.gname, np.arange(len(aln_mat.gname))))
-    gtmask = np.zeros((aln_mat.num_haplotypes, aln_mat.num_loci))
-    gtcall_g = dict.fromkeys(aln_mat.gname)
-    gtcall_t = dict.fromkeys(aln_mat.lname)
+def read_genotype_calls(genotype_file):
+    """{gene id: diplotype string} from a `genotypes.tsv` (`#Gene_ID<TAB>Diplotype` header, then one
+    line per gene).  Only the comment lines that open the file are skipped (gbrs/emase_utils.py:248)."""
+    calls = {}
+    in_header = True
     with open(genotype_file) as fh:
-        for curline in dropwhile(is_comment, fh):
-            item = curline.rstrip().split('\t')
-            g, gt = item[:2]
-            gtcall_g[g] = gt
-            hid2set = np.array([hid[c] for c in gt])
-            tid2set = np.array(aln_mat.groups[gid[g]])
-            gtmask[tuple(np.meshgrid(hid2set, tid2set))] = 1.0
-            for t in tid2set:
-                gtcall_t[aln_mat.lname[t]] = gt
-    return gtmask, gtcall_g, gtcall_t
+        for line in fh:
+            if in_header and line.startswith('#'):
+                continue
+            in_header = False
+            fields = line.rstrip().split('\t')
+            calls[fields[0]] = fields[1]
+    return calls
+
+
+def diplotype_mask(aln_mat, calls):
+    """(mask, gene notes, isoform notes) for a set of genotype calls.
+
+    mask is (H x L) with 1 where the haplotype is one of the two letters called for the locus's gene
+    (gbrs/emase_utils.py:245-269); the notes map every gene / isoform name to its call, None when
+    the gene has none (those print as `None` in the reports' notes column, as in the reference)."""
+    hap_index = {name: k for k, name in enumerate(aln_mat.hname)}
+    gene_index = {name: k for k, name in enumerate(aln_mat.gname)}
+    mask = np.zeros((aln_mat.num_haplotypes, aln_mat.num_loci))
+    gene_notes = {str(g): None for g in aln_mat.gname}
+    isoform_notes = {t: None for t in aln_mat.lname}
+    for gene, call in calls.items():
+        members = np.asarray(aln_mat.groups[gene_index[gene]], dtype=np.int64)
+        letters = [hap_index[ch] for ch in call]
+        mask[np.ix_(letters, members)] = 1.0
+        gene_notes[gene] = call
+        for t in members:
+            isoform_notes[aln_mat.lname[t]] = call
+    return mask, gene_notes, isoform_notes
+
+
+def _write_expression_reports(em, outbase, with_groups, isoform_notes, gene_notes, report_posterior):
+    """The 2-5 files `gbrs quantify` leaves behind, in the reference's order (the isoform TPM report
+    comes first because it rescales theta in place, which the later reports inherit)."""
+    def emit(label, suffix, writer, **kw):
+        path = f'{outbase}.{suffix}'
+        logger.info(f'Generating {label}: {path}')
+        writer(filename=path, **kw)
+
+    emit('isoform TPMs', 'isoforms.tpm', em.report_depths, tpm=True, notes=isoform_notes)
+    emit('isoform Read Counts', 'isoforms.expected_read_counts', em.report_read_counts, notes=isoform_notes)
+    if report_posterior:
+        emit('Posterior Probabilities', 'posterior.h5', em.export_posterior_probability)
+    if with_groups:
+        emit('gene TPMs', 'genes.tpm', em.report_depths, tpm=True, grp_wise=True, notes=gene_notes)
+        emit('gene Read Counts', 'genes.expected_read_counts', em.report_read_counts, grp_wise=True,
+             notes=gene_notes)
 
 
 def quantify(alignment_file: str, group_file: str = None, length_file: str = None,
              genotype_file: str = None, outbase: str = 'gbrs.quantified', multiread_model: int = 4,
              pseudocount: float = 0.0, max_iters: int = 999, tolerance: float = 0.0001,
              report_alignment_counts: bool = False, report_posterior: bool = False,
-             device: int = 0, merge_identical_rows: bool = False) -> None:
-    """Quantify expected read counts."""
-    data_dir = os.getenv('GBRS_DATA', '.')
-    if group_file is None:
-        group_file = os.path.join(data_dir, 'ref.gene2transcripts.tsv')
-        if not os.path.exists(group_file):
-            logger.warning('A group file is not given. Group-level results will not be reported.')
-    if length_file is None:
-        length_file = os.path.join(data_dir, 'gbrs.hybridized.targets.info')
-        if not os.path.exists(length_file):
-            logger.warning('A length file is not given. Transcript length adjustment will *not* be performed.')
-    report_group_counts = group_file is not None
+             device: int = 0, merge_identical_rows: bool = False, stage_times: dict = None) -> None:
+    """Quantify allele-specific expression from an EMASE alignment file.  `stage_times` (optional
+    dict) receives the wall-clock seconds of the stages: load, mask, em_setup, em_run, reports,
+    alignment_counts."""
+    clock = time.perf_counter
+    marks = stage_times if stage_times is not None else {}
+    group_file = _default_support_file(
+        group_file, DEFAULT_GROUP_FILE,
+        'A group file is not given. Group-level results will not be reported.')
+    length_file = _default_support_file(
+        length_file, DEFAULT_LENGTH_FILE,
+        'A length file is not given. Transcript length adjustment will *not* be performed.')
+    for label, value in (('Alignment File', alignment_file), ('Group File', group_file),
+                         ('Length File', length_file), ('Genotype File', genotype_file),
+                         ('Outbase', outbase), ('Multiread Model', multiread_model),
+                         ('Pseudocount', pseudocount), ('Tolerance', tolerance),
+                         ('Report Alignment Counts', report_alignment_counts),
+                         ('Report Posterior', report_posterior)):
+        logger.info(f'{label}: {value}')
 
-    logger.info(f'Alignment File: {alignment_file}')
-    logger.info(f'Group File: {group_file}')
-    logger.info(f'Length File: {length_file}')
-    logger.info(f'Genotype File: {genotype_file}')
-    logger.info(f'Outbase: {outbase}')
-    logger.info(f'Multiread Model: {multiread_model}')
-    logger.info(f'Pseudocount: {pseudocount}')
-    logger.info(f'Tolerance: {tolerance}')
-    logger.info(f'Report Alignment Counts: {report_alignment_counts}')
-    logger.info(f'Report Posterior: {report_posterior}')
-
+    t0 = clock()
     logger.info(f'Loading EMASE file: {alignment_file}')
     aln_mat = load_alignment(alignment_file, grpfile=group_file)
+    marks['load'] = clock() - t0
 
-    if genotype_file is not None:
-        outbase = f'{outbase}.diploid'
-        logger.debug(f'Outbase now: {outbase}')
-        logger.info(f'Loading and processing genotype calls from: {genotype_file}')
-        gtmask, gtcall_g, gtcall_t = genotype_mask(aln_mat, genotype_file)
-        aln_mat.mask_haplotype_loci(gtmask)
-    else:
+    t0 = clock()
+    gene_notes = isoform_notes = None
+    if genotype_file is None:
         outbase = f'{outbase}.multiway'
-        logger.debug(f'Outbase now: {outbase}')
-        gtcall_g = None
-        gtcall_t = None
+    else:
+        outbase = f'{outbase}.diploid'
+        logger.info(f'Loading and processing genotype calls from: {genotype_file}')
+        mask, gene_notes, isoform_notes = diplotype_mask(aln_mat, read_genotype_calls(genotype_file))
+        aln_mat.mask_haplotype_loci(mask)
+    logger.debug(f'Outbase now: {outbase}')
+    marks['mask'] = clock() - t0
 
     logger.info('Running EMASE')
-    em_factory = EMfactory(aln_mat, device=device, merge_identical_rows=merge_identical_rows)
-    em_factory.prepare(pseudocount=pseudocount, lenfile=length_file)
-    em_factory.run(model=multiread_model, tol=tolerance, max_iters=max_iters, verbose=True)
+    t0 = clock()
+    em = EMfactory(aln_mat, device=device, merge_identical_rows=merge_identical_rows)
+    em.prepare(pseudocount=pseudocount, lenfile=length_file)
+    marks['em_setup'] = clock() - t0
+    t0 = clock()
+    em.run(model=multiread_model, tol=tolerance, max_iters=max_iters, verbose=True)
+    marks['em_run'] = clock() - t0
+    marks['em_iterations'] = em.num_iters
 
-    logger.info(f'Generating isoform TPMs: {outbase}.isoforms.tpm')
-    em_factory.report_depths(filename=f'{outbase}.isoforms.tpm', tpm=True, notes=gtcall_t)
-    logger.info(f'Generating isoform Read Counts: {outbase}.isoforms.expected_read_counts')
-    em_factory.report_read_counts(filename=f'{outbase}.isoforms.expected_read_counts', notes=gtcall_t)
-    if report_posterior:
-        logger.info(f'Generating Posterior Probabilities: {outbase}.posterior.h5')
-        em_factory.export_posterior_probability(filename=f'{outbase}.posterior.h5')
-    if report_group_counts:
-        logger.info(f'Generating gene TPMs: {outbase}.genes.tpm')
-        em_factory.report_depths(filename=f'{outbase}.genes.tpm', tpm=True, grp_wise=True, notes=gtcall_g)
-        logger.info(f'Generating gene Read Counts: {outbase}.genes.expected_read_counts')
-        em_factory.report_read_counts(filename=f'{outbase}.genes.expected_read_counts', grp_wise=True,
-                                      notes=gtcall_g)
-    em_factory.close()
+    t0 = clock()
+    _write_expression_reports(em, outbase, group_file is not None, isoform_notes, gene_notes, report_posterior)
+    em.close()
+    marks['reports'] = clock() - t0
 
     if report_alignment_counts:
+        t0 = clock()
         from .counts import report_alignment_counts as write_counts
-        alnmat = load_alignment(alignment_file, grpfile=group_file)
-        logger.info(f'Generating isoform Alignment Counts: {outbase}.isoforms.alignment_counts')
-        write_counts(alnmat, f'{outbase}.isoforms.alignment_counts', grp_wise=False, device=device)
-        if report_group_counts:
-            logger.info(f'Generating gene Alignment Counts: {outbase}.genes.alignment_counts')
-            write_counts(alnmat, f'{outbase}.genes.alignment_counts', grp_wise=True, device=device)
+        # the EM above may have masked the tensor (-G); the reference reloads the file for this report
+        # (gbrs/emase_utils.py:318-331), so the counts are always those of the unmasked alignments
+        fresh = load_alignment(alignment_file, grpfile=group_file) if genotype_file is not None else aln_mat
+        for level, grp_wise in (('isoform', False), ('gene', True)):
+            if grp_wise and group_file is None:
+                continue
+            path = f'{outbase}.{level}s.alignment_counts'
+            logger.info(f'Generating {level} Alignment Counts: {path}')
+            write_counts(fresh, path, grp_wise=grp_wise, device=device)
+        marks['alignment_counts'] = clock() - t0
     logger.debug('Done')

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GBRS_ABI_VERSION 1
+#define GBRS_ABI_VERSION 2
 
 enum gbrs_status {
     GBRS_OK = 0,
@@ -110,9 +110,13 @@ int gbrs_em_step(gbrs_em_t *em, int n_iters, double *err_sum_out);
 
 /* Replaces EMfactory.run (EMfactory.py:234-287).  model must be 4.  Stops when
  * err_sum <= 1e6*tol or after max_iters steps.  err_hist (nullable) receives up to
- * err_hist_cap per-iteration err_sum values (the numbers the reference prints). */
+ * err_hist_cap per-iteration err_sum values (the numbers the reference prints); elapsed_s (nullable,
+ * same capacity) the wall-clock seconds since the start of the run at which each iteration was
+ * complete on the host's side - the "Time" column of the reference's progress table (:284-287).
+ * The device loop hands control back once per batch of 8 iterations, so the iterations of a batch
+ * share one time stamp. */
 int gbrs_em_run(gbrs_em_t *em, int model, double tol, int max_iters,
-                int *n_iters_out, double *err_hist, int err_hist_cap);
+                int *n_iters_out, double *err_hist, int err_hist_cap, double *elapsed_s);
 
 /* theta (H x L) = EMfactory.allelic_expression; expected_counts (H x L) = probability.sum(READ)
  * of the last E-step (EMfactory.py:302).  Either pointer may be NULL. */
@@ -162,14 +166,20 @@ typedef struct gbrs_em_info {
     uint64_t num_tiles;         /* layout 1: workgroup tiles                                */
     uint64_t num_slots;         /* layout 1: (tile, locus) partial-sum slots                */
     uint64_t num_long_rows;     /* layout 1: rows handled by the long-row kernel            */
+    uint64_t num_heavy_loci;    /* layout 1: loci with more than 16 slots (one wavefront each in the
+                                   gather: emase/AlignmentPropertyMatrix.py:288-298 column sums)   */
+    uint64_t num_light_loci;    /* layout 1: loci with 2..16 slots (summed in place)        */
+    uint64_t estep_bytes;       /* bytes the E-step kernel itself moves per launch: word stream, tile
+                                   headers, dictionary, theta gather, slot stores [, row weights]  */
 } gbrs_em_info_t;
 int gbrs_em_info(gbrs_em_t *em, gbrs_em_info_t *info);
 
 /* `--report-alignment-counts` (emase/AlignmentPropertyMatrix.py:389-459), stand-alone (the
  * reference reloads the alignment file for it, gbrs/emase_utils.py:318-331).  Inputs as for
  * gbrs_em_create.  locus_group (nullable) int32[L] maps every locus to an output column, which
- * gives the gene-level report after _bundle_inline(reset=True) (:155-188); num_out_loci = G then,
- * ignored (= L) otherwise.  Outputs, any nullable: aln_counts and allele_unique (H x Lout)
+ * gives the gene-level report after _bundle_inline(reset=True) (:155-188); -1 = the locus is in no
+ * group: its entries drop out, as they do from the product with grp_conv_mat.  num_out_loci = G
+ * then, ignored (= L) otherwise.  Outputs, any nullable: aln_counts and allele_unique (H x Lout)
  * row-major, locus_unique (Lout).  Sums of EC counts in float64: exact for integer counts. */
 int gbrs_alignment_counts(uint64_t num_rows, uint32_t num_loci, uint32_t num_haps,
                           const uint32_t *const *indptr, const uint32_t *const *indices,

@@ -23,6 +23,9 @@ def alignment_counts(R, L, H, indptr, indices, count=None, locus_group=None, num
         cols.append(col)
         haps.append(np.full(len(col), h, dtype=np.int64))
     rows, cols, haps = np.concatenate(rows), np.concatenate(cols), np.concatenate(haps)
+    # a locus in no group (locus_group == -1) has no column in grp_conv_mat: its entries drop out (:166-176)
+    keep = cols >= 0
+    rows, cols, haps = rows[keep], cols[keep], haps[keep]
     # bundling makes (row, gene, hap) a set: several isoforms of one gene collapse to one entry
     ent = np.unique(np.stack((rows, cols, haps), axis=1), axis=0)
     r, c, h = ent[:, 0], ent[:, 1], ent[:, 2]

@@ -264,7 +264,7 @@ def hmm_case(name, H, genes_per_chrom, seed, len_minus_one, extra_fai_chrom=True
 
 # ----------------------------------------------------------------------------- alignment counts
 
-def counts_case(name, R, H, L, seed, with_count, drop_rows=0):
+def counts_case(name, R, H, L, seed, with_count, drop_rows=0, drop_every_nth_group=0):
     """`--report-alignment-counts` (AlignmentPropertyMatrix.py:389-459) at isoform level and, after
     _bundle_inline(reset=True) (:155-188), at gene level, from the reference's own methods."""
     inc = synth.make_em_problem(R=R, H=H, L=L, seed=seed, with_count=with_count, max_count=7)
@@ -276,6 +276,12 @@ def counts_case(name, R, H, L, seed, with_count, drop_rows=0):
             loc = np.repeat(np.arange(L), np.diff(inc.indptr[h].astype(np.int64)))[keep]
             inc.indices[h] = inc.indices[h][keep]
             inc.indptr[h] = np.searchsorted(loc, np.arange(L + 1)).astype(np.uint32)
+    if drop_every_nth_group:
+        # genes missing from the group file: their isoforms belong to no group and vanish from the
+        # bundled matrix (the product with grp_conv_mat, AlignmentPropertyMatrix.py:166-176)
+        keep_g = [i for i in range(len(inc.groups)) if i % drop_every_nth_group != 1]
+        inc.groups = [inc.groups[i] for i in keep_g]
+        inc.group_names = [inc.group_names[i] for i in keep_g]
     case_dir = os.path.join(WORK, name)
     os.makedirs(case_dir)
     grpfile = os.path.join(case_dir, "g2t.tsv")
@@ -367,6 +373,7 @@ def main():
             counts_case("h8_count", 1500, 8, 80, 41, True)
             counts_case("h8_plain_emptyrows", 2000, 8, 100, 42, False, drop_rows=100)
             counts_case("h2_count", 1200, 2, 60, 43, True)
+            counts_case("h8_ungrouped", 1500, 8, 80, 44, True, drop_every_nth_group=4)
         if only == "counts":
             return
         if only == "postproc":

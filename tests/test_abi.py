@@ -18,14 +18,33 @@ def test_header_symbols_exported(hip_lib):
     for n in names:
         assert hasattr(hip_lib, n), f"{n} declared in gbrs_hip.h but not exported"
     assert sorted(_lib.EXPORTS) == names
-    assert hip_lib.gbrs_abi_version() == 1
+    assert hip_lib.gbrs_abi_version() == 2
 
 
-def test_struct_sizes():
+def test_struct_sizes(tmp_path):
+    """The ctypes mirrors of the info structs have the size and field offsets a C compiler gives the
+    declarations in include/gbrs_hip.h (the header must also compile as plain C)."""
     import ctypes as C
+    import shutil
+    import subprocess
     from gbrs_amd import _lib
-    assert C.sizeof(_lib.EmInfo) == 8 * 8 + 4 * 4 + 3 * 8
+    assert C.sizeof(_lib.EmInfo) == 8 * 8 + 4 * 4 + 6 * 8
     assert C.sizeof(_lib.HmmInfo) == 2 * 8 + 4 * 8 + 2 * 4 + 8
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if cc is None:
+        return
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "gbrs_hip.h"\n'
+                   'int main(void){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(gbrs_em_info_t), '
+                   'sizeof(gbrs_hmm_info_t), offsetof(gbrs_em_info_t, estep_bytes), '
+                   'offsetof(gbrs_em_info_t, num_tiles), offsetof(gbrs_hmm_info_t, last_run_ms), '
+                   'offsetof(gbrs_em_info_t, last_estep_ms));return 0;}\n')
+    exe = tmp_path / "sz"
+    subprocess.run([cc, "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)],
+                   check=True)
+    got = [int(x) for x in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    assert got == [C.sizeof(_lib.EmInfo), C.sizeof(_lib.HmmInfo), _lib.EmInfo.estep_bytes.offset,
+                   _lib.EmInfo.num_tiles.offset, _lib.HmmInfo.last_run_ms.offset, _lib.EmInfo.last_estep_ms.offset]
 
 
 def test_no_cpu_fallback_without_device(hip_lib):

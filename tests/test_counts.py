@@ -24,7 +24,7 @@ def test_counts_oracle_matches_reference(path):
     np.testing.assert_array_equal(a, g["isoforms_aln"])
     np.testing.assert_array_equal(u, g["isoforms_uniq"])
     np.testing.assert_array_equal(lu, g["isoforms_locus_uniq"])
-    grp = np.zeros(L, dtype=np.int64)
+    grp = np.full(L, -1, dtype=np.int64)
     for i, m in enumerate(groups):
         grp[m] = i
     a, u, lu = alignment_counts(R, L, H, indptr, indices, count, grp, len(groups))
@@ -54,3 +54,31 @@ def test_counts_hip_bit_exact(path, tmp_path):
         p = tmp_path / f"{level}.tsv"
         report_alignment_counts(apm, str(p), grp_wise=grp_wise)
         assert open(p).read() == str(g[f"text_{level}"])
+
+
+@pytest.mark.gpu
+def test_counts_and_compress_reject_bad_row_ids():
+    """A row id >= num_rows must come back as an error before any kernel indexes per-row storage."""
+    from gbrs_amd import _lib
+    from gbrs_amd.alignment import AlignmentPropertyMatrix
+    from gbrs_amd.compress import compress_matrix
+    from gbrs_amd.counts import alignment_counts
+    apm = AlignmentPropertyMatrix(shape=(2, 1, 3), indptr=[np.array([0, 2, 3], dtype=np.uint32)],
+                                  indices=[np.array([0, 4_000_000_000, 1], dtype=np.uint32)],
+                                  haplotype_names=["A"], locus_names=["t0", "t1"])
+    with pytest.raises(_lib.GbrsHipError, match="row id"):
+        alignment_counts(apm)
+    with pytest.raises(_lib.GbrsHipError, match="row id"):
+        compress_matrix(apm)
+
+
+@pytest.mark.gpu
+def test_counts_locus_in_two_groups_is_rejected():
+    from gbrs_amd.alignment import AlignmentPropertyMatrix
+    from gbrs_amd.counts import alignment_counts
+    apm = AlignmentPropertyMatrix(shape=(2, 1, 3), indptr=[np.array([0, 2, 3], dtype=np.uint32)],
+                                  indices=[np.array([0, 2, 1], dtype=np.uint32)],
+                                  haplotype_names=["A"], locus_names=["t0", "t1"])
+    apm.groups, apm.gname, apm.num_groups = [[0, 1], [1]], np.array(["g0", "g1"]), 2
+    with pytest.raises(RuntimeError, match="more than one group"):
+        alignment_counts(apm, grp_wise=True)

@@ -20,7 +20,7 @@ def make_apm(g):
 
 def test_report_text_matches_reference_digits():
     """The writer reproduces the reference's TSV byte for byte given the reference's numbers."""
-    from gbrs_amd.em import _write_report
+    from gbrs_amd.em import write_locus_table
     import io, os, tempfile
     g = golden("h8_count_len")
     H = int(g["num_haps"])
@@ -34,7 +34,7 @@ def test_report_text_matches_reference_digits():
     for key, names, vals in cases:
         with tempfile.TemporaryDirectory() as d:
             p = os.path.join(d, "r.tsv")
-            _write_report(p, hn, names, vals, vals.sum(axis=0), "as-is", None)
+            write_locus_table(p, hn, names, vals)
             assert open(p).read() == str(g[key]), key
     # gene TPM: the reference first rescales theta in place (isoform report), then groups, then rescales
     from oracle.em_oracle import EMOracle
@@ -43,7 +43,7 @@ def test_report_text_matches_reference_digits():
     gene = gene * (1000000.0 / gene.sum())
     with tempfile.TemporaryDirectory() as d:
         p = os.path.join(d, "r.tsv")
-        _write_report(p, hn, gn, gene, gene.sum(axis=0), "as-is", None)
+        write_locus_table(p, hn, gn, gene)
         assert open(p).read() == str(g["text_genes_tpm"])
 
 
@@ -118,7 +118,7 @@ def test_cli_surface_and_error_swallowing(tmp_path, capsys):
 
 
 def test_genotype_mask_parsing(tmp_path):
-    from gbrs_amd.quantify import genotype_mask
+    from gbrs_amd.quantify import diplotype_mask, read_genotype_calls
     g = golden("h8_mask")
     apm, groups, gtmask, _ = make_apm(g)
     apm.groups = groups
@@ -131,6 +131,12 @@ def test_genotype_mask_parsing(tmp_path):
             hs = np.flatnonzero(gtmask[:, mem[0]])
             code = "".join(apm.hname[h] for h in (hs if len(hs) == 2 else [hs[0], hs[0]]))
             fh.write(f"G{i:07d}\t{code}\n")
-    m, cg, ct = genotype_mask(apm, str(gt))
+    calls = read_genotype_calls(str(gt))
+    m, cg, ct = diplotype_mask(apm, calls)
     np.testing.assert_array_equal(m, gtmask)
     assert cg["G0000000"] is not None and ct[apm.lname[groups[0][0]]] == cg["G0000000"]
+    assert len(cg) == len(groups) and len(ct) == apm.num_loci
+    # a gene missing from the file keeps the note None, as the reference's dict.fromkeys tables do
+    m2, cg2, ct2 = diplotype_mask(apm, {k: v for k, v in calls.items() if k != "G0000001"})
+    assert cg2["G0000001"] is None and ct2[apm.lname[groups[1][0]]] is None
+    assert not m2[:, groups[1]].any()
