@@ -39,6 +39,7 @@ GBRS_EM_LAYOUT_CSC = 2
 GBRS_EM_NO_INTERLEAVE = 4
 GBRS_EM_FORCE_INTERLEAVE = 8
 GBRS_EM_NO_STREAMS = 16
+GBRS_EM_DETERMINISTIC = 32
 
 
 class EmInfo(C.Structure):

@@ -447,14 +447,17 @@ int em_estep_tiles_h(gbrs_em *em) {
         if (ONES || !em->err_pending) ea.n_err_blocks = 0;
         em->err_pending = false;
         const dim3 grid((unsigned)tl.n_tiles + ea.n_err_blocks), block(TILE_THREADS);
-        if (tl.weighted)
-            hipLaunchKernelGGL((tile_estep_kernel<HT, true, ONES>), grid, block, 0, em->stream, em->H, tl.tiles.p,
-                               tl.words.p, tl.dict.p, tl.word_weight.p, em->theta.p, tl.partials.p, tl.slot_dest.p,
-                               em->acc.p, em->scalars.p, (uint32_t)tl.n_tiles, ea);
-        else
-            hipLaunchKernelGGL((tile_estep_kernel<HT, false, ONES>), grid, block, 0, em->stream, em->H, tl.tiles.p,
-                               tl.words.p, tl.dict.p, (const double *)nullptr, em->theta.p, tl.partials.p,
-                               tl.slot_dest.p, em->acc.p, em->scalars.p, (uint32_t)tl.n_tiles, ea);
+        const double *ww = tl.weighted ? tl.word_weight.p : (const double *)nullptr;
+#define GBRS_LAUNCH_TILES(W, D)                                                                                        \
+        hipLaunchKernelGGL((tile_estep_kernel<HT, W, ONES, D>), grid, block, 0, em->stream, em->H, tl.tiles.p, tl.words.p, \
+                           tl.dict.p, ww, em->theta.p, tl.partials.p, tl.slot_dest.p, em->acc.p, em->scalars.p,       \
+                           (uint32_t)tl.n_tiles, ea)
+        if (tl.deterministic) {           // fixed-order sums instead of LDS float atomics (GBRS_EM_DETERMINISTIC)
+            if (tl.weighted) GBRS_LAUNCH_TILES(true, true); else GBRS_LAUNCH_TILES(false, true);
+        } else {
+            if (tl.weighted) GBRS_LAUNCH_TILES(true, false); else GBRS_LAUNCH_TILES(false, false);
+        }
+#undef GBRS_LAUNCH_TILES
     }
     return GBRS_OK;
 }
@@ -473,9 +476,14 @@ int em_estep_tiles(gbrs_em *em, bool materialize, bool skip_gather = false) {
     }
     if (tl.n_long) {
         GBRS_HIP_CHECK(hipMemsetAsync(tl.acc_extra.p, 0, tl.acc_extra.bytes(), em->stream));
-        hipLaunchKernelGGL(long_rows_estep_kernel<ONES>, dim3((unsigned)((tl.n_long + 3) / 4)), dim3(256), 0, em->stream,
-                           tl.n_long, em->H, tl.long_ptr.p, tl.long_loc.p, tl.long_mask.p, tl.long_weight.p,
-                           em->theta.p, tl.acc_extra.p, em->scalars.p);
+        if (tl.deterministic)
+            hipLaunchKernelGGL(long_rows_estep_serial_kernel<ONES>, dim3(1), dim3(64), 0, em->stream, tl.n_long, em->H,
+                               tl.long_ptr.p, tl.long_loc.p, tl.long_mask.p, tl.long_weight.p, em->theta.p,
+                               tl.acc_extra.p, em->scalars.p);
+        else
+            hipLaunchKernelGGL(long_rows_estep_kernel<ONES>, dim3((unsigned)((tl.n_long + 3) / 4)), dim3(256), 0, em->stream,
+                               tl.n_long, em->H, tl.long_ptr.p, tl.long_loc.p, tl.long_mask.p, tl.long_weight.p,
+                               em->theta.p, tl.acc_extra.p, em->scalars.p);
     }
     if (em->ev_after_estep) {
         GBRS_HIP_CHECK(hipEventRecord(em->ev_after_estep, em->stream));
@@ -918,6 +926,9 @@ int em_create_impl(uint64_t R, uint32_t L, uint32_t H, const uint32_t *const *in
     GBRS_HIP_CHECK(hipDeviceSynchronize());
     GBRS_TRY(check_row_ids(n, em->ent_row.p, R, em->stream));
     stg.mark("vectors, checks");
+    if ((flags & GBRS_EM_DETERMINISTIC) && ((flags & GBRS_EM_LAYOUT_CSC) || H > 16 || n >= 0xFFFFFFFFull))
+        return fail(GBRS_ERR_UNSUPPORTED, "GBRS_EM_DETERMINISTIC needs the tiled layout (H <= 16, not GBRS_EM_LAYOUT_CSC): "
+                                          "the CSC kernels accumulate with global float atomics");
     if (!(flags & GBRS_EM_LAYOUT_CSC) && H <= 16 && n < 0xFFFFFFFFull) {
         // Row order inside a tile: the stream order (gbrs_hip.h) by default - every lane walks a
         // contiguous piece of the tile's sorted rows, so it stays on one locus list for long stretches
@@ -931,7 +942,7 @@ int em_create_impl(uint64_t R, uint32_t L, uint32_t H, const uint32_t *const *in
         }
         GBRS_TRY(build_tile_layout(em->tl, R, L, H, n, em->ent_row.p, em->col_ptr.p,
                                    count ? em->count.p : nullptr, (flags & GBRS_EM_MERGE_IDENTICAL_ROWS) != 0,
-                                   row_order,
+                                   row_order, (flags & GBRS_EM_DETERMINISTIC) != 0,
                                    em->stream));
         em->layout = 1;
         stg.mark("build_tile_layout");

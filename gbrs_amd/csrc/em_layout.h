@@ -34,6 +34,9 @@ __host__ __device__ constexpr int max_row_words(int H) { return 1 << pos_bits(H)
 #endif
 constexpr int LDS_THETA_DOUBLES = GBRS_LDS_DOUBLES;        // theta of the tile: D_MAX * H doubles
 constexpr int LDS_ACC_DOUBLES = GBRS_LDS_DOUBLES + 64;     // privatised partial sums
+// deterministic mode (GBRS_EM_DETERMINISTIC): every wavefront of a tile owns a private copy of the tile's
+// sums, so a tile may reference at most this many loci
+__host__ __device__ constexpr uint32_t det_dict_cap(int H) { return (LDS_ACC_DOUBLES / TILE_WAVES - 1) / H; }
 constexpr uint32_t SLOT_DIRECT = 0x80000000u;
 constexpr int HEAVY_SLOTS = 16;                // loci with more slots get a whole wave in the gather (measured 1, 4, 16, 64)
 
@@ -53,6 +56,7 @@ struct TileLayout {
     uint64_t n_tiles = 0, n_batches = 0, n_slots = 0, n_heavy = 0, n_light = 0;
     uint32_t d_max = 0;          // dictionary capacity used when cutting tiles
     bool weighted = false;       // per-row weights present (count given or rows merged)
+    bool deterministic = false;  // dictionaries capped at det_dict_cap(H): one private sum copy per wavefront
 
     DevBuf<uint32_t> words;          // n_batches * 64
     DevBuf<TileHdr> tiles;           // n_tiles
@@ -79,7 +83,7 @@ struct TileLayout {
 int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L, uint32_t H, uint64_t N,
                       const uint32_t *ent_row, const uint64_t *col_ptr, const double *count,
                       bool merge_identical_rows, int row_order /* 0 sorted, 1 interleaved, 2 streams */,
-                      hipStream_t stream);
+                      bool deterministic, hipStream_t stream);
 
 // `gbrs compress`: equivalence classes of identical rows, in first-seen order.
 struct CompressResult {

@@ -818,7 +818,7 @@ int compress_device(CompressResult &out, uint64_t R, uint32_t L, uint32_t H, uin
 
 int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L, uint32_t H, uint64_t N,
                       const uint32_t *ent_row, const uint64_t *col_ptr, const double *count,
-                      bool merge, int row_order, hipStream_t s) {
+                      bool merge, int row_order, bool deterministic, hipStream_t s) {
     const bool interleave = row_order == 1, streams = row_order == 2;
     if (H > 16) return fail(GBRS_ERR_INVALID, "the tiled layout packs the haplotype mask in 16 bits (H <= 16)");
     if (N >= 0xFFFFFFFFull || L >= (1u << 27))
@@ -835,6 +835,10 @@ int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L, uint32_t H, uint6
         return GBRS_OK;
     };
     out.d_max = std::min<uint32_t>(1024, LDS_THETA_DOUBLES / H);
+    out.deterministic = deterministic;
+    if (deterministic) out.d_max = std::min<uint32_t>(out.d_max, det_dict_cap(H));
+    if (out.d_max <= (uint32_t)max_row_words(H))
+        return fail(GBRS_ERR_UNSUPPORTED, "the deterministic tile layout has no room for a row's loci at H = %u", H);
     const uint32_t dseg = out.d_max - max_row_words(H);
     out.weighted = merge || count != nullptr;
     out.n_pairs = out.n_rows = out.n_rows_in = out.n_long = out.n_tiles = out.n_batches = out.n_slots = 0;

@@ -19,14 +19,15 @@ class EMfactory:
     """A class that coordinates Expectation-Maximization (MI355X HIP path)."""
 
     def __init__(self, alignments, device: int = 0, merge_identical_rows: bool = False,
-                 csc_layout: bool = False, extra_flags: int = 0):
+                 csc_layout: bool = False, extra_flags: int = 0, deterministic: bool = False):
         self.probability = alignments
         self.grp_conv_mat = None          # kept for attribute parity; groups live in probability
         self.t2t_mat = None               # Models 1-3 only (EMfactory.py:48-59): never built
         self.target_lengths = None
         self.device = device
         self.flags = (_lib.GBRS_EM_MERGE_IDENTICAL_ROWS if merge_identical_rows else 0) | \
-                     (_lib.GBRS_EM_LAYOUT_CSC if csc_layout else 0) | int(extra_flags)   # tuning switches of gbrs_hip.h
+                     (_lib.GBRS_EM_LAYOUT_CSC if csc_layout else 0) | \
+                     (_lib.GBRS_EM_DETERMINISTIC if deterministic else 0) | int(extra_flags)   # tuning switches of gbrs_hip.h
         self._h = None
         self._theta = None                # host copy of allelic_expression (H x L)
         self._theta_dirty = False         # host copy edited, device not yet updated

@@ -74,6 +74,13 @@ typedef struct gbrs_em gbrs_em_t;
 #define GBRS_EM_NO_INTERLEAVE 4u
 #define GBRS_EM_FORCE_INTERLEAVE 8u
 #define GBRS_EM_NO_STREAMS 16u
+/* Bit-reproducible sums: the E-step's LDS float64 atomics are replaced by a fixed-order reduction
+ * (every wavefront of a tile owns a private copy of the tile's partial sums; lanes that hand in sums
+ * for one locus are added by a fixed tree; copies, slots and block sums are added in index order), so
+ * two runs on the same input give bit-identical theta and therefore the same iteration count even when
+ * err_sum lands next to 1e6*tol (EMfactory.py:266).  The tiles are cut smaller (at most
+ * (4160/8 - 1)/H loci each); not available with GBRS_EM_LAYOUT_CSC or H > 16. */
+#define GBRS_EM_DETERMINISTIC 32u
 
 /*
  * Replaces: AlignmentPropertyMatrix(h5file=...) as consumed by EMfactory.__init__

@@ -123,3 +123,24 @@ def test_c2_full_size_properties(c2_sample):
     em.step(3)
     close(em.theta(), th3)
     em.close()
+
+
+def test_c2_full_size_deterministic_mode(c2_sample):
+    """40M reads: two deterministic-mode runs are bit-identical, agree with the default path to 1e-9 and stop
+    at the same iteration."""
+    from gbrs_amd import _lib
+    prob = c2_sample
+    res = []
+    for _ in range(2):
+        eng = _engine(prob, _lib.GBRS_EM_DETERMINISTIC)
+        eng.prepare(0.0)
+        n, hist = eng.run(model=4, tol=1e-4, max_iters=999)
+        res.append((n, hist, eng.theta()))
+        eng.close()
+    assert res[0][0] == res[1][0] and np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+    eng = _engine(prob)
+    eng.prepare(0.0)
+    n, hist = eng.run(model=4, tol=0.0, max_iters=res[0][0])
+    close(eng.theta(), res[0][2])
+    np.testing.assert_allclose(hist, res[0][1], rtol=1e-7)
+    eng.close()

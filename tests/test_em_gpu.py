@@ -15,7 +15,9 @@ RTOL = 1e-9
 # tiles = packed row tiles in the default stream order; the other row orders stay reachable through
 # GBRS_EM_NO_STREAMS (16: sorted order, or interleaved when rows are distinct patterns)
 LAYOUTS = {"tiles": dict(), "tiles_merged": dict(merge_identical_rows=True), "csc": dict(csc_layout=True),
-           "tiles_sorted": dict(extra_flags=16), "tiles_merged_interleaved": dict(merge_identical_rows=True, extra_flags=16)}
+           "tiles_sorted": dict(extra_flags=16), "tiles_merged_interleaved": dict(merge_identical_rows=True, extra_flags=16),
+           "tiles_deterministic": dict(deterministic=True),
+           "tiles_deterministic_merged": dict(deterministic=True, merge_identical_rows=True)}
 
 
 def make_factory(g, layout="tiles"):
@@ -401,3 +403,69 @@ def test_create_rejects_bad_inputs():
             EmEngine.from_device(3, 2, 1, [d_ip.data_ptr()], [d_ix.data_ptr()], flags=flags)
     with pytest.raises(_lib.GbrsHipError):
         EmEngine.from_host(3, 2, 40, ip * 40, [np.array([0, 1, 2], dtype=np.uint32)] * 40)     # H > 32
+
+
+@pytest.mark.parametrize("H,with_count,merge", [(8, False, False), (8, True, False), (8, False, True), (16, False, False),
+                                                (2, True, False), (3, False, False)])
+def test_deterministic_mode_is_bit_reproducible(H, with_count, merge):
+    """GBRS_EM_DETERMINISTIC: fixed-order sums instead of LDS float atomics.  Two handles built from the
+    same arrays, and two runs on one handle, give bit-identical theta / expected counts / err history and
+    the same iteration count; the result agrees with the default (atomic) path and the oracle to 1e-9."""
+    from gbrs_amd import _lib, synth
+    from gbrs_amd.engine import EmEngine
+    from oracle.em_oracle import EMOracle
+    inc = synth.make_em_problem(R=150_000, H=H, L=1_500, seed=200 + H, with_count=with_count, max_count=4)
+    eff = inc.effective_length(100)
+    flags = _lib.GBRS_EM_DETERMINISTIC | (_lib.GBRS_EM_MERGE_IDENTICAL_ROWS if merge else 0)
+    runs = []
+    for _ in range(2):
+        eng = EmEngine.from_host(inc.num_rows, inc.num_loci, H, inc.indptr, inc.indices, inc.count, eff, flags=flags)
+        assert eng.info().layout == 1
+        for _ in range(2):
+            eng.prepare(0.0)
+            n, hist = eng.run(model=4, tol=1e-4, max_iters=60)
+            runs.append((n, hist, eng.theta(), eng.expected_counts()))
+        eng.close()
+    n0, h0, t0, c0 = runs[0]
+    for n, hist, th, cn in runs[1:]:
+        assert n == n0
+        assert np.array_equal(hist, h0) and np.array_equal(th, t0) and np.array_equal(cn, c0)
+    ref = EmEngine.from_host(inc.num_rows, inc.num_loci, H, inc.indptr, inc.indices, inc.count, eff,
+                             flags=flags & ~_lib.GBRS_EM_DETERMINISTIC)
+    # the same number of steps on the default (LDS atomics) path and on the oracle: a run-to-run last-bit
+    # difference there must not be able to move the comparison by a whole iteration
+    ref.prepare(0.0)
+    nr, hr = ref.run(model=4, tol=0.0, max_iters=n0)
+    close(ref.theta(), t0)
+    np.testing.assert_allclose(hr, h0, rtol=1e-7)
+    ref.close()
+    o = EMOracle(inc.num_rows, inc.num_loci, H, inc.indptr, inc.indices, inc.count)
+    o.prepare(0.0, eff)
+    o.run(tol=0.0, max_iters=n0)
+    close(t0, o.theta)
+    assert h0[-1] <= 100.0 and (n0 == 1 or h0[-2] > 100.0)        # stopped exactly where the rule says
+
+
+def test_deterministic_mode_long_rows_and_limits():
+    """Rows beyond the word capacity go through the serial long-row kernel in deterministic mode; the CSC
+    layout (global float atomics) refuses the flag."""
+    from gbrs_amd import _lib
+    from gbrs_amd.engine import EmEngine
+    from oracle.em_oracle import EMOracle
+    indptr, indices, count, eff = _random_rows_problem(600, 8, 400, 321, 20, 70, True)
+    o = EMOracle(600, 400, 8, indptr, indices, count)
+    o.prepare(0.0, eff)
+    o.run(tol=0.0, max_iters=4)
+    out = []
+    for _ in range(2):
+        eng = EmEngine.from_host(600, 400, 8, indptr, indices, count, eff, flags=_lib.GBRS_EM_DETERMINISTIC)
+        assert eng.info().num_long_rows > 0
+        eng.prepare(0.0)
+        eng.run(model=4, tol=0.0, max_iters=4)
+        out.append((eng.theta(), eng.expected_counts()))
+        eng.close()
+    assert np.array_equal(out[0][0], out[1][0]) and np.array_equal(out[0][1], out[1][1])
+    close(out[0][0], o.theta)
+    with pytest.raises(_lib.GbrsHipError, match="DETERMINISTIC"):
+        EmEngine.from_host(600, 400, 8, indptr, indices, count, eff,
+                           flags=_lib.GBRS_EM_DETERMINISTIC | _lib.GBRS_EM_LAYOUT_CSC)
