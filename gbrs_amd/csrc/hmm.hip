@@ -1957,23 +1957,33 @@ int gbrs_hmm_create(int num_haps, int n_chrom, const int32_t *n_genes, const int
 int gbrs_hmm_set_expression(gbrs_hmm_t *h, int n_samples, const double *const *expr,
                             const double *const *avecs, const uint8_t *const *has_avec,
                             double expr_threshold, double sigma) {
-    if (!h || !expr || !avecs || !has_avec || n_samples < 1) return fail(GBRS_ERR_INVALID, "bad argument");
+    if (!h || !expr || n_samples < 1 || (avecs == nullptr) != (has_avec == nullptr))
+        return fail(GBRS_ERR_INVALID, "bad argument");
     GBRS_TRY(select_device(h->device));
     GBRS_TRY(hmm_alloc_samples(h, n_samples));
     const int H = h->H;
-    GBRS_TRY(h->expr.alloc((size_t)h->total_genes * n_samples * H));
-    GBRS_TRY(h->avecs.alloc((size_t)h->total_genes * H * H));
-    GBRS_TRY(h->has_avec.alloc(h->total_genes));
+    if (h->expr.n != (size_t)h->total_genes * n_samples * H) GBRS_TRY(h->expr.alloc((size_t)h->total_genes * n_samples * H));
+    // The specificity blocks are sample independent (20 MB for 40k genes x 8 x 8): they are uploaded when
+    // given and stay resident on the handle; later calls pass NULL tables and only move the expression rows.
+    if (avecs) {
+        if (!h->avecs.p) GBRS_TRY(h->avecs.alloc((size_t)h->total_genes * H * H));
+        if (!h->has_avec.p) GBRS_TRY(h->has_avec.alloc(h->total_genes));
+    } else if (!h->avecs.p) {
+        return fail(GBRS_ERR_STATE, "no alignment specificity on the handle yet: pass avecs / has_avec once");
+    }
     for (int c = 0; c < h->n_chrom; ++c) {
         const ChromDesc &cd = h->chroms[c];
-        if (!expr[c] || !avecs[c] || !has_avec[c]) return fail(GBRS_ERR_INVALID, "NULL table for chromosome %d", c);
-        for (int s = 0; s < n_samples; ++s)
-            GBRS_HIP_CHECK(hipMemcpy(h->expr.p + ((size_t)s * h->total_genes + cd.gene_off) * H,
-                                     expr[c] + (size_t)s * cd.n_genes * H,
-                                     (size_t)cd.n_genes * H * sizeof(double), hipMemcpyHostToDevice));
-        GBRS_HIP_CHECK(hipMemcpy(h->avecs.p + (size_t)cd.gene_off * H * H, avecs[c],
-                                 (size_t)cd.n_genes * H * H * sizeof(double), hipMemcpyHostToDevice));
-        GBRS_HIP_CHECK(hipMemcpy(h->has_avec.p + cd.gene_off, has_avec[c], cd.n_genes, hipMemcpyHostToDevice));
+        if (!expr[c] || (avecs && (!avecs[c] || !has_avec[c]))) return fail(GBRS_ERR_INVALID, "NULL table for chromosome %d", c);
+        if (cd.n_genes == 0) continue;
+        // one strided copy per chromosome: the caller's [sample][gene][H] block into the genome-wide rows
+        const size_t row = (size_t)cd.n_genes * H * sizeof(double);
+        GBRS_HIP_CHECK(hipMemcpy2D(h->expr.p + (size_t)cd.gene_off * H, (size_t)h->total_genes * H * sizeof(double),
+                                   expr[c], row, row, (size_t)n_samples, hipMemcpyHostToDevice));
+        if (avecs) {
+            GBRS_HIP_CHECK(hipMemcpy(h->avecs.p + (size_t)cd.gene_off * H * H, avecs[c],
+                                     (size_t)cd.n_genes * H * H * sizeof(double), hipMemcpyHostToDevice));
+            GBRS_HIP_CHECK(hipMemcpy(h->has_avec.p + cd.gene_off, has_avec[c], cd.n_genes, hipMemcpyHostToDevice));
+        }
     }
     const int64_t total = h->total_genes * n_samples;
     GBRS_HIP_CHECK(hipEventRecord(h->ev[0], h->stream));

@@ -55,8 +55,12 @@ class DiplotypeHMM:
         except Exception:
             pass
 
-    def set_expression(self, expr, avecs, has_avec, expr_threshold=1.5, sigma=0.12):
-        """expr[c] [n_samples, n_c, H] (or [n_c, H]); avecs[c] [n_c, H, H]; has_avec[c] bool [n_c]."""
+    def set_expression(self, expr, avecs=None, has_avec=None, expr_threshold=1.5, sigma=0.12):
+        """expr[c] [n_samples, n_c, H] (or [n_c, H]); avecs[c] [n_c, H, H]; has_avec[c] bool [n_c].
+        avecs / has_avec are sample independent and stay on the device once given: pass them with the
+        first sample (or batch) and leave them out afterwards."""
+        if (avecs is None) != (has_avec is None):
+            raise ValueError('avecs and has_avec go together')
         ex, av, ha = [], [], []
         ns = None
         for c, n in enumerate(self.n_genes):
@@ -68,15 +72,16 @@ class DiplotypeHMM:
             ns = e.shape[0] if ns is None else ns
             if e.shape[0] != ns:
                 raise ValueError('inconsistent number of samples')
-            ex.append(np.ascontiguousarray(e))
-            a = np.ascontiguousarray(avecs[c], dtype=np.float64)
-            if a.shape != (n, self.H, self.H):
-                raise ValueError(f'avecs[{c}] has shape {a.shape}')
-            av.append(a)
-            ha.append(np.ascontiguousarray(has_avec[c], dtype=np.uint8))
+            ex.append(e)
+            if avecs is not None:
+                a = np.ascontiguousarray(avecs[c], dtype=np.float64)
+                if a.shape != (n, self.H, self.H):
+                    raise ValueError(f'avecs[{c}] has shape {a.shape}')
+                av.append(a)
+                ha.append(np.ascontiguousarray(has_avec[c], dtype=np.uint8))
         _lib.check(_lib.load().gbrs_hmm_set_expression(
-            self._h, ns, _lib.ptr_table(ex), _lib.ptr_table(av), _lib.ptr_table(ha),
-            float(expr_threshold), float(sigma)))
+            self._h, ns, _lib.ptr_table(ex), _lib.ptr_table(av) if av else None,
+            _lib.ptr_table(ha) if ha else None, float(expr_threshold), float(sigma)))
         self.n_samples = ns
 
     def set_eprob(self, eprob):

@@ -197,8 +197,39 @@ def diplotype_names(hap_names):
     return [a + b for a, b in combinations_with_replacement(hap_names, 2)]
 
 
+def _recombination_tables(rng, H, nt, structural_zeros=True):
+    """DO-shaped log transition tables [nt, S, S] (T[i][to, from]): between neighbouring genes each of the
+    two chromosomes of a diplotype keeps its founder with probability 1 - r and switches to one of the
+    other H - 1 founders with probability r, r log-uniform over 1e-15 .. 1e-2 per interval (gene-dense
+    stretches are near-deterministic, a few intervals recombine freely).  So a table holds entries from
+    ~1 down to r^2 / (H-1)^2 ~ 1e-32, and - when `structural_zeros` - every fourth interval forbids double
+    switches outright (probability 0, log = -inf), as a table built by thresholding would."""
+    S = H * (H + 1) // 2
+    pairs = list(combinations_with_replacement(range(H), 2))
+    # number of founder changes between unordered pairs: best matching of the two chromosomes
+    change = np.zeros((S, S), dtype=np.int64)
+    for j, (a, b) in enumerate(pairs):
+        for k, (c, d) in enumerate(pairs):
+            change[j, k] = min((a != c) + (b != d), (a != d) + (b != c))
+    r = 10.0 ** rng.uniform(-15.0, -2.0, size=nt)
+    T = np.empty((nt, S, S))
+    for i in range(nt):
+        q = r[i] / (H - 1)
+        P = np.where(change == 0, (1.0 - r[i]) ** 2, np.where(change == 1, q * (1.0 - r[i]), q * q))
+        P = P * (1.0 + 0.05 * rng.random((S, S)))          # break the exact symmetry of the model
+        if structural_zeros and i % 4 == 1:
+            P = np.where(change == 2, 0.0, P)
+        T[i] = P / P.sum(axis=0, keepdims=True)            # column-stochastic: sum over `to`
+    with np.errstate(divide="ignore"):
+        return np.log(T)
+
+
 def make_hmm_problem(H=8, genes_per_chrom=None, chroms=None, seed=SEED_HMM,
-                     tprob_len_minus_one=False) -> HmmProblem:
+                     tprob_len_minus_one=False, style="benign", expressed_fraction=0.5) -> HmmProblem:
+    """style "benign": SURVEY 8d's tables (eye + 0.01 U, log entries -5 .. 0).  style "do": recombination-
+    shaped tables with entries down to ~1e-32 and structural zeros (_recombination_tables).
+    expressed_fraction: probability that a haplotype of a gene is expressed at all (low values give many
+    genes under the expression threshold, whose emission is the prior)."""
     rng = np.random.default_rng(seed)
     if genes_per_chrom is None:
         genes_per_chrom = MOUSE_GENES
@@ -213,10 +244,13 @@ def make_hmm_problem(H=8, genes_per_chrom=None, chroms=None, seed=SEED_HMM,
         gno += n
         gene_ids[c] = ids
         nt = n - 1 if tprob_len_minus_one else n
-        T = np.eye(S)[None, :, :] + 0.01 * rng.random((nt, S, S))
-        T /= T.sum(axis=1, keepdims=True)          # column-stochastic: sum over `to`
-        tprob[c] = np.log(T)
-        e = rng.gamma(1.0, 5.0, size=(n, H)) * (rng.random((n, H)) < 0.5)
+        if style == "do":
+            tprob[c] = _recombination_tables(rng, H, nt)
+        else:
+            T = np.eye(S)[None, :, :] + 0.01 * rng.random((nt, S, S))
+            T /= T.sum(axis=1, keepdims=True)          # column-stochastic: sum over `to`
+            tprob[c] = np.log(T)
+        e = rng.gamma(1.0, 5.0, size=(n, H)) * (rng.random((n, H)) < expressed_fraction)
         has_avec = rng.random(n) < 0.7
         for i, g in enumerate(ids):
             expr[g] = e[i]

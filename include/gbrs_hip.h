@@ -232,6 +232,9 @@ int gbrs_hmm_create(int num_haps, int n_chrom, const int32_t *n_genes, const int
  *   expr[c]     double[n_samples][n_genes[c]][H]   gene-level TPM per haplotype
  *   avecs[c]    double[n_genes[c]][H][H]           alignment specificity (row i = haplotype i)
  *   has_avec[c] uint8[n_genes[c]]  0 -> naive avecs with sigma fixed 0.450 (:483-487)
+ * avecs / has_avec are sample independent: they are copied to the device when given and stay resident
+ * on the handle, so later calls (the next sample or batch of samples) may pass NULL for both and move
+ * only the expression rows.
  */
 int gbrs_hmm_set_expression(gbrs_hmm_t *hmm, int n_samples, const double *const *expr,
                             const double *const *avecs, const uint8_t *const *has_avec,

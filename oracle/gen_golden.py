@@ -197,9 +197,11 @@ def em_case(name, R, H, L, seed, with_count, with_len, pseudocount, mask, tol, m
 
 # ----------------------------------------------------------------------------- HMM
 
-def hmm_case(name, H, genes_per_chrom, seed, len_minus_one, extra_fai_chrom=True):
+def hmm_case(name, H, genes_per_chrom, seed, len_minus_one, extra_fai_chrom=True, style="benign",
+             expressed_fraction=0.5):
     prob = synth.make_hmm_problem(H=H, genes_per_chrom=genes_per_chrom, seed=seed,
-                                  tprob_len_minus_one=len_minus_one)
+                                  tprob_len_minus_one=len_minus_one, style=style,
+                                  expressed_fraction=expressed_fraction)
     case_dir = os.path.join(WORK, name)
     os.makedirs(case_dir)
     # ref.fa.fai fixes the chromosome order; one chromosome without tprob exercises the skip
@@ -380,6 +382,15 @@ def main():
             postproc_case("h8", "h8_full", 25)
             postproc_case("h4", "h4_full", 12)
             return
+        if only in (None, "hmm_do"):
+            # recombination-shaped tables: entries down to ~1e-32, structural zeros (-inf), near-deterministic
+            # stretches; the sparse-expression case has most genes under the expression threshold
+            hmm_case("h8_do_full", 8, [70, 45, 30], 35, False, style="do")
+            hmm_case("h8_do_short", 8, [70, 45, 30], 36, True, style="do")
+            hmm_case("h8_do_sparse_expr", 8, [90, 40], 37, False, style="do", expressed_fraction=0.12)
+            hmm_case("h4_do_full", 4, [50, 21], 38, False, style="do")
+        if only == "hmm_do":
+            return
         #        name            R     H  L    seed  count  len    pc   mask   tol   max
         em_case("h2_plain",      1500, 2, 60,  11,   False, False, 0.0, False, 1e-4, 999)
         em_case("h2_len",        1500, 2, 60,  12,   False, True,  0.0, False, 1e-4, 999)
@@ -397,6 +408,8 @@ def main():
         hmm_case("h8_short", 8, [40, 25, 33], 32, True)
         hmm_case("h4_full", 4, [30, 12], 33, False)
         hmm_case("h2_short", 2, [20, 1 + 1], 34, True)
+        if only == "hmm":
+            return
         postproc_case("h8", "h8_full", 25)
         postproc_case("h4", "h4_full", 12)
     finally:

@@ -66,3 +66,22 @@ def _torch_cuda_first(request):
             torch.zeros(1, device="cuda")
     except Exception:
         pass
+
+
+def viterbi_decision_margins(T, delta):
+    """Gap between the best and the second-best candidate at every argmax the reference's backtrace
+    takes (gbrs_utils.py:586-596): the last column of delta, then delta[:, i] + T[i][sid] walking back.
+    A device delta that differs from the reference's by much less than the smallest gap gives the same
+    calls."""
+    S, n = delta.shape
+    v = delta[:, n - 1]
+    top = np.sort(v)[::-1]
+    gaps = [top[0] - top[1]] if S > 1 else []
+    sid = int(v.argmax())
+    for i in reversed(range(min(n, len(T)))):
+        v = delta[:, i] + T[i][sid]
+        top = np.sort(v)[::-1]
+        if S > 1:
+            gaps.append(top[0] - top[1])
+        sid = int(v.argmax())
+    return np.asarray(gaps)

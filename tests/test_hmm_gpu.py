@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from conftest import golden_files, hmm_case_inputs, load_golden
+from conftest import golden_files, hmm_case_inputs, load_golden, viterbi_decision_margins
 
 pytestmark = pytest.mark.gpu
 
@@ -34,6 +34,9 @@ def test_hmm_matches_reference_golden(path):
         np.testing.assert_allclose(r["scaler"], g[f"scaler_{ch}"], rtol=1e-9, atol=1e-9)
         np.testing.assert_allclose(r["beta"], g[f"beta_{ch}"], rtol=1e-9, atol=1e-9)
         np.testing.assert_allclose(r["delta"], g[f"delta_{ch}"], rtol=1e-9, atol=1e-9)
+        # the calls are argmax decisions: the device delta must sit far inside the smallest decision gap
+        gap = viterbi_decision_margins(c["tprob"][ch], g[f"delta_{ch}"]).min()
+        assert np.max(np.abs(r["delta"] - g[f"delta_{ch}"])) < 1e-6 * gap
         # posteriors: north-star 1e-4 relative; held to 1e-8
         np.testing.assert_allclose(r["gamma"], g[f"gamma_{ch}"], rtol=1e-8, atol=1e-300)
         np.testing.assert_allclose(r["gamma"].sum(axis=0), 1.0, rtol=1e-12)
@@ -290,3 +293,26 @@ def test_batched_emission_kernel_matches_the_single_sample_kernel_bit_for_bit():
             np.testing.assert_array_equal(a, b, err_msg=f"sample {s} chromosome {ci}")
     batch.close()
     one.close()
+
+
+def test_specificity_tables_stay_resident():
+    """avecs / has_avec are uploaded once per handle; later samples pass only their expression rows."""
+    g = load_golden([p for p in golden_files("hmm") if p.endswith("hmm_h8_do_full.npz")][0])
+    c = hmm_case_inputs(g)
+    chroms = c["chroms"]
+    hmm = build(c)
+    ex = [c["expr"][ch] for ch in chroms]
+    with pytest.raises(Exception, match="specificity"):
+        hmm.set_expression(ex)
+    rng = np.random.default_rng(3)
+    other = [rng.gamma(1.0, 5.0, size=e.shape) * (rng.random(e.shape) < 0.5) for e in ex]
+    hmm.set_expression(other, [c["avecs"][ch] for ch in chroms], [c["has_avec"][ch] for ch in chroms], 1.5, 0.12)
+    hmm.run()
+    hmm.set_expression(ex, expr_threshold=float(g["expr_threshold"]), sigma=float(g["sigma"]))   # tables reused
+    hmm.run()
+    for ci, ch in enumerate(chroms):
+        r = hmm.get(ci, want=("gamma", "calls", "eprob"))
+        np.testing.assert_array_equal(r["calls"], g[f"calls_{ch}"])
+        np.testing.assert_allclose(r["eprob"], g[f"eprob_{ch}"], rtol=1e-10, atol=1e-10)
+        np.testing.assert_allclose(r["gamma"], g[f"gamma_{ch}"], rtol=1e-8, atol=1e-300)
+    hmm.close()

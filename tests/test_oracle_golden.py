@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from conftest import em_case_inputs, golden_files, hmm_case_inputs, load_golden
+from conftest import em_case_inputs, golden_files, hmm_case_inputs, load_golden, viterbi_decision_margins
 from oracle import hmm_oracle
 from oracle.em_oracle import EMOracle, tpm_report_values
 
@@ -72,3 +72,15 @@ def test_hmm_oracle_matches_reference_outputs(path):
             assert len(T) == n - 1 and calls[-1] == -1 and len(states) == n
         else:
             assert len(T) == n and (calls >= 0).all() and len(states) == n + 1
+
+
+@pytest.mark.parametrize("path", golden_files("hmm"), ids=lambda p: p.split("/")[-1][:-4])
+def test_viterbi_calls_are_decided_by_a_wide_margin(path):
+    """The genotype calls are argmax decisions over delta + T.  On every golden the closest decision is
+    won by more than 1e-3 log units, nine orders of magnitude above the 1e-12-level differences between a
+    device-computed delta and the reference's (tests/test_hmm_gpu.py measures those): that is what
+    "bit-exact calls" rests on, next to the tests that compare the calls themselves."""
+    g = load_golden(path)
+    c = hmm_case_inputs(g)
+    gaps = np.concatenate([viterbi_decision_margins(c["tprob"][ch], g[f"delta_{ch}"]) for ch in c["chroms"]])
+    assert gaps.min() > 1e-3, gaps.min()
