@@ -79,10 +79,30 @@ def build_parser():
     return ap
 
 
+def _write_stage_times(stages, error):
+    """GBRS_STAGE_TIMES=<path> (measurement aid, scripts/e2e_bench.py): the wall-clock seconds of the
+    driver's stages as JSON; with GBRS_T0=<time.time() of the launcher> also the start-up time up to
+    main()."""
+    path = os.getenv('GBRS_STAGE_TIMES')
+    if not path:
+        return
+    import json
+    if error is not None:
+        stages['error'] = f'{type(error).__name__}: {error}'
+    with open(path, 'w') as fh:
+        json.dump(stages, fh)
+
+
 def main(argv=None) -> int:
+    import time
+    t_main = time.time()
+    stages = {}
+    if os.getenv('GBRS_T0'):
+        stages['startup'] = t_main - float(os.environ['GBRS_T0'])
     args = build_parser().parse_args(argv)
     logger = configure_logging(args.verbose)
     logger.debug(args.command)
+    failure = None
     # as in the reference, failures are logged and the exit code stays 0 (commands.py:146-150)
     try:
         if args.command == 'quantify':
@@ -95,7 +115,7 @@ def main(argv=None) -> int:
                      max_iters=args.max_iters, tolerance=args.tolerance,
                      report_alignment_counts=args.report_alignment_counts,
                      report_posterior=args.report_posterior, device=args.device,
-                     merge_identical_rows=args.merge_identical_rows)
+                     merge_identical_rows=args.merge_identical_rows, stage_times=stages)
         elif args.command == 'compress':
             from .compress import compress
             files = [f for x in args.emase_files for f in x.split(',')]
@@ -114,12 +134,15 @@ def main(argv=None) -> int:
             reconstruct(expression_file=args.expression_file, tprob_file=args.tprob_file,
                         avec_file=args.avec_file, gpos_file=args.gpos_file,
                         expr_threshold=args.expr_threshold, sigma=args.sigma, outbase=args.outbase,
-                        device=args.device)
+                        device=args.device, stage_times=stages)
     except Exception as e:   # noqa: BLE001 - mirror of the reference's catch-all
+        failure = e
         if logger.level == logging.DEBUG:
             logger.exception(e)
         else:
             logger.error(e)
+    stages['main'] = time.time() - t_main
+    _write_stage_times(stages, failure)
     return 0
 
 

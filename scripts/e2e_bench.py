@@ -1,0 +1,254 @@
+#!/usr/bin/env python3
+"""End-to-end wall clock of `gbrs quantify` + `gbrs reconstruct` (file in -> reports out), the quantity
+BASELINE.json's ">= 50x" is stated on (gbrs/emase_utils.py:180-332, gbrs/gbrs_utils.py:382-609).
+
+  1. builds the BASELINE configs[1] sample with the bench generator and writes it as an EMASE file
+     (`.h5` through libhdf5 and/or the `.npz` mirror), with its group and length files;
+  2. runs `python -m gbrs_amd quantify ...` and `python -m gbrs_amd reconstruct ...` as fresh child
+     processes (interpreter start, imports and HIP initialisation are inside the measured wall clock) and
+     collects the per-stage times the drivers record (GBRS_STAGE_TIMES);
+  3. runs oracle/e2e_oracle.py (the numpy restatement of the reference workflow, one core) on a row
+     subsample of the same sample and scales its row-dependent stages linearly to the full size.
+
+Prints one JSON object.  Needs an MI355X.  Usage:
+    python scripts/e2e_bench.py [--rows N] [--format h5|npz|both] [--cpu-rows M] [--workdir DIR] [--keep]
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def write_support_files(workdir, L, H, gene_starts, eff_len_row):
+    import numpy as np
+    lname = [f"T{l:07d}" for l in range(L)]
+    hname = [chr(65 + h) for h in range(H)]
+    starts = list(gene_starts) + [L]
+    gname = [f"G{g:07d}" for g in range(len(gene_starts))]
+    grp = os.path.join(workdir, "ref.gene2transcripts.tsv")
+    with open(grp, "w") as fh:
+        for g in range(len(gene_starts)):
+            fh.write(gname[g] + "\t" + "\t".join(lname[starts[g]:starts[g + 1]]) + "\n")
+    lens = os.path.join(workdir, "gbrs.hybridized.targets.info")
+    raw = (np.asarray(eff_len_row) + 99).astype(np.int64)       # max(raw - 100 + 1, 1) == eff
+    with open(lens, "w") as fh:
+        for l in range(L):
+            for h in hname:
+                fh.write(f"{lname[l]}_{h}\t{raw[l]}\n")
+    return lname, hname, gname, grp, lens
+
+
+def build_sample(workdir, rows, haps, loci, fmt):
+    """The full-size sample as alignment file(s) + support files.  Returns a dict of paths and sizes."""
+    import numpy as np
+    import torch
+    from gbrs_amd import synth, synth_torch
+    from gbrs_amd.alignment import AlignmentPropertyMatrix
+    t0 = time.perf_counter()
+    prob = synth_torch.make_em_problem_device(rows, haps, loci, synth.SEED_BASE_EM + 1, "cuda:0")
+    ip = [t.cpu().numpy().view(np.uint32) for t in prob["indptr"]]
+    ix = [t.cpu().numpy().view(np.uint32) for t in prob["indices"]]
+    eff = prob["eff_len"].cpu().numpy()
+    gene_starts = prob["gene_starts"]
+    N = prob["N"]
+    del prob
+    torch.cuda.empty_cache()
+    lname, hname, gname, grp, lens = write_support_files(workdir, loci, haps, gene_starts, eff[0])
+    apm = AlignmentPropertyMatrix(shape=(loci, haps, rows), indptr=ip, indices=ix, haplotype_names=hname,
+                                  locus_names=lname)
+    out = dict(group_file=grp, length_file=lens, N=N, genes=gname, files={}, write_s={})
+    if fmt in ("h5", "both"):
+        t1 = time.perf_counter()
+        p = os.path.join(workdir, "sample.h5")
+        apm.save(p)
+        out["files"]["h5"] = p
+        out["write_s"]["h5"] = time.perf_counter() - t1
+    if fmt in ("npz", "both"):
+        t1 = time.perf_counter()
+        p = os.path.join(workdir, "sample.npz")
+        apm.save_npz(p)
+        out["files"]["npz"] = p
+        out["write_s"]["npz"] = time.perf_counter() - t1
+    out["bytes"] = {k: os.path.getsize(v) for k, v in out["files"].items()}
+    out["build_s"] = time.perf_counter() - t0
+    return out, (ip, ix, eff, lname, hname)
+
+
+def write_cpu_subsample(workdir, arrays, rows_sub, loci, haps):
+    """The first rows_sub reads of the sample as an .npz alignment file for the one-core baseline."""
+    import numpy as np
+    from gbrs_amd.alignment import AlignmentPropertyMatrix
+    ip, ix, eff, lname, hname = arrays
+    sip, six = [], []
+    for h in range(haps):
+        keep = ix[h] < rows_sub
+        col = np.repeat(np.arange(loci, dtype=np.int64), np.diff(ip[h].astype(np.int64)))[keep]
+        six.append(ix[h][keep])
+        sip.append(np.searchsorted(col, np.arange(loci + 1)).astype(np.uint32))
+    apm = AlignmentPropertyMatrix(shape=(loci, haps, rows_sub), indptr=sip, indices=six, haplotype_names=hname,
+                                  locus_names=lname)
+    p = os.path.join(workdir, "sub.npz")
+    apm.save_npz(p)
+    return p, int(sum(len(x) for x in six))
+
+
+def write_reconstruct_inputs(workdir, genes_tpm):
+    """ref.fa.fai, gene order, transition tables and specificity blocks for the genes of a genes.tpm file
+    (SURVEY 8d's HMM recipe: 20 chromosomes in mouse proportions, `eye + 0.01 U` tables of DO length)."""
+    import numpy as np
+    from gbrs_amd import synth
+    with open(genes_tpm) as fh:
+        H = len(fh.readline().rstrip().split("\t")) - 2
+        ids = [line.split("\t", 1)[0] for line in fh]
+    S = H * (H + 1) // 2
+    frac = np.cumsum(synth.MOUSE_GENES) / float(sum(synth.MOUSE_GENES))
+    cuts = [0] + [int(round(f * len(ids))) for f in frac]
+    rng = np.random.default_rng(synth.SEED_HMM)
+    tprob, gpos, avecs = {}, {}, {}
+    with open(os.path.join(workdir, "ref.fa.fai"), "w") as fh:
+        for c in synth.MOUSE_CHROMS:
+            fh.write(f"{c}\t100000000\t0\t60\t61\n")
+    for k, c in enumerate(synth.MOUSE_CHROMS):
+        g = ids[cuts[k]:cuts[k + 1]]
+        n = len(g)
+        T = np.eye(S)[None, :, :] + 0.01 * rng.random((n, S, S))
+        T /= T.sum(axis=1, keepdims=True)
+        tprob[c] = np.log(T)
+        arr = np.zeros(n, dtype=[("f0", "U24"), ("f1", "i8")])
+        arr["f0"] = g
+        arr["f1"] = np.arange(n) * 1000
+        gpos[c] = arr
+        has = rng.random(n) < 0.7
+        for i in np.flatnonzero(has):
+            a = np.eye(H) + 0.05 * rng.random((H, H))
+            avecs[g[i]] = a / a.sum(axis=1, keepdims=True)
+    paths = dict(tprob=os.path.join(workdir, "tranprob.npz"), avecs=os.path.join(workdir, "avecs.npz"),
+                 gpos=os.path.join(workdir, "ref.gene_pos.ordered.npz"), fai=os.path.join(workdir, "ref.fa.fai"))
+    np.savez(paths["tprob"], **tprob)
+    np.savez(paths["avecs"], **avecs)
+    np.savez(paths["gpos"], **gpos)
+    return paths, len(ids)
+
+
+def run_cli(argv, workdir, tag):
+    """One `gbrs` subcommand as a fresh process; returns (wall seconds, stage dict)."""
+    stages = os.path.join(workdir, f"stages_{tag}.json")
+    env = dict(os.environ, GBRS_DATA=workdir, GBRS_STAGE_TIMES=stages, PYTHONPATH=ROOT)
+    t0 = time.time()
+    env["GBRS_T0"] = repr(t0)
+    r = subprocess.run([sys.executable, "-m", "gbrs_amd"] + argv, env=env, cwd=workdir, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True)
+    wall = time.time() - t0
+    if r.returncode != 0 or not os.path.exists(stages):
+        raise RuntimeError(f"gbrs {argv[0]} failed (rc {r.returncode}): {r.stderr[-2000:]}")
+    with open(stages) as fh:
+        st = json.load(fh)
+    if st.get("error"):
+        raise RuntimeError(f"gbrs {argv[0]} logged an error: {st['error']}")
+    return wall, st
+
+
+def run_oracle(argv):
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1", PYTHONPATH=ROOT)
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "e2e_oracle.py")] + argv, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    wall = time.time() - t0
+    if r.returncode != 0:
+        raise RuntimeError(f"oracle {argv[0]} failed: {r.stderr[-2000:]}")
+    return wall, json.loads(r.stdout.strip().split("\n")[-1])
+
+
+def measure(rows=40_000_000, haps=8, loci=120_000, fmt="h5", cpu_rows=2_000_000, workdir=None, keep=False,
+            repeats=2, with_cpu=True):
+    own = workdir is None
+    workdir = tempfile.mkdtemp(prefix="gbrs_e2e_") if own else workdir
+    os.makedirs(workdir, exist_ok=True)
+    res = dict(workload=f"configs[1]/[2]: R={rows} reads x H={haps} x L={loci} isoforms from file, quantify "
+                        "(Model 4, tol 1e-4, 4 reports) then reconstruct on its genes.tpm (20 chromosomes)")
+    try:
+        sample, arrays = build_sample(workdir, rows, haps, loci, fmt)
+        res["sample"] = dict(entries=sample["N"], file_bytes=sample["bytes"], write_s=sample["write_s"])
+        res["quantify"] = {}
+        for kind, path in sample["files"].items():
+            runs = []
+            for _ in range(repeats):
+                wall, st = run_cli(["quantify", "-i", path, "-g", sample["group_file"], "-L", sample["length_file"],
+                                    "-o", os.path.join(workdir, f"out_{kind}")], workdir, f"q_{kind}")
+                runs.append(dict(wall_s=wall, stages=st))
+            best = min(runs, key=lambda r: r["wall_s"])
+            res["quantify"][kind] = dict(wall_s=best["wall_s"], stages=best["stages"],
+                                         all_wall_s=[r["wall_s"] for r in runs])
+        first = next(iter(sample["files"]))
+        genes_tpm = os.path.join(workdir, f"out_{first}.multiway.genes.tpm")
+        rec, n_genes = write_reconstruct_inputs(workdir, genes_tpm)
+        runs = []
+        for _ in range(repeats):
+            wall, st = run_cli(["reconstruct", "-e", genes_tpm, "-t", rec["tprob"], "-x", rec["avecs"], "-g", rec["gpos"],
+                                "-o", os.path.join(workdir, "rec")], workdir, "r")
+            runs.append(dict(wall_s=wall, stages=st))
+        best = min(runs, key=lambda r: r["wall_s"])
+        res["reconstruct"] = dict(wall_s=best["wall_s"], stages=best["stages"], genes=n_genes,
+                                  all_wall_s=[r["wall_s"] for r in runs])
+        qbest = min(v["wall_s"] for v in res["quantify"].values())
+        res["total_wall_s"] = qbest + res["reconstruct"]["wall_s"]
+        if with_cpu:
+            sub, n_sub = write_cpu_subsample(workdir, arrays, min(cpu_rows, rows), loci, haps)
+            del arrays
+            wq, tq = run_oracle(["quantify", sub, sample["group_file"], sample["length_file"],
+                                 os.path.join(workdir, "cpu")])
+            wr, tr = run_oracle(["reconstruct", os.path.join(workdir, "cpu.multiway.genes.tpm"), rec["tprob"],
+                                 rec["avecs"], rec["gpos"], rec["fai"], os.path.join(workdir, "cpu_rec")])
+            scale = rows / float(min(cpu_rows, rows))
+            # row-dependent stages scale with the number of reads; file parsing of the L-sized tables,
+            # report writing and the whole of reconstruct do not
+            per_iter = tq["em_run"] / max(tq["em_iterations"], 1)
+            iters_full = res["quantify"][first]["stages"].get("em_iterations", tq["em_iterations"])
+            est_q = (tq["load"] * scale) + (tq["em_setup"] * scale) + per_iter * scale * iters_full + tq["reports"] \
+                + (wq - tq["total_in_process"])
+            res["cpu_baseline"] = dict(
+                kind="port", cores=1, host_cores=os.cpu_count(),
+                sample=f"oracle/e2e_oracle.py on the first {min(cpu_rows, rows)} reads ({n_sub} entries) of the same "
+                       f"sample as an .npz file; load, EM set-up and per-iteration time scaled x{scale:g} linearly in "
+                       f"reads, {iters_full} iterations (the full sample's count), reports and process start unscaled; "
+                       "reconstruct run whole",
+                quantify_measured=dict(wall_s=wq, stages=tq), reconstruct_measured=dict(wall_s=wr, stages=tr),
+                quantify_scaled_s=est_q, reconstruct_s=wr, total_s=est_q + wr)
+            res["speedup_vs_cpu"] = dict(quantify=est_q / qbest, reconstruct=wr / res["reconstruct"]["wall_s"],
+                                         total=(est_q + wr) / res["total_wall_s"])
+    finally:
+        if own and not keep:
+            shutil.rmtree(workdir, ignore_errors=True)
+    return res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--rows", type=int, default=40_000_000)
+    ap.add_argument("--haps", type=int, default=8)
+    ap.add_argument("--loci", type=int, default=120_000)
+    ap.add_argument("--format", default="h5", choices=["h5", "npz", "both"])
+    ap.add_argument("--cpu-rows", type=int, default=2_000_000)
+    ap.add_argument("--workdir", default=None)
+    ap.add_argument("--keep", action="store_true")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--repeats", type=int, default=2)
+    a = ap.parse_args()
+    import __graft_entry__
+    __graft_entry__.build()
+    out = measure(a.rows, a.haps, a.loci, a.format, a.cpu_rows, a.workdir, a.keep, a.repeats, not a.no_cpu)
+    print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()
