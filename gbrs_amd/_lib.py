@@ -23,6 +23,7 @@ EXPORTS = [
     "gbrs_hmm_create", "gbrs_hmm_set_expression", "gbrs_hmm_set_eprob", "gbrs_hmm_run",
     "gbrs_hmm_get", "gbrs_hmm_info", "gbrs_hmm_destroy", "gbrs_interpolate", "gbrs_genoprob_dosage",
     "gbrs_compress_create", "gbrs_compress_get", "gbrs_compress_destroy",
+    "gbrs_format_double", "gbrs_write_locus_table", "gbrs_parse_length_table",
 ]
 
 GBRS_OK = 0
@@ -120,6 +121,9 @@ def load():
         "gbrs_compress_create": [u64, u32, u32, pp, pp, vp, i32, pp, C.POINTER(u64), vp],
         "gbrs_compress_get": [vp, pp, pp, vp],
         "gbrs_compress_destroy": [vp],
+        "gbrs_format_double": [dbl, C.c_char_p],
+        "gbrs_parse_length_table": [C.c_char_p, i64, C.c_char_p, vp, i64, C.c_char_p, vp, i32, dbl, vp],
+        "gbrs_write_locus_table": [C.c_char_p, C.c_char_p, vp, i64, i32, i64, i64, vp, C.c_char_p, vp, C.c_char_p, vp, vp],
     }
     for name, args in sigs.items():
         fn = getattr(lib, name)

@@ -10,7 +10,11 @@ never materialises them.
 File formats
   * ``.h5``  EMASE/PyTables layout (gbrs_amd.emase_h5, needs libhdf5)
   * ``.npz`` mirror of the same fields for machines without libhdf5:
-        shape=(L,H,R)  hname  lname  [count]  indptr{h}  indices{h}
+        shape=(L,H,R)  hname  lname  [count]  indptr{h}  indices{h}  [values{h}]
+
+``values`` (normally None) holds stored alignment values other than 1, which only legacy files and
+files saved with ``incidence_only=False`` carry; they set the starting point of the EM
+(EMfactory.prepare normalises them per read, EMfactory.py:95-98) and nothing else.
 """
 from __future__ import annotations
 
@@ -19,7 +23,7 @@ import numpy as np
 
 class AlignmentPropertyMatrix:
     def __init__(self, shape=None, indptr=None, indices=None, count=None, haplotype_names=None,
-                 locus_names=None, grpfile=None, h5file=None, npzfile=None):
+                 locus_names=None, grpfile=None, h5file=None, npzfile=None, values=None):
         self.hname = None
         self.lname = None
         self.lid = None
@@ -27,6 +31,7 @@ class AlignmentPropertyMatrix:
         self.groups = None
         self.num_groups = 0
         self.count = None
+        self.values = None          # per-haplotype float64 arrays aligned with indices, or None = all ones
         if h5file is not None:
             from . import emase_h5
             emase_h5.load_into(self, h5file)
@@ -44,6 +49,8 @@ class AlignmentPropertyMatrix:
             self.indices = [np.ascontiguousarray(i, dtype=np.uint32) for i in indices]
             if count is not None:
                 self.count = np.ascontiguousarray(count, dtype=np.float64)
+            if values is not None:
+                self.values = [np.ascontiguousarray(v, dtype=np.float64) for v in values]
             if haplotype_names is not None:
                 if len(haplotype_names) != H:
                     raise RuntimeError('The number of names does not match to the matrix shape.')
@@ -66,6 +73,8 @@ class AlignmentPropertyMatrix:
                 raise RuntimeError(f'Malformed CSC arrays for haplotype {h}.')
         if self.count is not None and len(self.count) != R:
             raise RuntimeError('The length of count does not match to the matrix shape.')
+        if self.values is not None and [len(v) for v in self.values] != [len(i) for i in self.indices]:
+            raise RuntimeError('The stored values do not match the index arrays.')
         if self.lname is not None:
             self.lid = dict(zip(self.lname, np.arange(self.num_loci)))
         self.finalized = True
@@ -87,13 +96,20 @@ class AlignmentPropertyMatrix:
     def group_csr(self):
         """(group_ptr int64[G+1], members int64[...]) with members ascending and unique per group:
         the column structure of the reference's grp_conv_mat (EMfactory.py:41-47)."""
-        ptr = [0]
-        mem = []
-        for g in self.groups:
-            m = sorted(set(int(x) for x in g))
-            mem.extend(m)
-            ptr.append(len(mem))
-        return np.asarray(ptr, dtype=np.int64), np.asarray(mem, dtype=np.int64)
+        cached = getattr(self, '_group_csr', None)
+        if cached is not None and cached[0] is self.groups:
+            return cached[1]
+        sizes = np.fromiter(map(len, self.groups), dtype=np.int64, count=len(self.groups))
+        gene = np.repeat(np.arange(len(self.groups), dtype=np.int64), sizes)
+        mem = np.fromiter((x for g in self.groups for x in g), dtype=np.int64, count=int(sizes.sum()))
+        order = np.lexsort((mem, gene))                      # ascending members inside every group ...
+        gene, mem = gene[order], mem[order]
+        if len(mem):
+            keep = np.concatenate(([True], (gene[1:] != gene[:-1]) | (mem[1:] != mem[:-1])))   # ... without repeats
+            gene, mem = gene[keep], mem[keep]
+        ptr = np.searchsorted(gene, np.arange(len(self.groups) + 1)).astype(np.int64)
+        self._group_csr = (self.groups, (ptr, np.ascontiguousarray(mem)))
+        return self._group_csr[1]
 
     # ---- structure edits -------------------------------------------------------------------
     def mask_haplotype_loci(self, gtmask):
@@ -104,7 +120,10 @@ class AlignmentPropertyMatrix:
         for h in range(H):
             width = np.diff(self.indptr[h].astype(np.int64))
             keep_col = gtmask[h, :] != 0.0
-            self.indices[h] = np.ascontiguousarray(self.indices[h][np.repeat(keep_col, width)])
+            keep = np.repeat(keep_col, width)
+            self.indices[h] = np.ascontiguousarray(self.indices[h][keep])
+            if self.values is not None:
+                self.values[h] = np.ascontiguousarray(self.values[h][keep])
             self.indptr[h] = np.concatenate(([0], np.cumsum(np.where(keep_col, width, 0)))).astype(np.uint32)
 
     @property
@@ -113,17 +132,27 @@ class AlignmentPropertyMatrix:
 
     # ---- npz mirror ------------------------------------------------------------------------
     def _load_npz(self, path):
-        with np.load(path, allow_pickle=False) as z:
+        from .npzfast import FastNpz
+        z = FastNpz(path)                                   # members inflated in parallel (zlib drops the GIL)
+        try:
             self.shape = tuple(int(x) for x in z['shape'])
             L, H, R = self.shape
-            self.indptr = [np.ascontiguousarray(z[f'indptr{h}'], dtype=np.uint32) for h in range(H)]
-            self.indices = [np.ascontiguousarray(z[f'indices{h}'], dtype=np.uint32) for h in range(H)]
-            if 'count' in z.files:
-                self.count = np.ascontiguousarray(z['count'], dtype=np.float64)
-            if 'hname' in z.files:
-                self.hname = [str(x) for x in z['hname']]
-            if 'lname' in z.files:
-                self.lname = [str(x) for x in z['lname']]
+            want = [f'indptr{h}' for h in range(H)] + [f'indices{h}' for h in range(H)]
+            want += ['count'] if 'count' in z else []
+            want += [f'values{h}' for h in range(H)] if 'values0' in z else []
+            got = dict(zip(want, z.read_many(want)))
+            self.indptr = [np.ascontiguousarray(got[f'indptr{h}'], dtype=np.uint32) for h in range(H)]
+            self.indices = [np.ascontiguousarray(got[f'indices{h}'], dtype=np.uint32) for h in range(H)]
+            if 'count' in got:
+                self.count = np.ascontiguousarray(got['count'], dtype=np.float64)
+            if 'values0' in got:
+                self.values = [np.ascontiguousarray(got[f'values{h}'], dtype=np.float64) for h in range(H)]
+            if 'hname' in z:
+                self.hname = z['hname'].astype('U').tolist()
+            if 'lname' in z:
+                self.lname = z['lname'].astype('U').tolist()
+        finally:
+            z.close()
 
     def save_npz(self, path):
         out = dict(shape=np.asarray(self.shape, dtype=np.int64))
@@ -132,6 +161,9 @@ class AlignmentPropertyMatrix:
             out[f'indices{h}'] = self.indices[h]
         if self.count is not None:
             out['count'] = self.count
+        if self.values is not None:
+            for h in range(self.num_haplotypes):
+                out[f'values{h}'] = self.values[h]
         if self.hname is not None:
             out['hname'] = np.array(self.hname)
         if self.lname is not None:

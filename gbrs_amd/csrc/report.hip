@@ -1,0 +1,204 @@
+// Host-side text output of the quantify reports (no device code): `locus <haplotypes> total [notes]`
+// tables with every number in its shortest round-trip form, i.e. exactly what str(numpy.float64) /
+// repr(float) print in the reference's writers (emase/EMfactory.py:289-380).  At 120k isoforms + 48k
+// genes the four reports hold 1.5 M numbers; formatting them in the interpreter took ~1 s per sample,
+// as long as everything else of `gbrs quantify` on the device path together.
+#include "common.h"
+
+#include <algorithm>
+#include <charconv>
+#include <cmath>
+#include <cstdio>
+#include <string_view>
+#include <thread>
+#include <unordered_map>
+
+namespace gbrs {
+
+// repr(float): shortest digits that round-trip; fixed notation for 1e-4 <= |x| < 1e16, else d[.ddd]e+XX
+// with at least two exponent digits; a ".0" is appended to integral fixed values.  Returns the length.
+static int format_repr(double v, char *out) {
+    if (std::isnan(v)) { std::memcpy(out, "nan", 3); return 3; }
+    if (std::isinf(v)) {
+        if (v < 0) { std::memcpy(out, "-inf", 4); return 4; }
+        std::memcpy(out, "inf", 3);
+        return 3;
+    }
+    char *p = out;
+    if (std::signbit(v)) { *p++ = '-'; v = -v; }
+    if (v == 0.0) { std::memcpy(p, "0.0", 3); return (int)(p - out) + 3; }
+    char sci[40];
+    const auto res = std::to_chars(sci, sci + sizeof(sci), v, std::chars_format::scientific);
+    // sci = d[.ddd]e[+-]XX[X]
+    char digits[24];
+    int nd = 0;
+    const char *q = sci;
+    for (; q < res.ptr && *q != 'e'; ++q)
+        if (*q != '.') digits[nd++] = *q;
+    ++q;                                   // past 'e'
+    const bool eneg = *q == '-';
+    if (*q == '+' || *q == '-') ++q;
+    int e10 = 0;
+    for (; q < res.ptr; ++q) e10 = e10 * 10 + (*q - '0');
+    if (eneg) e10 = -e10;
+    const int decpt = e10 + 1;             // value = 0.d1d2... x 10^decpt
+    if (decpt <= -4 || decpt > 16) {
+        *p++ = digits[0];
+        if (nd > 1) {
+            *p++ = '.';
+            std::memcpy(p, digits + 1, nd - 1);
+            p += nd - 1;
+        }
+        *p++ = 'e';
+        int e = decpt - 1;
+        *p++ = e < 0 ? '-' : '+';
+        if (e < 0) e = -e;
+        if (e >= 100) { *p++ = (char)('0' + e / 100); e %= 100; *p++ = (char)('0' + e / 10); *p++ = (char)('0' + e % 10); }
+        else { *p++ = (char)('0' + e / 10); *p++ = (char)('0' + e % 10); }
+    } else if (decpt <= 0) {
+        *p++ = '0'; *p++ = '.';
+        for (int k = 0; k < -decpt; ++k) *p++ = '0';
+        std::memcpy(p, digits, nd);
+        p += nd;
+    } else if (decpt >= nd) {
+        std::memcpy(p, digits, nd);
+        p += nd;
+        for (int k = nd; k < decpt; ++k) *p++ = '0';
+        *p++ = '.'; *p++ = '0';
+    } else {
+        std::memcpy(p, digits, decpt);
+        p += decpt;
+        *p++ = '.';
+        std::memcpy(p, digits + decpt, nd - decpt);
+        p += nd - decpt;
+    }
+    return (int)(p - out);
+}
+
+}  // namespace gbrs
+
+extern "C" {
+
+int gbrs_format_double(double v, char *out32) {
+    if (!out32) return gbrs::fail(GBRS_ERR_INVALID, "out is NULL");
+    const int n = gbrs::format_repr(v, out32);
+    out32[n] = '\0';
+    return n;
+}
+
+int gbrs_write_locus_table(const char *path, const char *header_line, const double *values, int64_t n_rows,
+                           int32_t n_cols, int64_t row_stride, int64_t col_stride, const double *totals,
+                           const char *names, const int64_t *name_off, const char *notes,
+                           const int64_t *note_off, const int64_t *order) {
+    using gbrs::fail;
+    if (!path || !header_line || ((!values || !totals) && n_rows > 0) || !names || !name_off || n_rows < 0 ||
+        n_cols < 0 || ((notes == nullptr) != (note_off == nullptr)))
+        return fail(GBRS_ERR_INVALID, "bad argument");
+    for (int64_t k = 0; k < n_rows && order; ++k)
+        if (order[k] < 0 || order[k] >= n_rows)
+            return fail(GBRS_ERR_INVALID, "row order entry %lld out of range", (long long)order[k]);
+    // rows are formatted in contiguous slices on a few threads (std::to_chars costs ~0.2 us a number),
+    // then written out in order
+    unsigned nt = std::thread::hardware_concurrency();
+    if (const char *e = std::getenv("GBRS_IO_THREADS"); e && std::atoi(e) > 0) nt = (unsigned)std::atoi(e);
+    nt = std::max(1u, std::min({nt, 16u, (unsigned)(n_rows / 4096 + 1)}));
+    std::vector<std::vector<char>> parts(nt);
+    auto work = [&](unsigned t) {
+        const int64_t k0 = n_rows * t / nt, k1 = n_rows * (t + 1) / nt;
+        std::vector<char> &buf = parts[t];
+        buf.reserve((size_t)(k1 - k0) * (16 + ((size_t)n_cols + 1) * 20));
+        char num[40];
+        for (int64_t k = k0; k < k1; ++k) {
+            const int64_t r = order ? order[k] : k;
+            buf.insert(buf.end(), names + name_off[r], names + name_off[r + 1]);
+            for (int c = 0; c <= n_cols; ++c) {
+                buf.push_back('\t');
+                const double x = c < n_cols ? values[r * row_stride + c * col_stride] : totals[r];
+                const int n = gbrs::format_repr(x, num);
+                buf.insert(buf.end(), num, num + n);
+            }
+            if (notes) {
+                buf.push_back('\t');
+                buf.insert(buf.end(), notes + note_off[r], notes + note_off[r + 1]);
+            }
+            buf.push_back('\n');
+        }
+    };
+    {
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < nt; ++t) th.emplace_back(work, t);
+        work(0);
+        for (auto &x : th) x.join();
+    }
+    FILE *fh = std::fopen(path, "w");
+    if (!fh) return fail(GBRS_ERR_INVALID, "cannot open %s for writing", path);
+    bool ok = std::fwrite(header_line, 1, std::strlen(header_line), fh) == std::strlen(header_line);
+    for (unsigned t = 0; t < nt && ok; ++t)
+        ok = parts[t].empty() || std::fwrite(parts[t].data(), 1, parts[t].size(), fh) == parts[t].size();
+    if (std::fclose(fh) != 0 || !ok) return fail(GBRS_ERR_INVALID, "write to %s failed", path);
+    return GBRS_OK;
+}
+
+// `<locus>_<haplotype> TAB <length>` table -> effective lengths (EMfactory.py:60-94).  Returns 0 when every
+// line was plain (one underscore in the key, known names, a number from_chars takes whole), 1 when some
+// line needs the interpreter's more permissive parsing / error reporting: the caller then re-reads the
+// file with the line-by-line path, which raises what the reference raises.
+int gbrs_parse_length_table(const char *text, int64_t text_len, const char *names, const int64_t *name_off,
+                            int64_t n_loci, const char *haps, const int64_t *hap_off, int32_t n_haps,
+                            double read_length, double *eff_out) {
+    using gbrs::fail;
+    if (!text || !names || !name_off || !haps || !hap_off || !eff_out || n_loci < 1 || n_haps < 1 || text_len < 0)
+        return fail(GBRS_ERR_INVALID, "bad argument");
+    std::unordered_map<std::string_view, int64_t> locus_id;
+    locus_id.reserve((size_t)n_loci * 2);
+    for (int64_t l = 0; l < n_loci; ++l)
+        locus_id[std::string_view(names + name_off[l], (size_t)(name_off[l + 1] - name_off[l]))] = l;   // later duplicates win, as dict(zip()) does
+    std::vector<std::string_view> hap(n_haps);
+    for (int h = 0; h < n_haps; ++h) hap[h] = std::string_view(haps + hap_off[h], (size_t)(hap_off[h + 1] - hap_off[h]));
+    const char *p = text, *end = text + text_len;
+    std::string_view last_key;
+    int64_t last_l = -1;
+    while (p < end) {
+        const char *eol = (const char *)std::memchr(p, '\n', (size_t)(end - p));
+        const char *next = eol ? eol + 1 : end;
+        const char *le = eol ? eol : end;
+        while (le > p && (le[-1] == '\r' || le[-1] == ' ' || le[-1] == '\t')) --le;      // str.rstrip() on plain lines
+        const char *tab = (const char *)std::memchr(p, '\t', (size_t)(le - p));
+        if (!tab) return 1;
+        const char *num_end = (const char *)std::memchr(tab + 1, '\t', (size_t)(le - tab - 1));
+        if (!num_end) num_end = le;
+        std::string_view key(p, (size_t)(tab - p));
+        int64_t l;
+        int h = 0;
+        if (n_haps > 1) {
+            const size_t us = key.find('_');
+            if (us == std::string_view::npos || key.find('_', us + 1) != std::string_view::npos) return 1;
+            const std::string_view lk = key.substr(0, us);
+            if (lk == last_key) {                               // the haplotypes of a locus are usually adjacent lines
+                l = last_l;
+            } else {
+                const auto it = locus_id.find(lk);
+                if (it == locus_id.end()) return 1;
+                l = last_l = it->second;
+                last_key = lk;
+            }
+            const std::string_view hn = key.substr(us + 1);
+            for (h = n_haps - 1; h >= 0 && hap[h] != hn; --h) {}
+            if (h < 0) return 1;
+        } else {
+            const auto it = locus_id.find(key);
+            if (it == locus_id.end()) return 1;
+            l = it->second;
+        }
+        double len = 0.0;
+        const auto r = std::from_chars(tab + 1, num_end, len);
+        if (r.ec != std::errc() || r.ptr != num_end || num_end == tab + 1) return 1;
+        const double e = len - read_length + 1.0;
+        eff_out[(size_t)h * n_loci + l] = e > 1.0 ? e : 1.0;                 // max(..., 1.0); nan -> 1.0 differs: send it back
+        if (len != len) return 1;
+        p = next;
+    }
+    return 0;
+}
+
+}  // extern "C"

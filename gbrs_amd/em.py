@@ -9,6 +9,7 @@ no CPU fallback.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -220,6 +221,20 @@ def read_length_file(apm, lenfile, read_length=100):
     if H < 1:
         raise RuntimeError('There is something wrong with your emase-format alignment file.')
     eff = np.zeros((H, L))
+    # plain files (every line `<known locus>_<known haplotype> TAB <number>`) are parsed natively; anything
+    # else goes through the line-by-line path below, which raises what the reference raises
+    with open(lenfile, 'rb') as fh:
+        text = fh.read()
+    name_blob, name_off = _blob_cached(apm.lname)
+    hap_blob, hap_off = _blob(apm.hname)
+    st = _lib.load().gbrs_parse_length_table(text, len(text), name_blob, _lib.ptr(name_off), L, hap_blob,
+                                             _lib.ptr(hap_off), H, float(read_length), _lib.ptr(eff))
+    if st == 0:
+        return eff
+    if st < 0:
+        _lib.check(st)
+    del text
+    eff[:] = 0.0
     hap_row = {name: k for k, name in enumerate(apm.hname)}
     with open(lenfile) as fh:
         for line in fh:
@@ -233,26 +248,58 @@ def read_length_file(apm, lenfile, read_length=100):
     return eff
 
 
+def _blob(strings):
+    """(utf-8 bytes of the strings laid end to end, int64 offsets [n + 1])."""
+    enc = [x.encode() for x in strings]
+    off = np.zeros(len(enc) + 1, dtype=np.int64)
+    np.cumsum(np.fromiter(map(len, enc), dtype=np.int64, count=len(enc)), out=off[1:])
+    return b''.join(enc), off
+
+
+_blob_cache = {}
+
+
+def _blob_cached(names):
+    """_blob of a name list, remembered per list object: the isoform (and gene) names are written into
+    two reports each."""
+    key = id(names)
+    hit = _blob_cache.get(key)
+    if hit is None or hit[0] is not names:
+        if len(_blob_cache) > 4:
+            _blob_cache.clear()
+        hit = _blob_cache[key] = (names, _blob([str(x) for x in names]))
+    return hit[1]
+
+
 def write_locus_table(filename, hap_names, row_names, values, reorder='as-is', notes=None):
     """`locus <haplotypes...> total [notes]` table: one line per locus (or gene) with the per-haplotype
     values, their sum and, when `notes` maps names to text, that text.  Numbers are written in their
-    shortest round-trip form, which is what str(numpy.float64) gives in the reference's writers."""
-    values = np.asarray(values)
+    shortest round-trip form, which is what str(numpy.float64) gives in the reference's writers; the
+    text is produced by libgbrs_hip's gbrs_write_locus_table (1.5 M numbers per sample at DO size)."""
+    values = np.asarray(values, dtype=np.float64)
     totals = values.sum(axis=0)
-    order = range(values.shape[1])
+    order = None
     if reorder in ('increasing', 'decreasing'):
         order = np.argsort(totals.ravel())
         if reorder == 'decreasing':
             order = order[::-1]
+        order = np.ascontiguousarray(order, dtype=np.int64)
     elif reorder != 'as-is':
         raise ValueError(f'unknown reorder option: {reorder}')
-    columns = np.vstack((values, totals)).T.tolist()              # python floats: repr == str(np.float64)
-    head = ['locus', *hap_names, 'total'] + (['notes'] if notes is not None else [])
-    with open(filename, 'w') as out:
-        out.write('\t'.join(head) + '\n')
-        for k in order:
-            name = row_names[k]
-            cells = [name, *map(repr, columns[k])]
-            if notes is not None:
-                cells.append(str(notes[name]))
-            out.write('\t'.join(cells) + '\n')
+    if not (values.flags.c_contiguous or values.flags.f_contiguous):
+        values = np.ascontiguousarray(values)
+    totals = np.ascontiguousarray(totals.ravel(), dtype=np.float64)
+    n_haps, n_rows = values.shape
+    item = values.itemsize
+    names = row_names if isinstance(row_names, list) else [str(x) for x in row_names]
+    if len(names) != n_rows:
+        raise RuntimeError('The number of names does not match to the matrix shape.')
+    name_blob, name_off = _blob_cached(names)
+    note_blob = note_off = None
+    if notes is not None:
+        note_blob, note_off = _blob([str(notes[n]) for n in names])
+    head = '\t'.join(['locus', *hap_names, 'total'] + (['notes'] if notes is not None else [])) + '\n'
+    _lib.check(_lib.load().gbrs_write_locus_table(
+        os.fsencode(filename), head.encode(), _lib.ptr(values), n_rows, n_haps, values.strides[1] // item,
+        values.strides[0] // item, _lib.ptr(totals), name_blob, _lib.ptr(name_off), note_blob,
+        _lib.ptr(note_off) if note_off is not None else None, _lib.ptr(order) if order is not None else None))

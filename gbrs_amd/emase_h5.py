@@ -13,8 +13,21 @@ PyTables stores tuple/list attributes as pickled byte strings and scalars native
 PyTables nor h5py exists in this image, so the reader accepts every encoding HDF5 allows for
 these fields (pickled string, integer array, string array, bool/enum/int scalar) and the writer
 emits the PyTables conventions as documented; a file written by real PyTables could not be
-produced here to confirm - the round trip and `h5dump` structure are tested.
-Files without an `mtype` attribute (legacy COO form, Sparse3DMatrix.py:76-78) are rejected.
+produced here to confirm.  What has been verified, and how:
+  * group / dataset names, dtypes, chunking, shuffle + deflate filters: `h5dump -H -p` of this
+    writer's output (tests/test_emase_h5.py);
+  * attribute encodings - pickled protocol-0 strings for `shape` / `hname`, a native string for
+    `mtype`, an 8-bit integer for `incidence_only`: by this module's own reader and `h5dump` only,
+    never by PyTables itself (the reader therefore also takes integer arrays, string arrays, enum
+    booleans and variable-length strings for them);
+  * values (`incidence_only` false -> /h*/data) and the legacy COO form (files without `mtype` or
+    `incidence_only`: /h*/coor + /h*/data, Sparse3DMatrix.py:68-78, :93-99): files written by the
+    test-suite with libhdf5 in the shapes the reference's reader expects.
+
+Large index arrays are decoded in parallel: HDF5 chunks are independent deflate streams, so the
+reader takes every chunk's file address from H5Dget_chunk_info and inflates (libdeflate when
+present, else zlib) + unshuffles the chunks on a thread pool straight into the output array; the
+HDF5 library itself is only used for metadata there.
 """
 from __future__ import annotations
 
@@ -57,7 +70,7 @@ def _load():
     lib.H5Eset_auto2(0, None, None)          # we raise Python errors ourselves
     for name in ('H5Fopen', 'H5Fcreate', 'H5Gopen2', 'H5Gcreate2', 'H5Dopen2', 'H5Dcreate2', 'H5Dget_space',
                  'H5Dget_type', 'H5Aopen', 'H5Aget_type', 'H5Aget_space', 'H5Acreate2', 'H5Tcopy',
-                 'H5Screate_simple', 'H5Screate', 'H5Pcreate'):
+                 'H5Screate_simple', 'H5Screate', 'H5Pcreate', 'H5Dget_create_plist'):
         getattr(lib, name).restype = hid_t
     lib.H5Tget_size.restype = C.c_size_t
     lib.H5Sget_simple_extent_npoints.restype = C.c_int64
@@ -75,6 +88,9 @@ def _load():
         H5Sget_simple_extent_dims=[H, VP, VP],
         H5Pcreate=[H], H5Pset_chunk=[H, I, VP], H5Pset_deflate=[H, U], H5Pclose=[H],
         H5Lexists=[H, CP, H],
+        H5Dget_create_plist=[H], H5Pget_chunk=[H, I, VP], H5Pget_nfilters=[H], H5Pget_layout=[H],
+        H5Pget_filter2=[H, U, VP, VP, VP, SZ, CP, VP], H5Pset_shuffle=[H], H5Tget_order=[H],
+        H5Dget_num_chunks=[H, H, VP], H5Dget_chunk_info=[H, H, C.c_uint64, VP, VP, VP, VP],
     )
     for name, args in sig.items():
         getattr(lib, name).argtypes = args
@@ -145,12 +161,133 @@ def _read_typed(read, obj, ftype, space):
     raise RuntimeError(f'unsupported HDF5 type class {cls}')
 
 
-def _read_dataset(loc, name):
+H5Z_FILTER_DEFLATE, H5Z_FILTER_SHUFFLE = 1, 2
+H5D_CHUNKED = 2
+PARALLEL_MIN_BYTES = 1 << 22          # below this the plain H5Dread is as fast
+
+
+def _inflater():
+    """(name, fn(raw bytes, out_size) -> bytes): libdeflate through ctypes when the image has it (about
+    three times zlib's speed per core; ctypes and zlib both release the GIL while they run)."""
+    global _inflate_impl
+    try:
+        return _inflate_impl
+    except NameError:
+        pass
+    import zlib
+    impl = ('zlib', lambda raw, n: zlib.decompress(raw, bufsize=n))
+    for cand in (os.environ.get('GBRS_LIBDEFLATE'), '/opt/conda/lib/libdeflate.so', ctypes.util.find_library('deflate')):
+        if not cand:
+            continue
+        try:
+            ld = C.CDLL(cand)
+            ld.libdeflate_alloc_decompressor.restype = C.c_void_p
+            ld.libdeflate_zlib_decompress.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t,
+                                                     C.POINTER(C.c_size_t)]
+            ld.libdeflate_zlib_decompress.restype = C.c_int
+            import threading
+            local = threading.local()
+
+            def inflate(raw, n, ld=ld, local=local):
+                d = getattr(local, 'd', None)
+                if d is None:
+                    d = local.d = C.c_void_p(ld.libdeflate_alloc_decompressor())
+                out = (C.c_char * n)()
+                got = C.c_size_t(0)
+                if ld.libdeflate_zlib_decompress(d, raw, len(raw), out, n, C.byref(got)) != 0:
+                    return zlib.decompress(raw, bufsize=n)
+                return memoryview(out)[:got.value]
+            impl = ('libdeflate', inflate)
+            break
+        except (OSError, AttributeError):
+            continue
+    _inflate_impl = impl
+    return impl
+
+
+def _read_chunks_parallel(path, d, ftype, space):
+    """Decode a 1-D chunked dataset (numeric, little endian, filters within {shuffle, deflate}) chunk by
+    chunk on a thread pool.  Returns the array, or None when the dataset does not qualify."""
+    lib = _load()
+    shape = _dims(space)
+    cls, size = lib.H5Tget_class(ftype), int(lib.H5Tget_size(ftype))
+    if len(shape) != 1 or cls not in (H5T_INTEGER, H5T_FLOAT) or lib.H5Tget_order(ftype) != 0:
+        return None
+    n = shape[0]
+    if n * size < PARALLEL_MIN_BYTES:
+        return None
+    if cls == H5T_INTEGER:
+        dt = np.dtype(f"<{'i' if lib.H5Tget_sign(ftype) == 1 else 'u'}{size}")
+    else:
+        dt = np.dtype(f'<f{size}')
+    plist = lib.H5Dget_create_plist(d)
+    try:
+        if lib.H5Pget_layout(plist) != H5D_CHUNKED:
+            return None
+        cdim = (C.c_uint64 * 1)()
+        if lib.H5Pget_chunk(plist, 1, cdim) != 1:
+            return None
+        chunk = int(cdim[0])
+        filters = []
+        for k in range(lib.H5Pget_nfilters(plist)):
+            flags, ncd, cfg = C.c_uint(0), C.c_size_t(0), C.c_uint(0)
+            filters.append(lib.H5Pget_filter2(plist, k, C.byref(flags), C.byref(ncd), None, 0, None, C.byref(cfg)))
+        if filters not in ([], [H5Z_FILTER_DEFLATE], [H5Z_FILTER_SHUFFLE], [H5Z_FILTER_SHUFFLE, H5Z_FILTER_DEFLATE]):
+            return None
+    finally:
+        lib.H5Pclose(plist)
+    nchunks = C.c_uint64(0)
+    if lib.H5Dget_num_chunks(d, space, C.byref(nchunks)) < 0:
+        return None
+    todo = []
+    off, fmask, addr, csize = (C.c_uint64 * 1)(), C.c_uint(0), C.c_uint64(0), C.c_uint64(0)
+    for k in range(nchunks.value):
+        if lib.H5Dget_chunk_info(d, space, k, off, C.byref(fmask), C.byref(addr), C.byref(csize)) < 0:
+            return None
+        todo.append((int(off[0]), int(fmask.value), int(addr.value), int(csize.value)))
+    out = np.zeros(n, dtype=dt)            # chunks that were never written read as the fill value 0
+    raw_view = out.view(np.uint8)
+    _, inflate = _inflater()
+    fd = os.open(path, os.O_RDONLY)
+
+    def decode(item):
+        start, mask, address, stored = item
+        buf = os.pread(fd, stored, address)
+        count = min(chunk, n - start)
+        # filters were applied in pipeline order when writing: undo them back to front; bit k of the
+        # chunk's mask means filter k was skipped for this chunk
+        for k in reversed(range(len(filters))):
+            if mask & (1 << k):
+                continue
+            if filters[k] == H5Z_FILTER_DEFLATE:
+                buf = inflate(buf, chunk * size)
+            else:                                   # byte shuffle: plane b holds byte b of every element
+                planes = np.frombuffer(buf, dtype=np.uint8, count=chunk * size).reshape(size, chunk)
+                raw_view[start * size:(start + count) * size].reshape(count, size)[:] = planes[:, :count].T
+                buf = None
+        if buf is not None:
+            raw_view[start * size:(start + count) * size] = np.frombuffer(buf, dtype=np.uint8, count=count * size)
+
+    try:
+        from concurrent.futures import ThreadPoolExecutor
+        workers = int(os.environ.get('GBRS_IO_THREADS', 0)) or min(32, len(os.sched_getaffinity(0)))
+        with ThreadPoolExecutor(max_workers=max(1, workers)) as pool:
+            list(pool.map(decode, todo, chunksize=4))
+    finally:
+        os.close(fd)
+    return out
+
+
+def _read_dataset(loc, name, path=None):
     lib = _load()
     d = _check(lib.H5Dopen2(loc, name.encode(), H5P_DEFAULT), f'open dataset {name}')
     try:
         ftype, space = lib.H5Dget_type(d), lib.H5Dget_space(d)
         try:
+            if path is not None and not os.environ.get('GBRS_H5_SERIAL'):
+                fast = _read_chunks_parallel(path, d, ftype, space)
+                if fast is not None:
+                    return fast
             return _read_typed(lambda o, t, p: lib.H5Dread(o, t, H5S_ALL, H5S_ALL, H5P_DEFAULT, p),
                                d, ftype, space)
         finally:
@@ -203,9 +340,45 @@ def _unpickle_maybe(v):
     return v
 
 
+def _as_bool(v):
+    v = _unpickle_maybe(v)
+    if isinstance(v, np.ndarray):
+        v = v.ravel()[0] if v.size else 0
+    if isinstance(v, (bytes, np.bytes_)):
+        return bytes(v).strip(b'\x00').lower() not in (b'', b'0', b'false')
+    return bool(v)
+
+
+def _coo_to_csc(coor, data, R, L):
+    """Legacy COO component (Sparse3DMatrix.py:93-99: coo_matrix((data, coor), shape=(R, L)) followed by
+    .tocsc() in finalize(), which orders by column then row and adds up duplicate coordinates)."""
+    coor = np.asarray(coor)
+    if coor.ndim != 2 or 2 not in coor.shape:
+        raise RuntimeError('legacy EMASE file: /h*/coor must hold (row, column) pairs')
+    rows, cols = (coor[0], coor[1]) if coor.shape[0] == 2 else (coor[:, 0], coor[:, 1])
+    rows = rows.astype(np.int64)
+    cols = cols.astype(np.int64)
+    vals = np.asarray(data, dtype=np.float64)
+    if len(vals) != len(rows):
+        raise RuntimeError('legacy EMASE file: /h*/coor and /h*/data differ in length')
+    if len(rows) and (rows.min() < 0 or rows.max() >= R or cols.min() < 0 or cols.max() >= L):
+        raise ValueError('legacy EMASE file: coordinate outside the matrix shape')
+    order = np.lexsort((rows, cols))
+    rows, cols, vals = rows[order], cols[order], vals[order]
+    if len(rows):
+        first = np.concatenate(([True], (rows[1:] != rows[:-1]) | (cols[1:] != cols[:-1])))
+        if not first.all():
+            vals = np.add.reduceat(vals, np.flatnonzero(first))
+            rows, cols = rows[first], cols[first]
+    indptr = np.searchsorted(cols, np.arange(L + 1)).astype(np.uint32)
+    return indptr, rows.astype(np.uint32), vals
+
+
 def load_into(apm, path):
     """Fill an AlignmentPropertyMatrix from an EMASE h5 file (Sparse3DMatrix.py:42-102,
-    AlignmentPropertyMatrix.py:70-83)."""
+    AlignmentPropertyMatrix.py:70-83).  Stored values other than 1 end up in `apm.values` (they set the
+    starting point of the EM: EMfactory.prepare normalises them, EMfactory.py:95-98); an incidence-only
+    file, or one whose values are all 1, leaves `apm.values` None."""
     lib = _load()
     f = lib.H5Fopen(os.fsencode(path), H5F_ACC_RDONLY, H5P_DEFAULT)
     if f < 0:
@@ -213,18 +386,24 @@ def load_into(apm, path):
     try:
         root = _check(lib.H5Gopen2(f, b'/', H5P_DEFAULT), 'open /')
         try:
+            # a file lacking either attribute is the legacy COO form with values (Sparse3DMatrix.py:69-78)
             try:
                 mtype = _unpickle_maybe(_read_attr(root, 'mtype'))
+                incidence_only = _as_bool(_read_attr(root, 'incidence_only'))
+                if isinstance(mtype, (bytes, np.bytes_)):
+                    mtype = bytes(mtype).decode()
+                mtype = str(mtype).rstrip('\x00')
             except AttributeError:
-                raise RuntimeError('Only csc matrices are supported (legacy COO EMASE file without an '
-                                   '`mtype` attribute).')
-            if isinstance(mtype, (bytes, np.bytes_)):
-                mtype = bytes(mtype).decode()
-            mtype = str(mtype).rstrip('\x00')
-            if mtype != 'csc_matrix':
+                mtype, incidence_only = 'coo_matrix', False
+            if mtype not in ('csc_matrix', 'coo_matrix'):
                 raise RuntimeError('Only csc or coo matrices are supported.')
-            shape = _unpickle_maybe(_read_attr(root, 'shape'))
+            try:
+                shape = _unpickle_maybe(_read_attr(root, 'shape'))
+            except AttributeError:
+                raise RuntimeError(f'{path} is not an EMASE alignment file: the root attribute `shape` is missing')
             apm.shape = tuple(int(x) for x in np.asarray(shape).ravel())
+            if len(apm.shape) != 3 or min(apm.shape) < 1:
+                raise RuntimeError('The shape must be a tuple of three positive integers.')
             L, H, R = apm.shape
             try:
                 hname = _unpickle_maybe(_read_attr(root, 'hname'))
@@ -232,19 +411,30 @@ def load_into(apm, path):
                              for x in (hname.ravel() if isinstance(hname, np.ndarray) else hname)]
             except AttributeError:
                 apm.hname = None
-            apm.indptr, apm.indices = [], []
+            apm.indptr, apm.indices, values = [], [], []
             for h in range(H):
                 g = _check(lib.H5Gopen2(f, f'/h{h}'.encode(), H5P_DEFAULT), f'open /h{h}')
                 try:
-                    apm.indptr.append(np.ascontiguousarray(_read_dataset(g, 'indptr'), dtype=np.uint32))
-                    apm.indices.append(np.ascontiguousarray(_read_dataset(g, 'indices'), dtype=np.uint32))
+                    if mtype == 'csc_matrix':
+                        apm.indptr.append(np.ascontiguousarray(_read_dataset(g, 'indptr'), dtype=np.uint32))
+                        apm.indices.append(np.ascontiguousarray(_read_dataset(g, 'indices', path), dtype=np.uint32))
+                        values.append(None if incidence_only else
+                                      np.ascontiguousarray(_read_dataset(g, 'data', path), dtype=np.float64))
+                    else:
+                        ip, ix, v = _coo_to_csc(_read_dataset(g, 'coor'), _read_dataset(g, 'data', path), R, L)
+                        apm.indptr.append(ip)
+                        apm.indices.append(ix)
+                        values.append(v)
                 finally:
                     lib.H5Gclose(g)
+            if any(v is not None and len(v) and not (v == 1.0).all() for v in values):
+                apm.values = [np.ones(len(apm.indices[h])) if v is None else v for h, v in enumerate(values)]
             if lib.H5Lexists(root, b'count', H5P_DEFAULT) > 0:
-                apm.count = np.ascontiguousarray(_read_dataset(root, 'count'), dtype=np.float64)
+                apm.count = np.ascontiguousarray(_read_dataset(root, 'count', path), dtype=np.float64)
             if lib.H5Lexists(root, b'lname', H5P_DEFAULT) > 0:
                 ln = _read_dataset(root, 'lname')
-                apm.lname = [x.decode() if isinstance(x, (bytes, np.bytes_)) else str(x) for x in ln.ravel()]
+                apm.lname = ln.ravel().astype('U').tolist() if ln.dtype.kind == 'S' else \
+                    [x.decode() if isinstance(x, (bytes, np.bytes_)) else str(x) for x in ln.ravel()]
         finally:
             lib.H5Gclose(root)
     finally:
@@ -284,6 +474,8 @@ def _write_carray(loc, name, arr, title='', complevel=1):
     if n > 0:
         chunk = (C.c_uint64 * 1)(min(n, 1 << 16))
         lib.H5Pset_chunk(plist, 1, chunk)
+        if arr.dtype.kind != 'S':
+            lib.H5Pset_shuffle(plist)           # tables.Filters(complevel=1) shuffles by default
         lib.H5Pset_deflate(plist, complevel)
     if arr.dtype.kind == 'S':
         t = lib.H5Tcopy(_g('H5T_C_S1_g'))
@@ -313,7 +505,8 @@ def _group_attrs(g, title=''):
 
 def save(apm, path, title=None, complib='zlib', incidence_only=True, shallow=False, **_ignored):
     """Write the EMASE h5 layout (Sparse3DMatrix.save :400-444 + AlignmentPropertyMatrix.save :478-525).
-    Only incidence matrices are written (`incidence_only=True`, the reference's default)."""
+    incidence_only=True (the reference's default) writes the structure alone; False adds /h*/data with
+    `apm.values` (ones when the matrix has none)."""
     lib = _load()
     f = lib.H5Fcreate(os.fsencode(path), H5F_ACC_TRUNC, H5P_DEFAULT, H5P_DEFAULT)
     if f < 0:
@@ -322,7 +515,7 @@ def save(apm, path, title=None, complib='zlib', incidence_only=True, shallow=Fal
         root = lib.H5Gopen2(f, b'/', H5P_DEFAULT)
         _group_attrs(root, title or '')
         _write_str_attr(root, 'PYTABLES_FORMAT_VERSION', b'2.1')
-        _write_scalar_attr(root, 'incidence_only', 1, np.int8)
+        _write_scalar_attr(root, 'incidence_only', 1 if incidence_only else 0, np.int8)
         _write_str_attr(root, 'mtype', b'csc_matrix')
         _write_str_attr(root, 'shape', pickle.dumps(tuple(int(x) for x in apm.shape), 0))
         L, H, R = apm.shape
@@ -332,6 +525,10 @@ def save(apm, path, title=None, complib='zlib', incidence_only=True, shallow=Fal
             _group_attrs(g, f'Sparse matrix components for Haplotype {h}')
             _write_carray(g, 'indptr', apm.indptr[h].astype(np.uint32))
             _write_carray(g, 'indices', apm.indices[h].astype(np.uint32))
+            if not incidence_only:
+                vals = getattr(apm, 'values', None)
+                _write_carray(g, 'data', np.ones(len(apm.indices[h])) if vals is None
+                              else np.asarray(vals[h], dtype=np.float64))
             lib.H5Gclose(g)
         if apm.count is not None:
             _write_carray(root, 'count', np.asarray(apm.count, dtype=np.float64), 'Equivalence Class Counts')

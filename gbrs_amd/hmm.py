@@ -15,6 +15,7 @@ from itertools import combinations_with_replacement
 import numpy as np
 
 from . import _lib
+from .npzfast import FastNpz, savez_compressed
 
 logger = logging.getLogger('gbrs')
 
@@ -136,40 +137,53 @@ def get_chromosome_info(data_dir=None):
 
 
 def read_gene_tpm(expression_file):
-    """(haplotype letters, {gene id: TPM per haplotype}) from a `.genes.tpm` report.  The first column
-    is the gene id and the last the total; `gbrs reconstruct` assumes there is no notes column, i.e.
-    the multiway report (gbrs_utils.py:450-459)."""
+    """(haplotype letters, {gene id: row}, TPM matrix [genes x H]) from a `.genes.tpm` report.  The first
+    column is the gene id and the last the total; `gbrs reconstruct` assumes there is no notes column,
+    i.e. the multiway report (gbrs_utils.py:450-459).  The numbers of the whole file go
+    through one C-level parse instead of a float() per cell."""
     with open(expression_file) as fh:
         haplotypes = fh.readline().rstrip().split('\t')[1:-1]
-        table = {}
-        for line in fh:
-            fields = line.rstrip().split('\t')
-            table[fields[0]] = np.array(fields[1:-1], dtype=np.float64)
-    return haplotypes, table
+        lines = fh.read().splitlines()
+    ids, cells = [], []
+    for line in lines:
+        gid, _, rest = line.rstrip().partition('\t')
+        ids.append(gid)
+        cells.append(rest)
+    width = len(haplotypes) + 1
+    flat = np.fromstring('\t'.join(cells), dtype=np.float64, sep='\t') if cells else np.zeros(0)
+    if flat.size != len(ids) * width:
+        raise ValueError(f'{expression_file}: every line must hold {width} numbers after the gene id')
+    table = flat.reshape(len(ids), width)[:, :-1]
+    return haplotypes, {g: k for k, g in enumerate(ids)}, table
 
 
 def read_gene_order(gpos_file):
     """{chromosome: [gene ids in genome order]} from `ref.gene_pos.ordered.npz`, whose arrays hold
     (gene id, position) records with the id as bytes or str (gbrs_utils.py:437-447)."""
     order = {}
-    with np.load(gpos_file) as z:
-        for c in z.files:
-            order[c] = [gid.decode() if isinstance(gid, bytes) else str(gid) for gid, *_ in z[c]]
+    z = FastNpz(gpos_file)
+    for c in z.files:
+        a = z[c]
+        if a.dtype.names:                                   # structured records: first field is the id
+            col = a[a.dtype.names[0]]
+            order[c] = col.astype('U').tolist()
+        else:
+            order[c] = [gid.decode() if isinstance(gid, bytes) else str(gid) for gid, *_ in a]
+    z.close()
     return order
 
 
-def chromosome_inputs(gene_ids, expr, avecs, avec_ids, num_haps):
+def chromosome_inputs(gene_ids, expr_row, expr_table, avecs, num_haps):
     """Device inputs of one chromosome: expression rows (n x H), specificity blocks (n x H x H, zero
-    where the gene has none) and the has-block flags."""
+    where the gene has none) and the has-block flags.  `avecs` is a FastNpz of per-gene (H x H) blocks."""
     n = len(gene_ids)
-    rows = np.empty((n, num_haps), dtype=np.float64)
+    rows = expr_table[[expr_row[g] for g in gene_ids]] if n else np.zeros((0, num_haps))   # KeyError: gene without TPM
+    rows = np.ascontiguousarray(rows, dtype=np.float64).reshape(n, num_haps)
+    present = np.fromiter((g in avecs for g in gene_ids), dtype=np.uint8, count=n)
     blocks = np.zeros((n, num_haps, num_haps), dtype=np.float64)
-    present = np.zeros(n, dtype=np.uint8)
-    for k, gid in enumerate(gene_ids):
-        rows[k] = expr[gid]                                   # KeyError for a gene without TPM, as in the reference
-        if gid in avec_ids:
-            blocks[k] = avecs[gid]
-            present[k] = 1
+    have = np.flatnonzero(present)
+    if len(have):
+        blocks[have] = avecs.stack([gene_ids[k] for k in have], (num_haps, num_haps))
     return rows, blocks, present
 
 
@@ -196,19 +210,19 @@ def reconstruct(expression_file: str, tprob_file: str, avec_file: str = None, gp
     logger.info('Loading chromosome information')
     genome = list(get_chromosome_info(data_dir))
     logger.info(f'Loading alignment specificity: {avec_file}')
-    avecs = np.load(avec_file)
-    avec_ids = frozenset(avecs.files)
+    avecs = FastNpz(avec_file)
     logger.info(f'Loading gene meta data: {gpos_file}')
     gene_order = read_gene_order(gpos_file)
     logger.info(f'Loading expression level data: {expression_file}')
-    haplotypes, expr = read_gene_tpm(expression_file)
+    haplotypes, expr_row, expr_table = read_gene_tpm(expression_file)
     num_haps = len(haplotypes)
     diplotypes = [a + b for a, b in combinations_with_replacement(haplotypes, 2)]
     logger.info(f'Loading transition probabilities: {tprob_file}')
-    tprob = np.load(tprob_file)
-    chroms = [c for c in genome if c in tprob.files]            # chromosomes without a table are skipped (:495)
-    per_chrom = [chromosome_inputs(gene_order[c], expr, avecs, avec_ids, num_haps) for c in chroms]
-    tables = [tprob[c] for c in chroms]
+    tprob = FastNpz(tprob_file)
+    chroms = [c for c in genome if c in tprob]                  # chromosomes without a table are skipped (:495)
+    per_chrom = [chromosome_inputs(gene_order[c], expr_row, expr_table, avecs, num_haps) for c in chroms]
+    tables = tprob.read_many(chroms)                            # stored members: views of the page cache, no copy
+    avecs.close()
     marks['load'] = clock() - t0
 
     posterior, path_names, calls = {}, {}, {}
@@ -233,12 +247,12 @@ def reconstruct(expression_file: str, tprob_file: str, avec_file: str = None, gp
 
     t0 = clock()
     logger.info(f'Saving Reconstructed Genotype Probabilities: {out_post}')
-    np.savez_compressed(out_post, **posterior)
+    savez_compressed(out_post, posterior)
     logger.info(f'Saving Reconstructed Genotypes: {out_calls}')
     with open(out_calls, 'w') as out:
         out.write('#Gene_ID\tDiplotype\n')
         out.writelines(f'{gid}\t{calls[gid]}\n' for gid in sorted(calls))
     logger.info(f'Saving Reconstructed Ordered Genotypes: {out_path}')
-    np.savez_compressed(out_path, **path_names)
+    savez_compressed(out_path, {c: np.asarray(v) for c, v in path_names.items()})
     marks['save'] = clock() - t0
     logger.info('Done')

@@ -1,0 +1,195 @@
+"""Fast readers for the `.npz` inputs of `gbrs reconstruct` / `gbrs quantify`.
+
+`numpy.load(path)[name]` re-opens the zip member, re-parses its header and CRC-checks the payload on
+every access (~0.2-0.4 ms per member): the reference pays that once per gene for avecs.npz
+(gbrs/gbrs_utils.py:490, ~45 % of its run time).  An `.npz` is a plain zip of `.npy`
+members, so this module reads the central directory once and then
+
+  * maps stored (uncompressed) members straight out of the page cache (`numpy.frombuffer` on an mmap:
+    no copy for the 0.5 GB transition tables, ~1 us per small member), and
+  * inflates compressed members with raw zlib - large ones on a thread pool (zlib releases the GIL).
+
+Only C-ordered, non-object `.npy` members are handled here; anything else falls back to numpy.load.
+"""
+from __future__ import annotations
+
+import ast
+import mmap
+import os
+import struct
+import zipfile
+import zlib
+
+import numpy as np
+
+
+class FastNpz:
+    def __init__(self, path):
+        self.path = path
+        self._fh = open(path, 'rb')
+        self._mm = mmap.mmap(self._fh.fileno(), 0, access=mmap.ACCESS_READ)
+        with zipfile.ZipFile(path) as zf:
+            infos = zf.infolist()
+        self._info = {}
+        for zi in infos:
+            name = zi.filename[:-4] if zi.filename.endswith('.npy') else zi.filename
+            self._info[name] = zi
+        self.files = list(self._info)
+        self._fallback = None
+
+    def __contains__(self, name):
+        return name in self._info
+
+    def close(self):
+        try:
+            self._mm.close()
+        except (BufferError, ValueError):      # arrays handed out still point into the map
+            pass
+        self._fh.close()
+
+    # ---- one member ------------------------------------------------------------------------------
+    def _payload(self, zi):
+        """(compression method, offset of the member's data in the file, stored size)."""
+        o = zi.header_offset
+        sig, = struct.unpack_from('<I', self._mm, o)
+        if sig != 0x04034b50:
+            raise ValueError(f'{self.path}: bad local header for {zi.filename}')
+        nlen, xlen = struct.unpack_from('<HH', self._mm, o + 26)
+        return zi.compress_type, o + 30 + nlen + xlen, zi.compress_size
+
+    @staticmethod
+    def _npy_header(buf, base=0):
+        """(dtype, shape, data offset relative to base) of the .npy image starting at buf[base]."""
+        if bytes(buf[base:base + 6]) != b'\x93NUMPY':
+            raise ValueError('not an .npy member')
+        major = buf[base + 6]
+        if major == 1:
+            hlen, = struct.unpack_from('<H', buf, base + 8)
+            start = base + 10
+        else:
+            hlen, = struct.unpack_from('<I', buf, base + 8)
+            start = base + 12
+        meta = ast.literal_eval(bytes(buf[start:start + hlen]).decode('latin1'))
+        dt = np.dtype(meta['descr'])
+        if meta['fortran_order'] or dt.hasobject:
+            raise ValueError('unsupported .npy layout')
+        return dt, tuple(meta['shape']), start + hlen - base
+
+    def _numpy_load(self, name):
+        if self._fallback is None:
+            self._fallback = np.load(self.path, allow_pickle=False)
+        return self._fallback[name]
+
+    def __getitem__(self, name):
+        zi = self._info[name]
+        try:
+            method, off, csize = self._payload(zi)
+            if method == zipfile.ZIP_STORED:
+                dt, shape, doff = self._npy_header(self._mm, off)
+                return np.frombuffer(self._mm, dtype=dt, count=int(np.prod(shape, dtype=np.int64)),
+                                     offset=off + doff).reshape(shape)
+            if method == zipfile.ZIP_DEFLATED:
+                raw = zlib.decompress(self._mm[off:off + csize], -15, zi.file_size)
+                dt, shape, doff = self._npy_header(raw)
+                return np.frombuffer(raw, dtype=dt, count=int(np.prod(shape, dtype=np.int64)), offset=doff).reshape(shape)
+        except ValueError:
+            pass
+        return self._numpy_load(name)
+
+    # ---- many members ----------------------------------------------------------------------------
+    def read_many(self, names, threads=None):
+        """The members `names` as a list of arrays; large compressed ones are inflated in parallel."""
+        names = list(names)
+        big = sum(self._info[n].file_size for n in names) > (8 << 20) and \
+            any(self._info[n].compress_type != zipfile.ZIP_STORED for n in names)
+        if not big or len(names) < 2:
+            return [self[n] for n in names]
+        from concurrent.futures import ThreadPoolExecutor
+        workers = threads or int(os.environ.get('GBRS_IO_THREADS', 0)) or min(32, len(os.sched_getaffinity(0)))
+        with ThreadPoolExecutor(max_workers=max(1, min(workers, len(names)))) as pool:
+            return list(pool.map(self.__getitem__, names))
+
+    def stack(self, names, shape, dtype=np.float64):
+        """Equally shaped small members (the per-gene blocks of avecs.npz) as one [len(names), *shape]
+        array.  Members whose .npy header equals the first one's (same dtype, shape, order - the normal
+        case) are copied as raw bytes without parsing their header again."""
+        want = tuple(int(x) for x in shape)
+        out = np.empty((len(names),) + want, dtype=dtype)
+        if not len(names):
+            return out
+        nbytes = out[0].nbytes
+        flat = memoryview(out.reshape(-1).view(np.uint8))
+        mm, info, unpack = self._mm, self._info, struct.unpack_from
+        ref_hdr = None
+        for k, n in enumerate(names):
+            zi = info[n]
+            o = zi.header_offset
+            nlen, xlen = unpack('<HH', mm, o + 26)
+            ds = o + 30 + nlen + xlen
+            if zi.compress_type == zipfile.ZIP_STORED:
+                buf, base = mm, ds
+            elif zi.compress_type == zipfile.ZIP_DEFLATED:
+                buf, base = zlib.decompress(mm[ds:ds + zi.compress_size], -15, zi.file_size), 0
+            else:
+                buf = None
+            if buf is not None and ref_hdr is not None and buf[base:base + len(ref_hdr)] == ref_hdr:
+                start = base + len(ref_hdr)
+                flat[k * nbytes:(k + 1) * nbytes] = buf[start:start + nbytes]
+                continue
+            a = self[n]                                   # first member, or one with a header of its own
+            if a.shape != want:
+                raise ValueError(f'{self.path}: member {n} has shape {a.shape}, expected {want}')
+            out[k] = a
+            if ref_hdr is None and buf is not None and a.dtype == out.dtype:
+                try:
+                    _, _, doff = self._npy_header(buf, base)
+                    ref_hdr = bytes(buf[base:base + doff])
+                except ValueError:
+                    pass
+        return out
+
+
+def savez_compressed(path, arrays, level=6, threads=None):
+    """numpy.savez_compressed with the members deflated on a thread pool (zlib releases the GIL) and the zip
+    container written by hand: local header + raw deflate stream per member, central directory, end
+    record.  The result is an ordinary `.npz` that numpy.load reads."""
+    import io
+    from concurrent.futures import ThreadPoolExecutor
+    path = str(path)
+    if not path.endswith('.npz'):
+        path += '.npz'
+
+    def pack(item):
+        name, arr = item
+        bio = io.BytesIO()
+        np.lib.format.write_array(bio, np.asanyarray(arr), allow_pickle=False)
+        raw = bio.getvalue()
+        comp = zlib.compressobj(level, zlib.DEFLATED, -15)
+        data = comp.compress(raw) + comp.flush()
+        return (name + '.npy').encode(), zlib.crc32(raw), len(raw), data
+
+    items = list(arrays.items())
+    workers = threads or int(os.environ.get('GBRS_IO_THREADS', 0)) or min(32, len(os.sched_getaffinity(0)))
+    if len(items) > 1 and workers > 1:
+        with ThreadPoolExecutor(max_workers=min(workers, len(items))) as pool:
+            packed = list(pool.map(pack, items))
+    else:
+        packed = [pack(it) for it in items]
+    central = []
+    with open(path, 'wb') as fh:
+        for fname, crc, usize, data in packed:
+            off = fh.tell()
+            if max(usize, len(data), off) >= 0xFFFFFFFF:
+                raise ValueError('member too large for the plain zip format; use numpy.savez_compressed')
+            fh.write(struct.pack('<IHHHHHIIIHH', 0x04034b50, 20, 0, 8, 0, 0x21, crc, len(data), usize, len(fname), 0))
+            fh.write(fname)
+            fh.write(data)
+            central.append(struct.pack('<IHHHHHHIIIHHHHHII', 0x02014b50, 20, 20, 0, 8, 0, 0x21, crc, len(data), usize,
+                                       len(fname), 0, 0, 0, 0, 0, off) + fname)
+        cd_off = fh.tell()
+        for rec in central:
+            fh.write(rec)
+        cd_size = fh.tell() - cd_off
+        if len(central) > 0xFFFF:
+            raise ValueError('too many members for the plain zip format')
+        fh.write(struct.pack('<IHHHHIIH', 0x06054b50, 0, 0, len(central), len(central), cd_size, cd_off, 0))

@@ -286,6 +286,37 @@ int gbrs_interpolate(int num_states, int n_points, const double *x, const double
  * (S x H) matrix 0.5 * (founder count in diplotype) -> n_rows x H founder dosages. */
 int gbrs_genoprob_dosage(int num_haps, int64_t n_rows, const double *gprob, double *out, int device);
 
+/* ------------------------------------------------------------------------------------------
+ * Report text (host side, no device work): the `locus <haplotypes> total [notes]` tables of
+ * EMfactory.report_read_counts / report_depths (emase/EMfactory.py:289-380).
+ * ---------------------------------------------------------------------------------------- */
+
+/* One double in the form str(numpy.float64) / repr(float) give it (shortest round-trip digits, fixed
+ * notation for 1e-4 <= |x| < 1e16, otherwise d.ddde+XX).  out needs 32 bytes; returns the length. */
+int gbrs_format_double(double v, char *out32);
+
+/* Writes `header_line` and then, for k = 0 .. n_rows-1 and r = order ? order[k] : k, the line
+ *     name r  TAB  value(r, 0) TAB ... TAB value(r, n_cols-1)  TAB  totals[r]  [TAB note r]  LF
+ * with value(r, c) = values[r * row_stride + c * col_stride] (strides in elements, so both the
+ * (H x L) row-major matrix of gbrs_em_get and its transpose are taken as they lie in memory);
+ * totals[r] is the caller's column sum (kept outside so that its summation order stays the
+ * caller's); names / notes are byte blobs addressed by n_rows + 1 offsets, name r =
+ * names[name_off[r] .. name_off[r+1]); notes / note_off may both be NULL. */
+int gbrs_write_locus_table(const char *path, const char *header_line, const double *values, int64_t n_rows,
+                           int32_t n_cols, int64_t row_stride, int64_t col_stride, const double *totals,
+                           const char *names, const int64_t *name_off, const char *notes,
+                           const int64_t *note_off, const int64_t *order);
+
+/* The length table of EMfactory.prepare (emase/EMfactory.py:60-94) parsed natively: text is the whole
+ * file (`<locus>_<haplotype> TAB <length>` lines, plain `<locus>` keys when n_haps == 1), names / haps
+ * are byte blobs with n + 1 offsets, eff_out is (n_haps x n_loci) row-major and receives
+ * max(length - read_length + 1, 1) for the listed pairs (other elements untouched).  Returns 0 when
+ * every line was plain, 1 when some line needs the caller's own permissive line-by-line parsing and
+ * error reporting (unknown name, second underscore, a number in a form from_chars does not take). */
+int gbrs_parse_length_table(const char *text, int64_t text_len, const char *names, const int64_t *name_off,
+                            int64_t n_loci, const char *haps, const int64_t *hap_off, int32_t n_haps,
+                            double read_length, double *eff_out);
+
 #ifdef __cplusplus
 }
 #endif

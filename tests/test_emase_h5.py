@@ -56,7 +56,7 @@ def test_h5_structure_matches_emase_layout(tmp_path):
                    'ATTRIBUTE "incidence_only"', 'H5T_STD_U32LE', 'H5T_IEEE_F64LE'):
         assert needle in txt, needle
     prop = subprocess.run([h5dump, "-p", "-H", "-d", "/h0/indices", str(p)], capture_output=True, text=True).stdout
-    assert "DEFLATE" in prop and "CHUNKED" in prop
+    assert "DEFLATE" in prop and "CHUNKED" in prop and "SHUFFLE" in prop
 
 
 def test_h5_reader_accepts_plain_encodings(tmp_path):
@@ -82,13 +82,116 @@ def test_h5_reader_accepts_plain_encodings(tmp_path):
     assert b.shape == a.shape
 
 
-def test_h5_legacy_coo_rejected(tmp_path):
-    h5 = _lib_or_skip()
+def _write_dataset(lib, h5, loc, name, arr):
+    """Plain contiguous dataset (what an old writer without filters produced)."""
     import ctypes as C
+    arr = np.ascontiguousarray(arr)
+    dims = (C.c_uint64 * arr.ndim)(*arr.shape)
+    sp = lib.H5Screate_simple(arr.ndim, dims, None)
+    d = lib.H5Dcreate2(loc, name.encode(), h5._native(arr.dtype), sp, 0, 0, 0)
+    assert d >= 0
+    lib.H5Dwrite(d, h5._native(arr.dtype), 0, 0, 0, arr.ctypes.data_as(C.c_void_p))
+    lib.H5Dclose(d); lib.H5Sclose(sp)
+
+
+def test_h5_legacy_coo_file(tmp_path):
+    """Files without `mtype` / `incidence_only` are COO with values (Sparse3DMatrix.py:69-78, :93-99):
+    /h*/coor (row, column) pairs + /h*/data, converted to CSC as finalize() does (duplicates added)."""
+    h5 = _lib_or_skip()
+    import pickle
+    import scipy.sparse as sp
     lib = h5._load()
+    rng = np.random.default_rng(5)
+    L, H, R = 7, 2, 30
     p = tmp_path / "legacy.h5"
+    f = lib.H5Fcreate(str(p).encode(), 2, 0, 0)
+    root = lib.H5Gopen2(f, b"/", 0)
+    h5._write_str_attr(root, "shape", pickle.dumps((L, H, R), 0))
+    h5._write_str_attr(root, "hname", pickle.dumps(["A", "B"], 0))
+    expect = []
+    for h in range(H):
+        n = 40
+        rows, cols = rng.integers(0, R, n), rng.integers(0, L, n)          # duplicates on purpose
+        vals = rng.random(n) + 0.5
+        g = lib.H5Gcreate2(f, f"/h{h}".encode(), 0, 0, 0)
+        _write_dataset(lib, h5, g, "coor", np.vstack((rows, cols)).astype(np.int64))
+        _write_dataset(lib, h5, g, "data", vals)
+        lib.H5Gclose(g)
+        expect.append(sp.coo_matrix((vals, (rows, cols)), shape=(R, L)).tocsc())
+    h5._write_carray(root, "lname", np.array([f"t{l}" for l in range(L)], dtype="S"))
+    lib.H5Gclose(root); lib.H5Fclose(f)
+    from gbrs_amd.alignment import load_alignment
+    b = load_alignment(str(p))
+    assert b.shape == (L, H, R) and b.hname == ["A", "B"] and b.values is not None
+    for h in range(H):
+        m = expect[h]
+        m.sort_indices()
+        np.testing.assert_array_equal(b.indptr[h], m.indptr)
+        np.testing.assert_array_equal(b.indices[h], m.indices)
+        np.testing.assert_allclose(b.values[h], m.data, rtol=1e-15)
+
+
+def test_h5_values_round_trip_and_all_ones(tmp_path):
+    """incidence_only=False files carry /h*/data; values that are all 1 collapse to the incidence form."""
+    _lib_or_skip()
+    from gbrs_amd.alignment import load_alignment
+    a = _apm()
+    rng = np.random.default_rng(8)
+    a.values = [rng.random(len(ix)) + 0.25 for ix in a.indices]
+    p = tmp_path / "v.h5"
+    a.save(str(p), incidence_only=False)
+    b = load_alignment(str(p))
+    for h in range(a.num_haplotypes):
+        np.testing.assert_array_equal(b.values[h], a.values[h])
+    a.values = None
+    a.save(str(p), incidence_only=False)            # data arrays of ones
+    assert load_alignment(str(p)).values is None
+    a.save(str(tmp_path / "v.npz"))
+    assert load_alignment(str(tmp_path / "v.npz")).values is None
+
+
+def test_h5_parallel_chunk_decoder_matches_h5dread(tmp_path, monkeypatch):
+    """Index arrays above 4 MiB are inflated chunk by chunk on a thread pool (file addresses from
+    H5Dget_chunk_info); the result must equal what H5Dread returns, including the partly filled last
+    chunk, with zlib and with libdeflate."""
+    h5 = _lib_or_skip()
+    from gbrs_amd.alignment import AlignmentPropertyMatrix, load_alignment
+    rng = np.random.default_rng(11)
+    L, H, R = 50, 2, 900_000
+    indptr, indices = [], []
+    for h in range(H):
+        per = rng.multinomial(1_300_001 + h, np.ones(L) / L)
+        indptr.append(np.concatenate(([0], np.cumsum(per))).astype(np.uint32))
+        indices.append(np.concatenate([np.sort(rng.choice(R, size=k, replace=False)) for k in per]).astype(np.uint32))
+    a = AlignmentPropertyMatrix(shape=(L, H, R), indptr=indptr, indices=indices, count=rng.integers(1, 9, R).astype(float),
+                                haplotype_names=["A", "B"], locus_names=[f"t{l}" for l in range(L)])
+    p = tmp_path / "big.h5"
+    a.save(str(p))
+    calls = []
+    real = h5._read_chunks_parallel
+    monkeypatch.setattr(h5, "_read_chunks_parallel", lambda *aa: calls.append(1) or real(*aa))
+    b = load_alignment(str(p))
+    assert len(calls) >= H                                   # the fast path was taken for the index arrays
+    monkeypatch.setenv("GBRS_H5_SERIAL", "1")
+    c = load_alignment(str(p))
+    for h in range(H):
+        np.testing.assert_array_equal(b.indices[h], a.indices[h])
+        np.testing.assert_array_equal(c.indices[h], a.indices[h])
+    np.testing.assert_array_equal(b.count, a.count)
+    monkeypatch.delenv("GBRS_H5_SERIAL")
+    name, _ = h5._inflater()
+    if name == "libdeflate":                                 # and once more through the zlib module
+        monkeypatch.setattr(h5, "_inflate_impl", ("zlib", lambda raw, n: __import__("zlib").decompress(raw, bufsize=n)))
+        d = load_alignment(str(p))
+        np.testing.assert_array_equal(d.indices[1], a.indices[1])
+
+
+def test_h5_not_an_emase_file(tmp_path):
+    h5 = _lib_or_skip()
+    lib = h5._load()
+    p = tmp_path / "empty.h5"
     f = lib.H5Fcreate(str(p).encode(), 2, 0, 0)
     lib.H5Fclose(f)
     from gbrs_amd.alignment import load_alignment
-    with pytest.raises(RuntimeError, match="csc"):
+    with pytest.raises(RuntimeError, match="not an EMASE"):
         load_alignment(str(p))
