@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libgbrs_hip.so")
 # names every build must export (checked by tests/test_abi.py against include/gbrs_hip.h)
 EXPORTS = [
     "gbrs_last_error", "gbrs_abi_version", "gbrs_device_count",
-    "gbrs_em_create", "gbrs_em_create_device", "gbrs_em_prepare", "gbrs_em_step", "gbrs_em_run",
+    "gbrs_em_create", "gbrs_em_create_device", "gbrs_em_set_initial_values", "gbrs_em_prepare", "gbrs_em_step", "gbrs_em_run",
     "gbrs_em_get", "gbrs_em_set_theta", "gbrs_em_group_sums", "gbrs_em_estep_partial",
     "gbrs_em_finish_step", "gbrs_em_prepare_partial", "gbrs_em_finish_prepare", "gbrs_em_stream",
     "gbrs_em_set_stream",
@@ -24,6 +24,7 @@ EXPORTS = [
     "gbrs_hmm_get", "gbrs_hmm_info", "gbrs_hmm_destroy", "gbrs_interpolate", "gbrs_genoprob_dosage",
     "gbrs_compress_create", "gbrs_compress_get", "gbrs_compress_destroy",
     "gbrs_format_double", "gbrs_write_locus_table", "gbrs_parse_length_table",
+    "gbrs_decode_chunks", "gbrs_inflate_backend",
 ]
 
 GBRS_OK = 0
@@ -41,6 +42,7 @@ GBRS_EM_NO_INTERLEAVE = 4
 GBRS_EM_FORCE_INTERLEAVE = 8
 GBRS_EM_NO_STREAMS = 16
 GBRS_EM_DETERMINISTIC = 32
+GBRS_EM_KEEP_CSC = 64
 
 
 class EmInfo(C.Structure):
@@ -94,6 +96,7 @@ def load():
     sigs = {
         "gbrs_em_create": [u64, u32, u32, pp, pp, vp, vp, i32, u32, pp],
         "gbrs_em_create_device": [u64, u32, u32, pp, pp, vp, vp, i32, u32, pp],
+        "gbrs_em_set_initial_values": [vp, pp],
         "gbrs_em_prepare": [vp, dbl],
         "gbrs_em_step": [vp, i32, C.POINTER(dbl)],
         "gbrs_em_run": [vp, i32, dbl, i32, C.POINTER(i32), vp, i32, vp],
@@ -122,6 +125,8 @@ def load():
         "gbrs_compress_get": [vp, pp, pp, vp],
         "gbrs_compress_destroy": [vp],
         "gbrs_format_double": [dbl, C.c_char_p],
+        "gbrs_decode_chunks": [C.c_char_p, i64, vp, vp, vp, vp, u64, u32, u64, i32, i32, vp, i32],
+        "gbrs_inflate_backend": [],
         "gbrs_parse_length_table": [C.c_char_p, i64, C.c_char_p, vp, i64, C.c_char_p, vp, i32, dbl, vp],
         "gbrs_write_locus_table": [C.c_char_p, C.c_char_p, vp, i64, i32, i64, i64, vp, C.c_char_p, vp, C.c_char_p, vp, vp],
     }
@@ -167,3 +172,20 @@ def raw_table(addresses):
     for i, a in enumerate(addresses):
         tab[i] = a
     return tab
+
+
+def warm_up_device_async():
+    """Start the HIP runtime (library load, hipInit, device context: ~0.15-0.3 s in a fresh process) on a
+    background thread so that it overlaps with reading the input files; ctypes releases the GIL during
+    the call.  Returns the thread (join() is optional: the first real call blocks on the runtime's own
+    initialisation lock anyway)."""
+    import threading
+
+    def _go():
+        try:
+            load().gbrs_device_count()
+        except Exception:      # noqa: BLE001 - the foreground call will report the problem
+            pass
+    t = threading.Thread(target=_go, name='gbrs-hip-init', daemon=True)
+    t.start()
+    return t

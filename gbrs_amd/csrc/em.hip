@@ -346,6 +346,34 @@ csc_acc_kernel(uint64_t n, uint32_t ncols, uint32_t L, uint32_t H,
     }
 }
 
+// Stored alignment values (files saved with incidence_only = False, legacy COO files): EMfactory.prepare
+// normalises them per read and sums them per column (EMfactory.py:95-98), once; every later E-step
+// starts from ones again (Sparse3DMatrix.reset).  den[r] = sum of the row's values, then
+// acc[l][h] += count[r] * value / den[r].
+__global__ void __launch_bounds__(256)
+csc_den_values_kernel(uint64_t n, const uint32_t *__restrict__ ent_row, const double *__restrict__ vals,
+                      double *__restrict__ den) {
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) atomicAdd(&den[ent_row[k]], vals[k]);
+}
+
+__global__ void __launch_bounds__(256)
+csc_acc_values_kernel(uint64_t n, uint32_t ncols, uint32_t L, uint32_t H, const uint64_t *__restrict__ col_ptr,
+                      const uint32_t *__restrict__ ent_row, const double *__restrict__ vals,
+                      const double *__restrict__ count, const double *__restrict__ den, double *__restrict__ acc,
+                      int *__restrict__ bad) {
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k - (threadIdx.x & 63) >= n) return;
+    const bool live = k < n;
+    const uint32_t c = entry_column(col_ptr, ncols, live ? k : n - 1, n);
+    if (!live) return;
+    const uint32_t r = ent_row[k];
+    const double d = den[r];
+    if (!(d > 0.0) || !(vals[k] >= 0.0)) { *bad = 1; return; }
+    const uint32_t h = c / L, l = c - h * L;
+    atomicAdd(&acc[(size_t)l * H + h], (count ? count[r] : 1.0) * vals[k] / d);
+}
+
 // largest row id of the uploaded arrays (inputs that arrive as device pointers cannot be checked on
 // the host, and an out-of-range id would make the scatter kernels fault)
 __global__ void __launch_bounds__(256)
@@ -398,6 +426,8 @@ struct gbrs_em {
     DevBuf<double> den;           // R
 
     DevBuf<double> count, eff_len;                 // R ; L*H locus-major
+    DevBuf<double> acc_init;                       // L*H: prepare()'s column sums when the file stores values
+    bool has_init = false, keep_csc = false;
     DevBuf<double> theta, acc, counts;             // L*H locus-major
     DevBuf<double> tot_prev, tot_new;              // L
     DevBuf<double> partials;                       // 3 * RED_BLOCKS (pseudocount reductions)
@@ -946,9 +976,13 @@ int em_create_impl(uint64_t R, uint32_t L, uint32_t H, const uint32_t *const *in
                                    em->stream));
         em->layout = 1;
         stg.mark("build_tile_layout");
-        // the CSC copy and the per-row denominators are only needed by layout 0
-        em->ent_row.release();
-        em->den.release();
+        // the CSC copy and the per-row denominators are only needed by layout 0 (and, until
+        // gbrs_em_set_initial_values has run, when the caller announced stored values)
+        em->keep_csc = (flags & GBRS_EM_KEEP_CSC) != 0;
+        if (!em->keep_csc) {
+            em->ent_row.release();
+            em->den.release();
+        }
         stg.mark("release csc copy");
     }
     guard.p = nullptr;
@@ -1044,9 +1078,63 @@ namespace {
 int em_prepare_partial(gbrs_em *em) {
     GBRS_TRY(select_device(em->device));
     GBRS_TRY(em_reset_scalars(em, false));
+    if (em->has_init) {                       // stored alignment values: their normalised column sums
+        GBRS_HIP_CHECK(hipMemcpyAsync(em->acc.p, em->acc_init.p, em->acc.bytes(), hipMemcpyDeviceToDevice, em->stream));
+        em->acc_needs_extra = false;
+        return GBRS_OK;
+    }
     return em_estep<true>(em, true);
 }
 }  // namespace
+
+int gbrs_em_set_initial_values(gbrs_em_t *em, const double *const *values) {
+    if (!em || !values) return fail(GBRS_ERR_INVALID, "NULL argument");
+    if (!em->ent_row.p || !em->den.p)
+        return fail(GBRS_ERR_STATE, "the handle no longer holds the CSC arrays: create it with GBRS_EM_KEEP_CSC "
+                                    "and call gbrs_em_set_initial_values once, before prepare");
+    GBRS_TRY(select_device(em->device));
+    const uint64_t n = em->N;
+    const size_t LH = (size_t)em->L * em->H;
+    GBRS_TRY(em->acc_init.alloc(LH));
+    GBRS_HIP_CHECK(hipMemsetAsync(em->acc_init.p, 0, em->acc_init.bytes(), em->stream));
+    if (n) {
+        DevBuf<double> vals;
+        DevBuf<int> bad;
+        GBRS_TRY(vals.alloc(n));
+        GBRS_TRY(bad.alloc(1));
+        std::vector<uint64_t> cp((size_t)em->H * em->L + 1);
+        GBRS_HIP_CHECK(hipMemcpy(cp.data(), em->col_ptr.p, cp.size() * 8, hipMemcpyDeviceToHost));
+        for (uint32_t h = 0; h < em->H; ++h) {
+            const uint64_t b = cp[(size_t)h * em->L], cnt = cp[(size_t)(h + 1) * em->L] - b;
+            if (!cnt) continue;
+            if (!values[h]) return fail(GBRS_ERR_INVALID, "values[%u] is NULL", h);
+            GBRS_HIP_CHECK(hipMemcpy(vals.p + b, values[h], cnt * sizeof(double), hipMemcpyHostToDevice));
+        }
+        GBRS_HIP_CHECK(hipMemsetAsync(bad.p, 0, sizeof(int), em->stream));
+        GBRS_HIP_CHECK(hipMemsetAsync(em->den.p, 0, em->den.bytes(), em->stream));
+        const unsigned grid = (unsigned)((n + 255) / 256);
+        hipLaunchKernelGGL(csc_den_values_kernel, dim3(grid), dim3(256), 0, em->stream, n, em->ent_row.p, vals.p, em->den.p);
+        hipLaunchKernelGGL(csc_acc_values_kernel, dim3(grid), dim3(256), 0, em->stream, n, em->H * em->L, em->L, em->H,
+                           em->col_ptr.p, em->ent_row.p, vals.p, em->has_count ? em->count.p : (const double *)nullptr,
+                           em->den.p, em->acc_init.p, bad.p);
+        int hbad = 0;
+        GBRS_HIP_CHECK(hipMemcpyAsync(&hbad, bad.p, sizeof(int), hipMemcpyDeviceToHost, em->stream));
+        GBRS_HIP_CHECK(hipStreamSynchronize(em->stream));
+        GBRS_HIP_CHECK(hipGetLastError());
+        if (hbad) {
+            em->acc_init.release();
+            return fail(GBRS_ERR_FLOAT, "invalid value encountered in divide (a read's stored alignment values are "
+                                        "negative or add up to zero)");
+        }
+    }
+    em->has_init = true;
+    if (em->layout == 1 && em->keep_csc) {     // the tiled layout needs neither array from here on
+        em->ent_row.release();
+        em->den.release();
+        em->keep_csc = false;
+    }
+    return GBRS_OK;
+}
 
 int gbrs_em_prepare_partial(gbrs_em_t *em, void **partial_dev, uint64_t *n_elems) {
     if (!em) return fail(GBRS_ERR_INVALID, "handle is NULL");

@@ -866,11 +866,15 @@ int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L, uint32_t H, uint6
     DevBuf<uint32_t> pflag, pidx;
     GBRS_TRY(pflag.alloc(N));
     GBRS_TRY(pidx.alloc(N));
+    stg.mark("2a alloc flags");
     hipLaunchKernelGGL(pair_flag_kernel, dim3(grid_for(N)), dim3(256), 0, s, N, keys2.p, pflag.p, d_flags.p);
+    stg.mark("2b pair flags");
     GBRS_TRY(exclusive_scan(sc, pflag.p, pidx.p, N, s));
+    stg.mark("2c scan");
     uint32_t P32 = 0;
     GBRS_TRY(fetch_last_plus(pidx.p, pflag.p, N, P32, s));
     GBRS_TRY(read_flags());
+    stg.mark("2d fetch");
     if (hf.bad_row) return fail(GBRS_ERR_INVALID, "indices hold a row id >= num_rows");
     if (hf.duplicate) return fail(GBRS_ERR_INVALID, "duplicate (row, locus, haplotype) entry: the CSC arrays must be canonical");
     const uint64_t P = P32;
@@ -882,8 +886,9 @@ int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L, uint32_t H, uint6
     hipLaunchKernelGGL(emit_pairs_kernel, dim3(grid_for(N)), dim3(256), 0, s, N, keys2.p, pflag.p, pidx.p, row_shift,
                        prow.p, ploc.p, pmask.p);
     GBRS_HIP_CHECK(hipStreamSynchronize(s));
+    stg.mark("2e emit pairs");
     keys2.release(); pflag.release(); pidx.release();
-    stg.mark("2 pairs");
+    stg.mark("2 pairs (release)");
     // 3. rows
     DevBuf<uint32_t> rflag, ridx;
     GBRS_TRY(rflag.alloc(P));
@@ -1001,14 +1006,18 @@ int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L, uint32_t H, uint6
             gflag.release(); gpos.release();
         }
         GBRS_TRY(ikey.alloc(M)); GBRS_TRY(ikey2.alloc(M)); GBRS_TRY(ident.alloc(M)); GBRS_TRY(perm.alloc(M));
+        stg.mark("7b-a alloc");
         if (interleave)
             hipLaunchKernelGGL(interleave_key_kernel, dim3(grid_for(M)), dim3(256), 0, s, M, tincl.p, gstart.p, gord.p,
                                ikey.p, ident.p);
         else
             hipLaunchKernelGGL(stream_key_kernel, dim3(grid_for(M)), dim3(256), 0, s, M, tincl.p, npm.p, ikey.p, ident.p);
+        stg.mark("7b-b keys");
         GBRS_TRY(sort_pairs<uint64_t>(sc, ikey.p, ikey2.p, ident.p, perm.p, M, 40 + bits_for(T), s));
         GBRS_HIP_CHECK(hipStreamSynchronize(s));
+        stg.mark("7b-c sort");
         ikey.release(); ikey2.release(); ident.release(); gstart.release(); gord.release();
+        stg.mark("7b-d release");
         GBRS_TRY(hrow2.alloc(M)); GBRS_TRY(npm2.alloc(M));
         if (out.weighted) GBRS_TRY(weight2.alloc(M));
         hipLaunchKernelGGL(permute_rows_kernel, dim3(grid_for(M)), dim3(256), 0, s, M, perm.p, hrow.p, npm.p,

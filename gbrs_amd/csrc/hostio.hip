@@ -1,11 +1,18 @@
-// Host-side text output of the quantify reports (no device code): `locus <haplotypes> total [notes]`
+// Host-side file I/O helpers (no device code): report text, the length table, HDF5 chunk decoding.
+//
+// Text output of the quantify reports: `locus <haplotypes> total [notes]`
 // tables with every number in its shortest round-trip form, i.e. exactly what str(numpy.float64) /
 // repr(float) print in the reference's writers (emase/EMfactory.py:289-380).  At 120k isoforms + 48k
 // genes the four reports hold 1.5 M numbers; formatting them in the interpreter took ~1 s per sample,
 // as long as everything else of `gbrs quantify` on the device path together.
 #include "common.h"
 
+#include <dlfcn.h>
+#include <fcntl.h>
+#include <unistd.h>
+
 #include <algorithm>
+#include <atomic>
 #include <charconv>
 #include <cmath>
 #include <cstdio>
@@ -77,7 +84,142 @@ static int format_repr(double v, char *out) {
 
 }  // namespace gbrs
 
+// ---- parallel decode of HDF5 chunks (deflate [+ byte shuffle]) ------------------------------------------
+namespace gbrs {
+
+typedef int (*uncompress_fn)(unsigned char *, unsigned long *, const unsigned char *, unsigned long);
+typedef void *(*ld_alloc_fn)(void);
+typedef void (*ld_free_fn)(void *);
+typedef int (*ld_inflate_fn)(void *, const void *, size_t, void *, size_t, size_t *);
+
+struct Inflaters {
+    uncompress_fn z_uncompress = nullptr;
+    ld_alloc_fn ld_alloc = nullptr;
+    ld_free_fn ld_free = nullptr;
+    ld_inflate_fn ld_inflate = nullptr;
+    Inflaters() {
+        // libdeflate (about three times zlib's inflate speed) when the machine has it, zlib otherwise;
+        // both are looked up at run time so the library has no link-time dependency on either
+        const char *ld_names[] = {std::getenv("GBRS_LIBDEFLATE"), "libdeflate.so.0", "libdeflate.so", "/opt/conda/lib/libdeflate.so.0"};
+        for (const char *n : ld_names) {
+            if (!n || !*n) continue;
+            if (void *h = dlopen(n, RTLD_NOW | RTLD_LOCAL)) {
+                ld_alloc = (ld_alloc_fn)dlsym(h, "libdeflate_alloc_decompressor");
+                ld_free = (ld_free_fn)dlsym(h, "libdeflate_free_decompressor");
+                ld_inflate = (ld_inflate_fn)dlsym(h, "libdeflate_zlib_decompress");
+                if (ld_alloc && ld_free && ld_inflate) break;
+                ld_alloc = nullptr; ld_free = nullptr; ld_inflate = nullptr;
+            }
+        }
+        const char *z_names[] = {"libz.so.1", "libz.so", "/opt/conda/lib/libz.so.1"};
+        for (const char *n : z_names)
+            if (void *h = dlopen(n, RTLD_NOW | RTLD_LOCAL)) {
+                z_uncompress = (uncompress_fn)dlsym(h, "uncompress");
+                if (z_uncompress) break;
+            }
+    }
+};
+
+static const Inflaters &inflaters() {
+    static const Inflaters inf;
+    return inf;
+}
+
+}  // namespace gbrs
+
 extern "C" {
+
+// 1 = libdeflate, 2 = zlib, 0 = neither could be loaded
+int gbrs_inflate_backend(void) {
+    const gbrs::Inflaters &inf = gbrs::inflaters();
+    return inf.ld_inflate ? 1 : (inf.z_uncompress ? 2 : 0);
+}
+
+int gbrs_decode_chunks(const char *path, int64_t n_chunks, const uint64_t *file_addr, const uint64_t *stored_bytes,
+                       const uint64_t *elem_start, const uint32_t *filter_mask, uint64_t chunk_elems,
+                       uint32_t elem_size, uint64_t n_elems, int32_t shuffle_pos, int32_t deflate_pos, void *out,
+                       int32_t threads) {
+    using gbrs::fail;
+    if (!path || !out || n_chunks < 0 || (n_chunks && (!file_addr || !stored_bytes || !elem_start || !filter_mask)) ||
+        chunk_elems == 0 || elem_size == 0 || elem_size > 16)
+        return fail(GBRS_ERR_INVALID, "bad argument");
+    const gbrs::Inflaters &inf = gbrs::inflaters();
+    if (deflate_pos >= 0 && !inf.ld_inflate && !inf.z_uncompress)
+        return fail(GBRS_ERR_UNSUPPORTED, "neither libdeflate nor zlib could be loaded");
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return fail(GBRS_ERR_INVALID, "cannot open %s", path);
+    for (int64_t k = 0; k < n_chunks; ++k)
+        if (elem_start[k] >= n_elems && n_elems) { close(fd); return fail(GBRS_ERR_INVALID, "chunk %lld starts outside the dataset", (long long)k); }
+    unsigned nt = threads > 0 ? (unsigned)threads : std::thread::hardware_concurrency();
+    if (const char *e = std::getenv("GBRS_IO_THREADS"); threads <= 0 && e && std::atoi(e) > 0) nt = (unsigned)std::atoi(e);
+    nt = std::max(1u, std::min({nt, 64u, (unsigned)std::max<int64_t>(n_chunks, 1)}));
+    const size_t chunk_bytes = (size_t)chunk_elems * elem_size;
+    std::atomic<int64_t> next{0};
+    std::atomic<int> failed{0};
+    auto work = [&]() {
+        std::vector<unsigned char> raw, plain(chunk_bytes);
+        void *ld = inf.ld_inflate ? inf.ld_alloc() : nullptr;
+        for (;;) {
+            const int64_t k = next.fetch_add(1);
+            if (k >= n_chunks || failed.load()) break;
+            raw.resize(stored_bytes[k]);
+            size_t got = 0;
+            while (got < raw.size()) {
+                const ssize_t r = pread(fd, raw.data() + got, raw.size() - got, (off_t)(file_addr[k] + got));
+                if (r <= 0) { failed = 1; break; }
+                got += (size_t)r;
+            }
+            if (failed.load()) break;
+            const uint64_t count = std::min<uint64_t>(chunk_elems, n_elems - elem_start[k]);
+            unsigned char *dst = (unsigned char *)out + (size_t)elem_start[k] * elem_size;
+            // filters were applied in pipeline order when the chunk was written (shuffle, then deflate):
+            // undo them back to front; a set bit p in the chunk's mask means filter p was skipped
+            const unsigned char *cur = raw.data();
+            size_t cur_bytes = raw.size();
+            if (deflate_pos >= 0 && !(filter_mask[k] & (1u << deflate_pos))) {
+                bool ok = false;
+                if (ld) {
+                    size_t n = 0;
+                    ok = inf.ld_inflate(ld, cur, cur_bytes, plain.data(), chunk_bytes, &n) == 0 && n == chunk_bytes;
+                }
+                if (!ok && inf.z_uncompress) {
+                    unsigned long n = (unsigned long)chunk_bytes;
+                    ok = inf.z_uncompress(plain.data(), &n, cur, (unsigned long)cur_bytes) == 0 && n == chunk_bytes;
+                }
+                if (!ok) { failed = 2; break; }
+                cur = plain.data();
+                cur_bytes = chunk_bytes;
+            }
+            if (cur_bytes < chunk_bytes) { failed = 3; break; }
+            if (shuffle_pos >= 0 && !(filter_mask[k] & (1u << shuffle_pos))) {
+                // byte plane b of the chunk holds byte b of every element
+                if (elem_size == 4) {
+                    const unsigned char *p0 = cur, *p1 = cur + chunk_elems, *p2 = cur + 2 * chunk_elems, *p3 = cur + 3 * chunk_elems;
+                    uint32_t *d = (uint32_t *)dst;
+                    for (uint64_t i = 0; i < count; ++i)
+                        d[i] = (uint32_t)p0[i] | ((uint32_t)p1[i] << 8) | ((uint32_t)p2[i] << 16) | ((uint32_t)p3[i] << 24);
+                } else {
+                    for (uint64_t i = 0; i < count; ++i)
+                        for (uint32_t b = 0; b < elem_size; ++b) dst[i * elem_size + b] = cur[(size_t)b * chunk_elems + i];
+                }
+            } else {
+                std::memcpy(dst, cur, (size_t)count * elem_size);
+            }
+        }
+        if (ld) inf.ld_free(ld);
+    };
+    {
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < nt; ++t) th.emplace_back(work);
+        work();
+        for (auto &x : th) x.join();
+    }
+    close(fd);
+    if (failed.load() == 1) return fail(GBRS_ERR_INVALID, "short read from %s", path);
+    if (failed.load() == 2) return fail(GBRS_ERR_INVALID, "a chunk of %s does not inflate to the chunk size", path);
+    if (failed.load() == 3) return fail(GBRS_ERR_INVALID, "a chunk of %s is shorter than the chunk size", path);
+    return GBRS_OK;
+}
 
 int gbrs_format_double(double v, char *out32) {
     if (!out32) return gbrs::fail(GBRS_ERR_INVALID, "out is NULL");

@@ -47,9 +47,15 @@ class EMfactory:
         if self.target_lengths is not None:
             eff = np.ascontiguousarray(self.target_lengths, dtype=np.float64)
         cnt = None if apm.count is None else np.ascontiguousarray(apm.count, dtype=np.float64)
+        vals = getattr(apm, 'values', None)
+        flags = self.flags | (_lib.GBRS_EM_KEEP_CSC if vals is not None else 0)
         _lib.check(lib.gbrs_em_create(R, L, H, tab_p, tab_i, _lib.ptr(cnt), _lib.ptr(eff),
-                                      self.device, self.flags, C.byref(h)))
+                                      self.device, flags, C.byref(h)))
         self._h = h
+        if vals is not None:
+            # the file stores alignment values: they fix the starting point (EMfactory.py:95-98)
+            vals = [np.ascontiguousarray(v, dtype=np.float64) for v in vals]
+            _lib.check(lib.gbrs_em_set_initial_values(h, _lib.ptr_table(vals)))
 
     def close(self):
         if self._h is not None:

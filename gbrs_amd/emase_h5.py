@@ -246,6 +246,30 @@ def _read_chunks_parallel(path, d, ftype, space):
             return None
         todo.append((int(off[0]), int(fmask.value), int(addr.value), int(csize.value)))
     out = np.zeros(n, dtype=dt)            # chunks that were never written read as the fill value 0
+    try:
+        from . import _lib as _native
+        lib_native = _native.load()
+    except ImportError:
+        lib_native = None
+    if lib_native is not None:
+        # pread + inflate + un-shuffle on C++ threads straight into `out` (libgbrs_hip's host-side helper)
+        tab = np.array(todo, dtype=np.uint64).reshape(len(todo), 4)
+        start = np.ascontiguousarray(tab[:, 0])
+        mask = np.ascontiguousarray(tab[:, 1].astype(np.uint32))
+        addr = np.ascontiguousarray(tab[:, 2])
+        stored = np.ascontiguousarray(tab[:, 3])
+        pos = {f: k for k, f in enumerate(filters)}
+        _native.check(lib_native.gbrs_decode_chunks(
+            os.fsencode(path), len(todo), _native.ptr(addr), _native.ptr(stored), _native.ptr(start), _native.ptr(mask),
+            chunk, size, n, pos.get(H5Z_FILTER_SHUFFLE, -1), pos.get(H5Z_FILTER_DEFLATE, -1), _native.ptr(out),
+            int(os.environ.get('GBRS_IO_THREADS', 0))))
+        return out
+    return _decode_chunks_python(path, todo, filters, chunk, size, n, out)
+
+
+def _decode_chunks_python(path, todo, filters, chunk, size, n, out):
+    """The same decode on a Python thread pool (zlib / ctypes release the GIL): used when the native
+    library is not built."""
     raw_view = out.view(np.uint8)
     _, inflate = _inflater()
     fd = os.open(path, os.O_RDONLY)

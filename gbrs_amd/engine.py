@@ -45,6 +45,12 @@ class EmEngine:
                                              device, flags, C.byref(h)))
         return cls(h, (L, H, R))
 
+    def set_initial_values(self, values):
+        """Per-entry stored values (aligned with the indices given to from_host, which must have been
+        called with GBRS_EM_KEEP_CSC): prepare() then starts from their per-read normalisation."""
+        vals = [np.ascontiguousarray(v, dtype=np.float64) for v in values]
+        _lib.check(_lib.load().gbrs_em_set_initial_values(self._h, _lib.ptr_table(vals)))
+
     def close(self):
         if self._h is not None:
             _lib.load().gbrs_em_destroy(self._h)

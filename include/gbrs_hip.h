@@ -81,6 +81,9 @@ typedef struct gbrs_em gbrs_em_t;
  * err_sum lands next to 1e6*tol (EMfactory.py:266).  The tiles are cut smaller (at most
  * (4160/8 - 1)/H loci each); not available with GBRS_EM_LAYOUT_CSC or H > 16. */
 #define GBRS_EM_DETERMINISTIC 32u
+/* Keep the uploaded CSC arrays on the handle until gbrs_em_set_initial_values has run (files that
+ * store alignment values other than 1). */
+#define GBRS_EM_KEEP_CSC 64u
 
 /*
  * Replaces: AlignmentPropertyMatrix(h5file=...) as consumed by EMfactory.__init__
@@ -106,6 +109,14 @@ int gbrs_em_create_device(uint64_t num_rows, uint32_t num_loci, uint32_t num_hap
                           const uint32_t *const *indptr, const uint32_t *const *indices,
                           const double *count, const double *eff_len,
                           int device, uint32_t flags, gbrs_em_t **out);
+
+/* Stored alignment values (an EMASE file saved with incidence_only = False, or a legacy COO file:
+ * emase/Sparse3DMatrix.py:84-88, :93-99): values[h] double[nnz_h], aligned with indices[h] as given to
+ * create.  EMfactory.prepare normalises them per read and that is all they are used for
+ * (EMfactory.py:95-98; every E-step starts again from ones, Sparse3DMatrix.py:220-228), so this call
+ * computes prepare()'s column sums from them once; prepare then uses those instead of 1/nnz_row.
+ * Needs GBRS_EM_KEEP_CSC at create; call it once, before gbrs_em_prepare*. */
+int gbrs_em_set_initial_values(gbrs_em_t *em, const double *const *values);
 
 /* Replaces EMfactory.prepare (EMfactory.py:95-111): theta0 = sum_r count[r]/nnz_row / eff_len,
  * then the optional pseudocount rule (:105-111). */
@@ -306,6 +317,18 @@ int gbrs_write_locus_table(const char *path, const char *header_line, const doub
                            int32_t n_cols, int64_t row_stride, int64_t col_stride, const double *totals,
                            const char *names, const int64_t *name_off, const char *notes,
                            const int64_t *note_off, const int64_t *order);
+
+/* HDF5 chunk decoding for the EMASE reader (emase/Sparse3DMatrix.py:80-92 reads the h<k>/indices arrays through
+ * PyTables one array at a time): the chunks of a 1-D dataset, located by the caller with
+ * H5Dget_chunk_info (file address, stored size, first element, filter mask), are read with pread and
+ * inflated (+ un-shuffled) on `threads` threads (0 = all cores) straight into `out`.  shuffle_pos /
+ * deflate_pos are the positions of those filters in the dataset's pipeline, -1 when absent. */
+int gbrs_decode_chunks(const char *path, int64_t n_chunks, const uint64_t *file_addr, const uint64_t *stored_bytes,
+                       const uint64_t *elem_start, const uint32_t *filter_mask, uint64_t chunk_elems,
+                       uint32_t elem_size, uint64_t n_elems, int32_t shuffle_pos, int32_t deflate_pos, void *out,
+                       int32_t threads);
+/* 1 = libdeflate, 2 = zlib, 0 = neither could be loaded at run time. */
+int gbrs_inflate_backend(void);
 
 /* The length table of EMfactory.prepare (emase/EMfactory.py:60-94) parsed natively: text is the whole
  * file (`<locus>_<haplotype> TAB <length>` lines, plain `<locus>` keys when n_haps == 1), names / haps

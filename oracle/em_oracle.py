@@ -32,12 +32,14 @@ import numpy as np
 
 
 class EMOracle:
-    def __init__(self, num_rows, num_loci, num_haps, indptr, indices, count=None):
+    def __init__(self, num_rows, num_loci, num_haps, indptr, indices, count=None, values=None):
         self.R, self.L, self.H = int(num_rows), int(num_loci), int(num_haps)
         self.indptr = [np.asarray(p).astype(np.int64) for p in indptr]
         self.indices = [np.asarray(i).astype(np.int64) for i in indices]
         self.count = None if count is None else np.asarray(count, dtype=np.float64)
-        self.values = [np.ones(len(i), dtype=np.float64) for i in self.indices]
+        # stored values of a file saved with incidence_only=False (Sparse3DMatrix.py:84-88); ones otherwise
+        self.values = [np.ones(len(i), dtype=np.float64) for i in self.indices] if values is None else \
+            [np.array(v, dtype=np.float64) for v in values]
         self.theta = None            # allelic_expression (H x L)
         self.eff_len = None          # target_lengths (H x L) or None
         self.err_history = []

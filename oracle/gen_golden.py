@@ -56,12 +56,12 @@ def beq(a, b, what):
 
 # ----------------------------------------------------------------------------- EM
 
-def ref_apm_from(inc, grpfile):
+def ref_apm_from(inc, grpfile, values=None):
     apm = RefAPM(shape=(inc.num_loci, inc.num_haps, inc.num_rows),
                  haplotype_names=inc.hap_names, locus_names=inc.locus_names, grpfile=grpfile)
     for h in range(inc.num_haps):
         apm.data[h] = sp.csc_matrix(
-            (np.ones(len(inc.indices[h])), inc.indices[h].astype(np.int64),
+            (np.ones(len(inc.indices[h])) if values is None else values[h].copy(), inc.indices[h].astype(np.int64),
              inc.indptr[h].astype(np.int64)), shape=(inc.num_rows, inc.num_loci))
     apm.finalized = True
     if inc.count is not None:
@@ -70,7 +70,7 @@ def ref_apm_from(inc, grpfile):
 
 
 def em_case(name, R, H, L, seed, with_count, with_len, pseudocount, mask, tol, max_iters,
-            drop_rows=0):
+            drop_rows=0, with_values=False):
     inc = synth.make_em_problem(R=R, H=H, L=L, seed=seed, with_count=with_count, max_count=5)
     if drop_rows:
         # make some rows empty (no alignment at all) - reads that the aligner dropped
@@ -98,8 +98,14 @@ def em_case(name, R, H, L, seed, with_count, with_len, pseudocount, mask, tol, m
                 else:
                     fh.write(f"{inc.locus_names[l]}\t{int(inc.raw_length[l])}\n")
 
-    apm = ref_apm_from(inc, grpfile)
-    orc = EMOracle(R, L, H, inc.indptr, inc.indices, inc.count)
+    values = None
+    if with_values:
+        # what a file saved with incidence_only=False (or a legacy COO file) carries: the matrices arrive in
+        # EMfactory with values other than 1, and prepare() normalises them (EMfactory.py:95-98)
+        rng = np.random.default_rng(seed + 3)
+        values = [rng.random(len(ix)) + 0.25 for ix in inc.indices]
+    apm = ref_apm_from(inc, grpfile, values)
+    orc = EMOracle(R, L, H, inc.indptr, inc.indices, inc.count, values=values)
     gtmask = None
     if mask:
         # a called diplotype per gene: two haplotypes (possibly equal) kept, rest masked out
@@ -130,7 +136,7 @@ def em_case(name, R, H, L, seed, with_count, with_len, pseudocount, mask, tol, m
     # the reference's run() has no per-iteration hook: re-run it with max_iters = k for snapshots
     snaps = {}
     for k in SNAP_ITERS:
-        apm_k = ref_apm_from(inc, grpfile)
+        apm_k = ref_apm_from(inc, grpfile, values)
         if mask:
             apm_k.multiply(gtmask, axis=2)
             for h in range(H):
@@ -189,6 +195,8 @@ def em_case(name, R, H, L, seed, with_count, with_len, pseudocount, mask, tol, m
     for h in range(H):
         out[f"indptr{h}"] = inc.indptr[h]
         out[f"indices{h}"] = inc.indices[h]
+        if values is not None:
+            out[f"values{h}"] = values[h]
     assert n_it == len(orc.err_history)
     np.savez_compressed(os.path.join(GOLD, f"em_{name}.npz"), **out)
     print(f"em_{name}: R={R} H={H} L={L} nnz={inc.nnz} iters={n_it} "
@@ -404,6 +412,8 @@ def main():
                 drop_rows=150)
         em_case("h16_len",       2000, 16, 70, 20,   True,  True,  0.0, False, 1e-4, 999)
         em_case("h8_maxiter",    2000, 8, 100, 21,   False, True,  0.0, False, 0.0,  7)
+        em_case("h8_values",     1800, 8, 90,  22,   True,  True,  0.0, False, 1e-4, 999, with_values=True)
+        em_case("h2_values_pc",  1500, 2, 60,  23,   False, True,  0.5, False, 1e-4, 999, with_values=True)
         hmm_case("h8_full", 8, [40, 25, 33], 31, False)
         hmm_case("h8_short", 8, [40, 25, 33], 32, True)
         hmm_case("h4_full", 4, [30, 12], 33, False)

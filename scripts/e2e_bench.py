@@ -48,8 +48,11 @@ def write_support_files(workdir, L, H, gene_starts, eff_len_row):
     return lname, hname, gname, grp, lens
 
 
-def build_sample(workdir, rows, haps, loci, fmt):
-    """The full-size sample as alignment file(s) + support files.  Returns a dict of paths and sizes."""
+def build_sample(workdir, rows, haps, loci, fmt, cpu_rows):
+    """Child-process body (`--make-sample`): the full-size sample from the bench generator as alignment
+    file(s) + support files, and the row subsample for the one-core baseline.  Runs in a process of its own
+    so that the measuring parent never opens the GPU: a second process holding a device context slows every
+    large hipMalloc / hipFree of the measured one (layout build 87 -> 410 ms on this pool)."""
     import numpy as np
     import torch
     from gbrs_amd import synth, synth_torch
@@ -66,7 +69,7 @@ def build_sample(workdir, rows, haps, loci, fmt):
     lname, hname, gname, grp, lens = write_support_files(workdir, loci, haps, gene_starts, eff[0])
     apm = AlignmentPropertyMatrix(shape=(loci, haps, rows), indptr=ip, indices=ix, haplotype_names=hname,
                                   locus_names=lname)
-    out = dict(group_file=grp, length_file=lens, N=N, genes=gname, files={}, write_s={})
+    out = dict(group_file=grp, length_file=lens, N=N, files={}, write_s={})
     if fmt in ("h5", "both"):
         t1 = time.perf_counter()
         p = os.path.join(workdir, "sample.h5")
@@ -80,8 +83,21 @@ def build_sample(workdir, rows, haps, loci, fmt):
         out["files"]["npz"] = p
         out["write_s"]["npz"] = time.perf_counter() - t1
     out["bytes"] = {k: os.path.getsize(v) for k, v in out["files"].items()}
+    if cpu_rows:
+        out["cpu_sub"], out["cpu_sub_entries"] = write_cpu_subsample(workdir, (ip, ix, eff, lname, hname),
+                                                                     min(cpu_rows, rows), loci, haps)
     out["build_s"] = time.perf_counter() - t0
-    return out, (ip, ix, eff, lname, hname)
+    return out
+
+
+def build_sample_in_child(workdir, rows, haps, loci, fmt, cpu_rows):
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--make-sample", "--workdir", workdir,
+                        "--rows", str(rows), "--haps", str(haps), "--loci", str(loci), "--format", fmt,
+                        "--cpu-rows", str(cpu_rows)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                       env=dict(os.environ, PYTHONPATH=ROOT))
+    if r.returncode != 0:
+        raise RuntimeError(f"sample generation failed: {r.stderr[-2000:]}")
+    return json.loads(r.stdout.strip().split("\n")[-1])
 
 
 def write_cpu_subsample(workdir, arrays, rows_sub, loci, haps):
@@ -177,7 +193,7 @@ def measure(rows=40_000_000, haps=8, loci=120_000, fmt="h5", cpu_rows=2_000_000,
     res = dict(workload=f"configs[1]/[2]: R={rows} reads x H={haps} x L={loci} isoforms from file, quantify "
                         "(Model 4, tol 1e-4, 4 reports) then reconstruct on its genes.tpm (20 chromosomes)")
     try:
-        sample, arrays = build_sample(workdir, rows, haps, loci, fmt)
+        sample = build_sample_in_child(workdir, rows, haps, loci, fmt, cpu_rows if with_cpu else 0)
         res["sample"] = dict(entries=sample["N"], file_bytes=sample["bytes"], write_s=sample["write_s"])
         res["quantify"] = {}
         for kind, path in sample["files"].items():
@@ -203,8 +219,7 @@ def measure(rows=40_000_000, haps=8, loci=120_000, fmt="h5", cpu_rows=2_000_000,
         qbest = min(v["wall_s"] for v in res["quantify"].values())
         res["total_wall_s"] = qbest + res["reconstruct"]["wall_s"]
         if with_cpu:
-            sub, n_sub = write_cpu_subsample(workdir, arrays, min(cpu_rows, rows), loci, haps)
-            del arrays
+            sub, n_sub = sample["cpu_sub"], sample["cpu_sub_entries"]
             wq, tq = run_oracle(["quantify", sub, sample["group_file"], sample["length_file"],
                                  os.path.join(workdir, "cpu")])
             wr, tr = run_oracle(["reconstruct", os.path.join(workdir, "cpu.multiway.genes.tpm"), rec["tprob"],
@@ -243,9 +258,13 @@ def main():
     ap.add_argument("--keep", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--repeats", type=int, default=2)
+    ap.add_argument("--make-sample", action="store_true", help="(internal) child process that writes the sample files")
     a = ap.parse_args()
+    if a.make_sample:
+        print(json.dumps(build_sample(a.workdir, a.rows, a.haps, a.loci, a.format, a.cpu_rows)), flush=True)
+        return
     import __graft_entry__
-    __graft_entry__.build()
+    __graft_entry__.build()                       # hipcc only: the parent never opens the GPU
     out = measure(a.rows, a.haps, a.loci, a.format, a.cpu_rows, a.workdir, a.keep, a.repeats, not a.no_cpu)
     print(json.dumps(out), flush=True)
 

@@ -37,6 +37,12 @@ def em_case_inputs(g):
     return R, L, H, indptr, indices, count, eff_len, groups, gtmask
 
 
+def em_case_values(g):
+    """Stored alignment values of an em_*.npz fixture (list per haplotype), or None."""
+    H = int(g["num_haps"])
+    return [g[f"values{h}"] for h in range(H)] if "values0" in g else None
+
+
 def hmm_case_inputs(g):
     H = int(g["num_haps"])
     chroms = [str(c) for c in g["chroms"]]

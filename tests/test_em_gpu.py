@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from conftest import em_case_inputs, golden_files, load_golden
+from conftest import em_case_inputs, em_case_values, golden_files, load_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -26,7 +26,7 @@ def make_factory(g, layout="tiles"):
     R, L, H, indptr, indices, count, eff_len, groups, gtmask = em_case_inputs(g)
     apm = AlignmentPropertyMatrix(shape=(L, H, R), indptr=indptr, indices=indices, count=count,
                                   haplotype_names=[chr(65 + h) for h in range(H)],
-                                  locus_names=[f"T{l:07d}" for l in range(L)])
+                                  locus_names=[f"T{l:07d}" for l in range(L)], values=em_case_values(g))
     apm.groups = groups
     apm.gname = np.array([f"G{i:07d}" for i in range(len(groups))])
     apm.num_groups = len(groups)
@@ -179,10 +179,13 @@ def _parse_tsv(text):
     return lines[0], {l[0]: l[1:] for l in lines[1:]}
 
 
-@pytest.mark.parametrize("name,use_mask", [("h8_count_len", False), ("h8_mask", True)])
-def test_quantify_cli_files(tmp_path, name, use_mask):
-    """`gbrs quantify` end to end through the CLI: npz alignment file, group/length/genotype files
-    in, the reference's report files out (numbers within 1e-9 of the reference's text)."""
+@pytest.mark.parametrize("name,use_mask,fmt", [("h8_count_len", False, "npz"), ("h8_mask", True, "npz"),
+                                               ("h8_count_len", False, "h5"), ("h8_mask", True, "h5"),
+                                               ("h8_values", False, "h5"), ("h8_values", False, "npz")])
+def test_quantify_cli_files(tmp_path, name, use_mask, fmt):
+    """`gbrs quantify` end to end through the CLI: EMASE alignment file (PyTables-layout .h5 through
+    libhdf5 on the GPU box, or the .npz mirror; with stored values for the *_values case), group / length /
+    genotype files in, the reference's report files out (numbers within 1e-9 of the reference's text)."""
     from gbrs_amd import cli
     from gbrs_amd.alignment import AlignmentPropertyMatrix
     g = load_golden([p for p in golden_files("em") if p.endswith(f"em_{name}.npz")][0])
@@ -190,9 +193,14 @@ def test_quantify_cli_files(tmp_path, name, use_mask):
     hn = [chr(65 + h) for h in range(H)]
     ln = [f"T{l:07d}" for l in range(L)]
     apm = AlignmentPropertyMatrix(shape=(L, H, R), indptr=indptr, indices=indices, count=count,
-                                  haplotype_names=hn, locus_names=ln)
-    aln = tmp_path / "aln.npz"
-    apm.save_npz(str(aln))
+                                  haplotype_names=hn, locus_names=ln, values=em_case_values(g))
+    aln = tmp_path / f"aln.{fmt}"
+    if fmt == "h5":
+        from gbrs_amd import emase_h5
+        emase_h5._load()                       # libhdf5 must be loadable on the GPU box
+        apm.save(str(aln), incidence_only=apm.values is None)
+    else:
+        apm.save_npz(str(aln))
     grp = tmp_path / "g2t.tsv"
     with open(grp, "w") as fh:
         for i, mem in enumerate(groups):

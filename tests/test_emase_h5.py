@@ -179,11 +179,25 @@ def test_h5_parallel_chunk_decoder_matches_h5dread(tmp_path, monkeypatch):
         np.testing.assert_array_equal(c.indices[h], a.indices[h])
     np.testing.assert_array_equal(b.count, a.count)
     monkeypatch.delenv("GBRS_H5_SERIAL")
+    # the pure-Python thread-pool decoder (used when libgbrs_hip.so is not built), with libdeflate and with zlib
+    import builtins
+    real_import = builtins.__import__
+
+    def no_native(name, globals=None, locals=None, fromlist=(), level=0):
+        if level == 1 and fromlist and "_lib" in fromlist and globals and globals.get("__name__") == "gbrs_amd.emase_h5":
+            raise ImportError("native library hidden for this test")
+        return real_import(name, globals, locals, fromlist, level)
+    monkeypatch.setattr(builtins, "__import__", no_native)
+    d = load_alignment(str(p))
+    np.testing.assert_array_equal(d.indices[1], a.indices[1])
     name, _ = h5._inflater()
-    if name == "libdeflate":                                 # and once more through the zlib module
+    if name == "libdeflate":
         monkeypatch.setattr(h5, "_inflate_impl", ("zlib", lambda raw, n: __import__("zlib").decompress(raw, bufsize=n)))
         d = load_alignment(str(p))
-        np.testing.assert_array_equal(d.indices[1], a.indices[1])
+        np.testing.assert_array_equal(d.indices[0], a.indices[0])
+    monkeypatch.setattr(builtins, "__import__", real_import)
+    from gbrs_amd import _lib
+    assert _lib.load().gbrs_inflate_backend() in (1, 2)
 
 
 def test_h5_not_an_emase_file(tmp_path):

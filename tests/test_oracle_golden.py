@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from conftest import em_case_inputs, golden_files, hmm_case_inputs, load_golden, viterbi_decision_margins
+from conftest import em_case_inputs, em_case_values, golden_files, hmm_case_inputs, load_golden, viterbi_decision_margins
 from oracle import hmm_oracle
 from oracle.em_oracle import EMOracle, tpm_report_values
 
@@ -13,7 +13,7 @@ RTOL = 1e-12   # same numpy build: bit-identical here; other CPUs may differ in 
 def test_em_oracle_matches_reference_outputs(path):
     g = load_golden(path)
     R, L, H, indptr, indices, count, eff_len, groups, gtmask = em_case_inputs(g)
-    o = EMOracle(R, L, H, indptr, indices, count)
+    o = EMOracle(R, L, H, indptr, indices, count, values=em_case_values(g))
     if gtmask is not None:
         o.apply_genotype_mask(gtmask)
     o.prepare(pseudocount=float(g["pseudocount"]), eff_len=eff_len)
