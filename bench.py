@@ -56,6 +56,8 @@ def parse():
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: one engine per GPU, all-reduce not overlapped with the E-step")
     ap.add_argument("--force-overlap-path", action="store_true", help="N = 1: run the two-engine form anyway (its compute-side cost without any exchange)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo only to rehearse N>1 on one GPU)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end `gbrs quantify` + `gbrs reconstruct` wall-clock measurement")
+    ap.add_argument("--e2e-format", default="h5", choices=["h5", "npz", "both"])
     return ap.parse_args()
 
 
@@ -480,6 +482,20 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    e2e = None
+    if world == 1 and not args.no_e2e and not args.merge and args.rows == 40_000_000 and args.haps == 8:
+        # End-to-end `gbrs quantify` + `gbrs reconstruct` (file in -> reports out) as fresh child processes,
+        # measured BEFORE this process opens the GPU: a second process holding a device context slows the
+        # large allocations of the measured one.  Outside the timed EM region; its own object in the line.
+        import __graft_entry__
+        __graft_entry__.build()
+        sys.path.insert(0, os.path.join(ROOT, "scripts"))
+        import e2e_bench
+        try:
+            e2e = e2e_bench.measure(args.rows, args.haps, args.loci, args.e2e_format, args.cpu_rows, repeats=3,
+                                    with_cpu=not args.no_cpu_baseline)
+        except Exception as ex:                         # noqa: BLE001 - reported in the line, never hidden
+            e2e = {"error": f"{type(ex).__name__}: {ex}"}
     import torch
     import torch.distributed as dist
     if not torch.cuda.is_available():
@@ -624,6 +640,8 @@ def main():
                 "state_check": m.get("check")}
         if not args.no_hmm and world == 1:
             line["hmm"] = hmm_bench(args, torch)
+        if e2e is not None:
+            line["end_to_end"] = e2e
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
