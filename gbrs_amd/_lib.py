@@ -43,7 +43,6 @@ GBRS_EM_FORCE_INTERLEAVE = 8
 GBRS_EM_NO_STREAMS = 16
 GBRS_EM_DETERMINISTIC = 32
 GBRS_EM_KEEP_CSC = 64
-GBRS_EM_FORCE_STREAMS = 128
 
 
 class EmInfo(C.Structure):

@@ -964,14 +964,12 @@ int em_create_impl(uint64_t R, uint32_t L, uint32_t H, const uint32_t *const *in
         // contiguous piece of the tile's sorted rows, so it stays on one locus list for long stretches
         // (E-step on C2: raw reads 0.158 -> 0.152 ms, merged distinct rows 0.110 -> 0.056 ms against
         // the interleaved order that used to be their default).
-        // Raw reads (no count, not merged) carry long runs of identical rows: in plain sorted order such a
-        // run fills whole consecutive batches with identical words, which the unweighted kernel counts
-        // instead of recomputing (em_tiles.inc, "run skipping"); GBRS_EM_FORCE_STREAMS puts them in stream
-        // order as well.
-        const bool distinct = count != nullptr || (flags & GBRS_EM_MERGE_IDENTICAL_ROWS);
-        int row_order = (distinct || (flags & GBRS_EM_FORCE_STREAMS)) ? 2 : 0;
+        int row_order = 2;
         if (flags & GBRS_EM_FORCE_INTERLEAVE) row_order = 1;
-        else if (flags & GBRS_EM_NO_STREAMS) row_order = (distinct && !(flags & GBRS_EM_NO_INTERLEAVE)) ? 1 : 0;
+        else if (flags & GBRS_EM_NO_STREAMS) {
+            const bool distinct = count != nullptr || (flags & GBRS_EM_MERGE_IDENTICAL_ROWS);
+            row_order = (distinct && !(flags & GBRS_EM_NO_INTERLEAVE)) ? 1 : 0;
+        }
         GBRS_TRY(build_tile_layout(em->tl, R, L, H, n, em->ent_row.p, em->col_ptr.p,
                                    count ? em->count.p : nullptr, (flags & GBRS_EM_MERGE_IDENTICAL_ROWS) != 0,
                                    row_order, (flags & GBRS_EM_DETERMINISTIC) != 0,

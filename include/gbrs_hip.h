@@ -65,7 +65,7 @@ typedef struct gbrs_em gbrs_em_t;
  * The default is the packed-row-tile layout; this one is the simple cross-check. */
 #define GBRS_EM_LAYOUT_CSC 2u
 /* Tuning switches for the order of rows inside a tile.
- * Stream order (default when `count` is given or rows are merged): rows are grouped by length and each group of 64/len lanes walks its own
+ * Stream order (default): rows are grouped by length and each group of 64/len lanes walks its own
  * contiguous run of the tile's sorted rows over successive batches, so a lane stays on one locus
  * list for long stretches and the per-lane register accumulation rarely spills to LDS atomics.
  * GBRS_EM_NO_STREAMS falls back to the previous defaults: sorted order for raw reads, interleaved
@@ -74,10 +74,6 @@ typedef struct gbrs_em gbrs_em_t;
 #define GBRS_EM_NO_INTERLEAVE 4u
 #define GBRS_EM_FORCE_INTERLEAVE 8u
 #define GBRS_EM_NO_STREAMS 16u
-/* Reads without `count` that are not merged go into the tiles in plain sorted order by default (runs of
- * identical reads then fill whole batches, which the E-step counts instead of recomputing);
- * GBRS_EM_FORCE_STREAMS selects the stream order for them too. */
-#define GBRS_EM_FORCE_STREAMS 128u
 /* Bit-reproducible sums: the E-step's LDS float64 atomics are replaced by a fixed-order reduction
  * (every wavefront of a tile owns a private copy of the tile's partial sums; lanes that hand in sums
  * for one locus are added by a fixed tree; copies, slots and block sums are added in index order), so
