@@ -3,8 +3,11 @@
 Restatement of the equivalence-class loop of gbrs/emase_utils.py:60-103 on in-memory CSC arrays:
 key of a row = per-haplotype sorted locus lists; classes in order of first appearance (dict
 insertion order); count = sum of member counts (1 per read when the input has no count).
-PARITY UNPINNED by a reference run: the reference's compress() can only be entered through
-PyTables file I/O, which does not exist in this image; the restatement follows the source text.
+Parity pin: tests/golden/compress_*.npz were written by oracle/gen_golden.py from the reference's own
+compress() run on in-memory matrices (its two PyTables file boundaries, the h5 load and the h5 save, are
+served from / captured into memory by a subclass of the reference's AlignmentPropertyMatrix; the
+equivalence-class loop runs untouched), and this restatement was checked bit for bit against it there:
+class order, structure and counts, with EC counts, empty rows, 16 haplotypes and two input files.
 """
 import numpy as np
 

@@ -318,6 +318,81 @@ def counts_case(name, R, H, L, seed, with_count, drop_rows=0, drop_every_nth_gro
     np.savez_compressed(os.path.join(GOLD, f"counts_{name}.npz"), **out)
     print(f"counts_{name}: R={R} H={H} L={L} nnz={inc.nnz}")
 
+# ----------------------------------------------------------------------------- compress
+
+def compress_case(name, R, H, L, seed, with_count, drop_rows=0, two_files=False):
+    """`gbrs compress` (gbrs/emase_utils.py:22-107): the reference's own function is run on in-memory
+    matrices.  Its equivalence-class loop (:46-103) is untouched; only the two file-I/O boundaries it
+    crosses - `AlignmentPropertyMatrix(h5file=...)` and `.save(h5file=...)`, which need PyTables - are
+    served from / captured into memory by a subclass of the reference's AlignmentPropertyMatrix (its
+    `other=` copy constructor does the loading).  No PyTables call is imitated."""
+    from gbrs.gbrs import emase_utils as ref_eu
+    from oracle.compress_oracle import compress as oracle_compress
+    inc = synth.make_em_problem(R=R, H=H, L=L, seed=seed, with_count=with_count, max_count=6)
+    if drop_rows:
+        rng = np.random.default_rng(seed + 1)
+        dead = rng.choice(R, size=drop_rows, replace=False)
+        for h in range(H):
+            keep = ~np.isin(inc.indices[h], dead)
+            loc = np.repeat(np.arange(L), np.diff(inc.indptr[h].astype(np.int64)))[keep]
+            inc.indices[h] = inc.indices[h][keep]
+            inc.indptr[h] = np.searchsorted(loc, np.arange(L + 1)).astype(np.uint32)
+    source = ref_apm_from(inc, None)
+
+    class MemoryAPM(RefAPM):
+        loaded, saved = {}, {}
+
+        def __init__(self, h5file=None, **kw):
+            if h5file is not None:
+                RefAPM.__init__(self, other=MemoryAPM.loaded[h5file])
+            else:
+                RefAPM.__init__(self, **kw)
+
+        def save(self, h5file, **kw):
+            MemoryAPM.saved[h5file] = self
+
+    files = ["mem://a.h5", "mem://b.h5"] if two_files else ["mem://a.h5"]
+    for f in files:
+        MemoryAPM.loaded[f] = source
+    keep_cls = ref_eu.AlignmentPropertyMatrix
+    ref_eu.AlignmentPropertyMatrix = MemoryAPM
+    try:
+        ref_eu.compress(files, "mem://out.h5", "zlib")
+    finally:
+        ref_eu.AlignmentPropertyMatrix = keep_cls
+    res = MemoryAPM.saved["mem://out.h5"]
+    n_ref = res.num_reads
+    # the oracle on the same rows (two files = the same reads twice, one after the other)
+    if two_files:
+        ip2, ix2 = [], []
+        for h in range(H):
+            cols = np.repeat(np.arange(L, dtype=np.int64), np.diff(inc.indptr[h].astype(np.int64)))
+            rows = inc.indices[h].astype(np.int64)
+            cols, rows = np.concatenate((cols, cols)), np.concatenate((rows, rows + R))
+            order = np.lexsort((rows, cols))
+            ix2.append(rows[order].astype(np.uint32))
+            ip2.append(np.searchsorted(cols[order], np.arange(L + 1)).astype(np.uint32))
+        cnt2 = None if inc.count is None else np.concatenate((inc.count, inc.count))
+        n, ip, ix, counts = oracle_compress(2 * R, L, H, ip2, ix2, cnt2)
+    else:
+        n, ip, ix, counts = oracle_compress(R, L, H, inc.indptr, inc.indices, inc.count)
+    assert n == n_ref, (n, n_ref)
+    beq(res.count, counts, f"{name} EC counts")
+    out = dict(num_rows=R, num_loci=L, num_haps=H, has_count=with_count, two_files=two_files,
+               count=inc.count if with_count else np.zeros(0), num_ecs=n_ref, ec_count=np.asarray(res.count))
+    for h in range(H):
+        m = res.data[h].tocsc()
+        m.sort_indices()
+        beq(m.indptr, ip[h], f"{name} EC indptr h{h}")
+        beq(m.indices, ix[h], f"{name} EC indices h{h}")
+        assert (m.data == 1).all()
+        out[f"indptr{h}"] = inc.indptr[h]
+        out[f"indices{h}"] = inc.indices[h]
+        out[f"ec_indptr{h}"] = m.indptr.astype(np.uint32)
+        out[f"ec_indices{h}"] = m.indices.astype(np.uint32)
+    np.savez_compressed(os.path.join(GOLD, f"compress_{name}.npz"), **out)
+    print(f"compress_{name}: R={R} H={H} L={L} -> {n_ref} ECs")
+
 # ----------------------------------------------------------------------------- interpolate / export
 
 def postproc_case(name, hmm_name, n_grid):
@@ -385,6 +460,13 @@ def main():
             counts_case("h2_count", 1200, 2, 60, 43, True)
             counts_case("h8_ungrouped", 1500, 8, 80, 44, True, drop_every_nth_group=4)
         if only == "counts":
+            return
+        if only in (None, "compress"):
+            compress_case("h8_plain", 2500, 8, 50, 51, False)
+            compress_case("h8_count_emptyrows", 1800, 8, 40, 52, True, drop_rows=60)
+            compress_case("h2_two_files", 1200, 2, 30, 53, False, two_files=True)
+            compress_case("h16_count", 700, 16, 25, 54, True)
+        if only == "compress":
             return
         if only == "postproc":
             postproc_case("h8", "h8_full", 25)

@@ -2,6 +2,8 @@
 import numpy as np
 import pytest
 
+from conftest import golden_files, load_golden
+
 
 def problem(R, H, L, seed, with_count, empty=0):
     from gbrs_amd import synth
@@ -30,6 +32,68 @@ def test_compress_oracle_small_known_answer():
     np.testing.assert_array_equal(ix[0], [0, 1, 0])
     np.testing.assert_array_equal(ip[1], [0, 1, 1, 1])
     np.testing.assert_array_equal(ix[1], [0])
+
+
+def _golden_inputs(g):
+    H, L, R = int(g["num_haps"]), int(g["num_loci"]), int(g["num_rows"])
+    ip = [g[f"indptr{h}"] for h in range(H)]
+    ix = [g[f"indices{h}"] for h in range(H)]
+    cnt = g["count"] if bool(g["has_count"]) else None
+    return R, L, H, ip, ix, cnt
+
+
+def _doubled(R, L, H, ip, ix, cnt):
+    """The reads of two identical input files one after the other."""
+    ip2, ix2 = [], []
+    for h in range(H):
+        cols = np.repeat(np.arange(L, dtype=np.int64), np.diff(ip[h].astype(np.int64)))
+        rows = ix[h].astype(np.int64)
+        cols, rows = np.concatenate((cols, cols)), np.concatenate((rows, rows + R))
+        order = np.lexsort((rows, cols))
+        ix2.append(rows[order].astype(np.uint32))
+        ip2.append(np.searchsorted(cols[order], np.arange(L + 1)).astype(np.uint32))
+    return 2 * R, L, H, ip2, ix2, None if cnt is None else np.concatenate((cnt, cnt))
+
+
+@pytest.mark.parametrize("path", golden_files("compress"), ids=lambda p: p.split("/")[-1][:-4])
+def test_compress_oracle_matches_reference(path):
+    """The restatement against what the reference's own compress() produced (oracle/gen_golden.py)."""
+    from oracle.compress_oracle import compress
+    g = load_golden(path)
+    args = _golden_inputs(g)
+    if bool(g["two_files"]):
+        args = _doubled(*args)
+    n, ip, ix, counts = compress(*args)
+    assert n == int(g["num_ecs"])
+    np.testing.assert_array_equal(counts, g["ec_count"])
+    for h in range(args[2]):
+        np.testing.assert_array_equal(ip[h], g[f"ec_indptr{h}"])
+        np.testing.assert_array_equal(ix[h], g[f"ec_indices{h}"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", golden_files("compress"), ids=lambda p: p.split("/")[-1][:-4])
+def test_compress_hip_matches_reference_golden(path, tmp_path):
+    """HIP equivalence classes against the reference's: same class order, structure and counts (exact)."""
+    from gbrs_amd.alignment import AlignmentPropertyMatrix, load_alignment
+    from gbrs_amd.compress import compress, compress_matrix
+    g = load_golden(path)
+    R, L, H, ip, ix, cnt = _golden_inputs(g)
+    apm = AlignmentPropertyMatrix(shape=(L, H, R), indptr=ip, indices=ix, count=cnt,
+                                  haplotype_names=[chr(65 + h) for h in range(H)],
+                                  locus_names=[f"T{l:05d}" for l in range(L)])
+    if bool(g["two_files"]):
+        a, b = tmp_path / "a.npz", tmp_path / "b.npz"
+        apm.save_npz(str(a)); apm.save_npz(str(b))
+        compress([str(a), str(b)], str(tmp_path / "ec.npz"))
+        ec = load_alignment(str(tmp_path / "ec.npz"))
+    else:
+        ec = compress_matrix(apm)
+    assert ec.num_reads == int(g["num_ecs"])
+    np.testing.assert_array_equal(ec.count, g["ec_count"])
+    for h in range(H):
+        np.testing.assert_array_equal(ec.indptr[h], g[f"ec_indptr{h}"])
+        np.testing.assert_array_equal(ec.indices[h], g[f"ec_indices{h}"])
 
 
 @pytest.mark.gpu
