@@ -20,18 +20,19 @@ for sub in ('pmc_sq', 'pmc_sq2', 'pmc_grbm', 'pmc_fetch', 'pmc_write'):
             print(' ', k, {c: round(sum(x) / len(x), 1) for c, x in v.items()})
 
 # derived figures for the E-step kernel -> JSON fragment for profiles/pmc_traffic.json
-import json
+import json, re
+EST = re.compile(r'tile_estep_kernel<\d+, (true|false), false, ')      # the EM step's launches, not prepare()'s (ONES)
 est = {}
 for sub in ('pmc_sq', 'pmc_sq2', 'pmc_grbm', 'pmc_fetch', 'pmc_write'):
     for f in glob.glob(f'{d}/{sub}/*/*_counter_collection.csv'):
         for r in csv.DictReader(open(f)):
-            if 'tile_estep_kernel' in r['Kernel_Name']:
+            if EST.search(r['Kernel_Name']):
                 est.setdefault(r['Counter_Name'], []).append(float(r['Counter_Value']))
 avg = {k: sum(v) / len(v) for k, v in est.items()}
 dur_us = None
 for f in glob.glob(d + '/kt/*/*_kernel_stats.csv'):
     for r in csv.DictReader(open(f)):
-        if 'tile_estep_kernel' in r['Name']:
+        if EST.search(r['Name']):
             dur_us = float(r['AverageNs']) / 1e3
 if avg and dur_us:
     out = dict(kernel_avg_us=dur_us)
