@@ -5,7 +5,20 @@
 // repr(float) print in the reference's writers (emase/EMfactory.py:289-380).  At 120k isoforms + 48k
 // genes the four reports hold 1.5 M numbers; formatting them in the interpreter took ~1 s per sample,
 // as long as everything else of `gbrs quantify` on the device path together.
+#ifdef GBRS_HOST_ONLY
+// CPU-only build of this file for the AddressSanitizer / UBSan test (tests/test_hostio_sanitizers.py:
+// g++ -x c++ -DGBRS_HOST_ONLY -fsanitize=address,undefined): nothing here touches the device, so the
+// HIP runtime headers are not needed; the test driver supplies gbrs::fail.
+#include <cstdarg>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+#include "../../include/gbrs_hip.h"
+namespace gbrs { int fail(int status, const char *fmt, ...); }
+#else
 #include "common.h"
+#endif
 
 #include <dlfcn.h>
 #include <fcntl.h>

@@ -1,0 +1,169 @@
+// Driver for the sanitizer build of gbrs_amd/csrc/hostio.hip (host-side file I/O helpers of libgbrs_hip):
+// exercises the number formatter, the report writer, the length-table parser and the chunk decoder,
+// including malformed inputs, under AddressSanitizer + UndefinedBehaviorSanitizer.  Exit code 0 = clean.
+#include <cinttypes>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <limits>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "../../include/gbrs_hip.h"
+
+namespace gbrs {
+static char g_err[512];
+int fail(int status, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    std::vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return status;
+}
+}  // namespace gbrs
+
+#define CHECK(cond)                                                                  \
+    do {                                                                             \
+        if (!(cond)) { std::fprintf(stderr, "CHECK failed: %s (%s:%d)\n", #cond, __FILE__, __LINE__); return 1; } \
+    } while (0)
+
+static std::string slurp(const std::string &p) {
+    std::ifstream f(p, std::ios::binary);
+    return std::string((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+}
+
+int main(int argc, char **argv) {
+    const std::string dir = argc > 1 ? argv[1] : "/tmp";
+    // ---- gbrs_format_double: round trip and a few fixed spellings
+    char buf[40];
+    std::mt19937_64 rng(7);
+    for (int i = 0; i < 200000; ++i) {
+        uint64_t bits = rng();
+        double v;
+        std::memcpy(&v, &bits, 8);
+        const int n = gbrs_format_double(v, buf);
+        CHECK(n > 0 && n < 32 && (int)std::strlen(buf) == n);
+        if (std::isfinite(v)) CHECK(std::strtod(buf, nullptr) == v);
+    }
+    const struct { double v; const char *s; } fixed[] = {{0.0, "0.0"}, {-0.0, "-0.0"}, {1.0, "1.0"}, {1e16, "1e+16"},
+        {1e15, "1000000000000000.0"}, {1e-5, "1e-05"}, {0.0001, "0.0001"}, {123.456, "123.456"}, {5e-324, "5e-324"},
+        {1.7976931348623157e308, "1.7976931348623157e+308"}, {std::numeric_limits<double>::infinity(), "inf"}};
+    for (const auto &f : fixed) {
+        gbrs_format_double(f.v, buf);
+        CHECK(std::strcmp(buf, f.s) == 0);
+    }
+    gbrs_format_double(std::nan(""), buf);
+    CHECK(std::strcmp(buf, "nan") == 0);
+    CHECK(gbrs_format_double(1.0, nullptr) < 0);
+
+    // ---- gbrs_write_locus_table: both memory orders, notes, an explicit order, bad arguments
+    {
+        const int H = 3;
+        const int64_t n = 5000;
+        std::vector<double> hl((size_t)H * n), lh((size_t)H * n), tot(n);
+        std::string names, notes;
+        std::vector<int64_t> noff(n + 1, 0), toff(n + 1, 0), order(n);
+        for (int64_t r = 0; r < n; ++r) {
+            tot[r] = 0;
+            for (int h = 0; h < H; ++h) {
+                const double x = (double)(rng() % 100000) / 7.0;
+                hl[(size_t)h * n + r] = x;
+                lh[(size_t)r * H + h] = x;
+                tot[r] += x;
+            }
+            names += "T" + std::to_string(r);
+            noff[r + 1] = (int64_t)names.size();
+            notes += (r % 3 ? "AB" : "None");
+            toff[r + 1] = (int64_t)notes.size();
+            order[r] = n - 1 - r;
+        }
+        const std::string p1 = dir + "/t1.tsv", p2 = dir + "/t2.tsv", p3 = dir + "/t3.tsv";
+        CHECK(gbrs_write_locus_table(p1.c_str(), "locus\tA\tB\tC\ttotal\n", hl.data(), n, H, 1, n, tot.data(),
+                                     names.data(), noff.data(), nullptr, nullptr, nullptr) == 0);
+        CHECK(gbrs_write_locus_table(p2.c_str(), "locus\tA\tB\tC\ttotal\n", lh.data(), n, H, H, 1, tot.data(),
+                                     names.data(), noff.data(), nullptr, nullptr, nullptr) == 0);
+        CHECK(slurp(p1) == slurp(p2) && slurp(p1).size() > 100000);
+        CHECK(gbrs_write_locus_table(p3.c_str(), "h\n", hl.data(), n, H, 1, n, tot.data(), names.data(), noff.data(),
+                                     notes.data(), toff.data(), order.data()) == 0);
+        const std::string t3 = slurp(p3);
+        CHECK(t3.rfind("h\nT4999\t", 0) == 0 && t3.find("\tNone\n") != std::string::npos);
+        order[7] = n;                                                // out of range
+        CHECK(gbrs_write_locus_table(p3.c_str(), "h\n", hl.data(), n, H, 1, n, tot.data(), names.data(), noff.data(),
+                                     nullptr, nullptr, order.data()) < 0);
+        CHECK(gbrs_write_locus_table((dir + "/no/such/dir/x").c_str(), "h\n", hl.data(), n, H, 1, n, tot.data(),
+                                     names.data(), noff.data(), nullptr, nullptr, nullptr) < 0);
+        CHECK(gbrs_write_locus_table(p3.c_str(), "h\n", hl.data(), 0, H, 1, 0, tot.data(), names.data(), noff.data(),
+                                     nullptr, nullptr, nullptr) == 0);           // empty table: header only
+        CHECK(slurp(p3) == "h\n");
+    }
+
+    // ---- gbrs_parse_length_table: plain file, fallback triggers, no trailing newline
+    {
+        const char *names = "T0T1T22";
+        const int64_t noff[] = {0, 2, 4, 7};
+        const char *haps = "AB";
+        const int64_t hoff[] = {0, 1, 2};
+        double eff[6];
+        for (double &x : eff) x = -1.0;
+        const std::string ok = "T0_A\t150\nT0_B\t151\r\nT1_A\t50\nT1_B\t1e3\nT22_A\t100.5\nT22_B\t99";
+        CHECK(gbrs_parse_length_table(ok.data(), (int64_t)ok.size(), names, noff, 3, haps, hoff, 2, 100.0, eff) == 0);
+        CHECK(eff[0] == 51.0 && eff[3] == 52.0 && eff[1] == 1.0 && eff[4] == 901.0 && eff[2] == 1.5 && eff[5] == 1.0);
+        const char *bad[] = {"T9_A\t1\n", "T0_C\t1\n", "T0_A_B\t1\n", "T0_A\n", "T0_A\t 12\n", "T0_A\tnan\n", "T0\t5\n", "\n"};
+        for (const char *b : bad)
+            CHECK(gbrs_parse_length_table(b, (int64_t)std::strlen(b), names, noff, 3, haps, hoff, 2, 100.0, eff) == 1);
+        const char *one = "T1\t300\nT22\t20\n";                      // a single haplotype: plain locus keys
+        double e1[3] = {0, 0, 0};
+        CHECK(gbrs_parse_length_table(one, (int64_t)std::strlen(one), names, noff, 3, haps, hoff, 1, 100.0, e1) == 0);
+        CHECK(e1[1] == 201.0 && e1[2] == 1.0);
+        CHECK(gbrs_parse_length_table("", 0, names, noff, 3, haps, hoff, 2, 100.0, eff) == 0);
+        CHECK(gbrs_parse_length_table(nullptr, 0, names, noff, 3, haps, hoff, 2, 100.0, eff) < 0);
+    }
+
+    // ---- gbrs_decode_chunks: stored (unfiltered) chunks with and without byte shuffle, partial last chunk,
+    //      a corrupt "deflate" chunk and a short file
+    {
+        const uint64_t chunk = 1000, n = 3500;
+        std::vector<uint32_t> data(n);
+        for (auto &x : data) x = (uint32_t)rng();
+        const std::string path = dir + "/chunks.bin";
+        std::vector<uint64_t> addr, stored, start;
+        std::vector<uint32_t> fmask;
+        {
+            std::ofstream f(path, std::ios::binary);
+            uint64_t pos = 0;
+            for (uint64_t s0 = 0; s0 < n; s0 += chunk) {
+                std::vector<unsigned char> plane(chunk * 4, 0);
+                const uint64_t cnt = std::min(chunk, n - s0);
+                for (uint64_t i = 0; i < cnt; ++i)
+                    for (int b = 0; b < 4; ++b) plane[(size_t)b * chunk + i] = (unsigned char)(data[s0 + i] >> (8 * b));
+                f.write((const char *)plane.data(), (std::streamsize)plane.size());
+                addr.push_back(pos); stored.push_back(plane.size()); start.push_back(s0);
+                fmask.push_back(2u);                                 // bit 1 = the deflate filter was skipped for this chunk
+                pos += plane.size();
+            }
+        }
+        std::vector<uint32_t> out(n, 0);
+        CHECK(gbrs_decode_chunks(path.c_str(), (int64_t)addr.size(), addr.data(), stored.data(), start.data(), fmask.data(),
+                                 chunk, 4, n, /*shuffle*/ 0, /*deflate*/ 1, out.data(), 3) == 0);
+        CHECK(out == data);
+        fmask[1] = 0u;                                               // claim chunk 1 is deflated: it is not a zlib stream
+        CHECK(gbrs_decode_chunks(path.c_str(), (int64_t)addr.size(), addr.data(), stored.data(), start.data(), fmask.data(),
+                                 chunk, 4, n, 0, 1, out.data(), 2) < 0);
+        fmask[1] = 2u;
+        stored[3] += 4096;                                           // runs past the end of the file
+        CHECK(gbrs_decode_chunks(path.c_str(), (int64_t)addr.size(), addr.data(), stored.data(), start.data(), fmask.data(),
+                                 chunk, 4, n, 0, 1, out.data(), 2) < 0);
+        stored[3] -= 4096;
+        start[2] = n + 5;                                            // chunk outside the dataset
+        CHECK(gbrs_decode_chunks(path.c_str(), (int64_t)addr.size(), addr.data(), stored.data(), start.data(), fmask.data(),
+                                 chunk, 4, n, 0, 1, out.data(), 2) < 0);
+        CHECK(gbrs_decode_chunks((dir + "/missing.bin").c_str(), 0, nullptr, nullptr, nullptr, nullptr, chunk, 4, n, 0, 1,
+                                 out.data(), 1) < 0);
+    }
+    std::printf("hostio sanitizer driver: ok (inflate backend %d)\n", gbrs_inflate_backend());
+    return 0;
+}
