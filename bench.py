@@ -56,6 +56,9 @@ def parse():
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: one engine per GPU, all-reduce not overlapped with the E-step")
     ap.add_argument("--force-overlap-path", action="store_true", help="N = 1: run the two-engine form anyway (its compute-side cost without any exchange)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (gloo only to rehearse N>1 on one GPU)")
+    ap.add_argument("--rccl-selftest", action="store_true",
+                    help="N = 1: create a one-rank RCCL process group and send every all-reduce of the multi-GPU code "
+                         "paths through it (the collectives, stream ordering and raw-pointer tensor views on hardware)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the end-to-end `gbrs quantify` + `gbrs reconstruct` wall-clock measurement")
     ap.add_argument("--e2e-format", default="h5", choices=["h5", "npz", "both"])
     return ap.parse_args()
@@ -103,7 +106,8 @@ def em_bench(args, rank, world, torch, dist):
         torch.cuda.synchronize()
 
     acc_t = None
-    if world > 1:
+    use_dist = world > 1 or args.rccl_selftest
+    if use_dist:
         # run the library on torch's current stream: E-step -> all-reduce -> M-step are then ordered
         # on the device and the loop below never synchronises with the host
         eng.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -115,7 +119,7 @@ def em_bench(args, rank, world, torch, dist):
         eng.prepare(0.0)
 
     def run_steps(k):
-        if world == 1:
+        if not use_dist:
             eng.step(k)
             return
         for _ in range(k):
@@ -273,7 +277,7 @@ def em_bench_pipelined(args, rank, world, torch, dist, state):
             pass
 
     def start_allreduce(ptr, n):
-        if world == 1:
+        if world == 1 and not args.rccl_selftest:
             return _Done()
         if ptr not in views:
             views[ptr] = torch.as_tensor(DevArray(ptr, n), device=dev)
@@ -511,6 +515,13 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
         else:
             dist.init_process_group(args.backend)
+    elif args.rccl_selftest:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        dist.init_process_group(args.backend, init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                                **({"device_id": torch.device(f"cuda:{local}")} if args.backend == "nccl" else {}))
     import __graft_entry__
     if rank == 0:
         __graft_entry__.build()
@@ -557,7 +568,7 @@ def main():
         "value": value, "unit": "iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
-        "path": path, "rccl_ranks": world if (world > 1 and args.backend == "nccl") else 0,
+        "path": path, "rccl_ranks": world if ((world > 1 or args.rccl_selftest) and args.backend == "nccl") else 0,
         "backend": args.backend if world > 1 else None,
         "config": {"workload": f"configs[1]: single DO sample, R={args.rows} reads x H={args.haps} x "
                                f"L={args.loci} isoforms, N={em['N']} alignment entries, quantify Model 4, "
@@ -645,6 +656,7 @@ def main():
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
+    if world > 1 or args.rccl_selftest:
         dist.destroy_process_group()
     chk = em.get("check") or {}
     if chk.get("ok") is False:

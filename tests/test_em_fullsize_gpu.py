@@ -144,3 +144,42 @@ def test_c2_full_size_deterministic_mode(c2_sample):
     close(eng.theta(), res[0][2])
     np.testing.assert_allclose(hist, res[0][1], rtol=1e-7)
     eng.close()
+
+
+def test_c5_shard_full_size_properties():
+    """One GPU's shard of BASELINE configs[4] (200M reads x 16 haplotypes x 200k isoforms over 8 GPUs =
+    25M reads per GPU): the 16-haplotype E-step at size - conservation of read mass, the tile layout against
+    the plain CSC kernels after 3 iterations, the sharded building blocks (A handed out as for the
+    all-reduce) against the fused single-GPU step, and two handles fed the same arrays agreeing to 1e-9."""
+    import torch
+    from gbrs_amd import _lib, synth, synth_torch
+    R, H, L = 25_000_000, 16, 200_000
+    prob = synth_torch.make_em_problem_device(R, H, L, synth.SEED_BASE_EM + 4, "cuda:0")
+    eng = _engine(prob)
+    inf = eng.info()
+    assert inf.layout == 1 and inf.num_haps == 16 and inf.num_entries == prob["N"] and inf.num_long_rows == 0
+    eng.prepare(0.0)
+    th0 = eng.theta()
+    eng.step(3)
+    th3, cnt3 = eng.theta(), eng.expected_counts()
+    assert np.isfinite(th3).all() and (th3 >= 0).all()
+    assert abs(cnt3.sum() - R) <= 1e-9 * R
+    eff = prob["eff_len"].cpu().numpy()
+    assert abs((th3 * eff).sum() - R) <= 1e-9 * R
+    # the sharded building blocks on the same handle: E-step into the partial vector, M-step on it
+    eng.prepare_partial()
+    eng.finish_prepare(0.0)
+    close(eng.theta(), th0)
+    for _ in range(3):
+        eng.estep_partial()
+        eng.finish_step(want_err=True)
+    close(eng.theta(), th3)
+    eng.close()
+    ec = _engine(prob, _lib.GBRS_EM_LAYOUT_CSC)
+    ec.prepare(0.0)
+    close(ec.theta(), th0)
+    ec.step(3)
+    close(ec.theta(), th3)
+    ec.close()
+    del prob
+    torch.cuda.empty_cache()

@@ -316,3 +316,41 @@ def test_specificity_tables_stay_resident():
         np.testing.assert_allclose(r["eprob"], g[f"eprob_{ch}"], rtol=1e-10, atol=1e-10)
         np.testing.assert_allclose(r["gamma"], g[f"gamma_{ch}"], rtol=1e-8, atol=1e-300)
     hmm.close()
+
+
+def test_hmm_sixteen_founders_at_size():
+    """BASELINE configs[4]'s reconstruct shape: 136 diplotype states on a genome-sized run (20 chromosomes,
+    6,000 genes, 2 samples).  Size-independent properties on every chromosome - posterior columns sum to one,
+    every gene gets a call in range, the Viterbi path has n + 1 entries - and the oracle on the two shortest
+    chromosomes (calls bit-exact, posteriors 1e-8)."""
+    from gbrs_amd import synth
+    from gbrs_amd.hmm import DiplotypeHMM
+    from oracle import hmm_oracle
+    lens = [int(round(n * 0.15)) for n in synth.MOUSE_GENES]
+    probs = [synth.make_hmm_problem(H=16, genes_per_chrom=lens, seed=9100 + s) for s in range(2)]
+    p0 = probs[0]
+    chroms = p0.chroms
+    hmm = DiplotypeHMM(16, chroms, [len(p0.gene_ids[c]) for c in chroms], [p0.tprob[c] for c in chroms])
+    ex, av, ha = [], [], []
+    for c in chroms:
+        ids = p0.gene_ids[c]
+        ex.append(np.array([[p.expr[g] for g in ids] for p in probs]))
+        ha.append(np.array([g in p0.avecs for g in ids], dtype=np.uint8))
+        av.append(np.array([p0.avecs.get(g, np.zeros((16, 16))) for g in ids]))
+    hmm.set_expression(ex, av, ha, 1.5, 0.12)
+    hmm.run()
+    short = sorted(range(len(chroms)), key=lambda k: lens[k])[:2]
+    for s, p in enumerate(probs):
+        for ci, c in enumerate(chroms):
+            r = hmm.get(ci, sample=s)
+            n = lens[ci]
+            assert r["gamma"].shape == (136, n) and np.isfinite(r["gamma"]).all()
+            np.testing.assert_allclose(r["gamma"].sum(axis=0), 1.0, rtol=1e-12)
+            assert len(r["states"]) == n + 1 and r["calls"].min() >= 0 and r["calls"].max() < 136
+        sub = [chroms[k] for k in short]
+        res = hmm_oracle.reconstruct_arrays(p0.hap_names, sub, p0.gene_ids, p0.tprob, p.expr, p0.avecs)
+        for k in short:
+            r = hmm.get(k, sample=s)
+            np.testing.assert_array_equal(r["calls"], res[chroms[k]]["calls"])
+            np.testing.assert_allclose(r["gamma"], res[chroms[k]]["gamma"], rtol=1e-8, atol=1e-300)
+    hmm.close()
