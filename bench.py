@@ -491,8 +491,11 @@ def main():
         # End-to-end `gbrs quantify` + `gbrs reconstruct` (file in -> reports out) as fresh child processes,
         # measured BEFORE this process opens the GPU: a second process holding a device context slows the
         # large allocations of the measured one.  Outside the timed EM region; its own object in the line.
-        import __graft_entry__
-        __graft_entry__.build()
+        # (the library is built in a child as well: loading libgbrs_hip.so here, before torch brings in its own
+        # HIP runtime, leaves this process with two runtimes and no visible device)
+        import subprocess
+        subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build()"], cwd=ROOT, check=True,
+                       stdout=sys.stderr)
         sys.path.insert(0, os.path.join(ROOT, "scripts"))
         import e2e_bench
         try:

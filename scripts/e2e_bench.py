@@ -263,8 +263,8 @@ def main():
     if a.make_sample:
         print(json.dumps(build_sample(a.workdir, a.rows, a.haps, a.loci, a.format, a.cpu_rows)), flush=True)
         return
-    import __graft_entry__
-    __graft_entry__.build()                       # hipcc only: the parent never opens the GPU
+    subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build()"], cwd=ROOT, check=True,
+                   stdout=sys.stderr)             # built in a child: the parent never loads the HIP runtime
     out = measure(a.rows, a.haps, a.loci, a.format, a.cpu_rows, a.workdir, a.keep, a.repeats, not a.no_cpu)
     print(json.dumps(out), flush=True)
 
