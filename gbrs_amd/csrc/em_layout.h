@@ -30,7 +30,7 @@ constexpr int TILE_WORDS = GBRS_TILE_CAP - 64;  // unpadded words per tile (sort
 __host__ __device__ constexpr int pos_bits(int H) { return H <= 8 ? 5 : 4; }
 __host__ __device__ constexpr int max_row_words(int H) { return 1 << pos_bits(H); }
 #ifndef GBRS_LDS_DOUBLES
-#define GBRS_LDS_DOUBLES 4096
+#define GBRS_LDS_DOUBLES 3072
 #endif
 constexpr int LDS_THETA_DOUBLES = GBRS_LDS_DOUBLES;        // theta of the tile: D_MAX * H doubles
 constexpr int LDS_ACC_DOUBLES = GBRS_LDS_DOUBLES + 64;     // privatised partial sums
