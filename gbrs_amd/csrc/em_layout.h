@@ -32,11 +32,18 @@ __host__ __device__ constexpr int max_row_words(int H) { return 1 << pos_bits(H)
 #ifndef GBRS_LDS_DOUBLES
 #define GBRS_LDS_DOUBLES 3072
 #endif
-constexpr int LDS_THETA_DOUBLES = GBRS_LDS_DOUBLES;        // theta of the tile: D_MAX * H doubles
-constexpr int LDS_ACC_DOUBLES = GBRS_LDS_DOUBLES + 64;     // privatised partial sums
+#ifndef GBRS_LDS_DOUBLES_WEIGHTED
+#define GBRS_LDS_DOUBLES_WEIGHTED 4096
+#endif
+// theta of the tile (D_MAX * H doubles) and, 64 doubles larger, its privatised partial sums.  Unweighted
+// layouts use 3,072 doubles (49 KB per workgroup with the sums: three workgroups per CU, which the
+// 72-register unweighted kernel fills); the weighted kernels need ~120 registers, two workgroups per CU
+// is all they can have, so their tiles take the larger dictionaries.
+__host__ __device__ constexpr int lds_theta_doubles(bool weighted) { return weighted ? GBRS_LDS_DOUBLES_WEIGHTED : GBRS_LDS_DOUBLES; }
+__host__ __device__ constexpr int lds_acc_doubles(bool weighted) { return lds_theta_doubles(weighted) + 64; }
 // deterministic mode (GBRS_EM_DETERMINISTIC): every wavefront of a tile owns a private copy of the tile's
 // sums, so a tile may reference at most this many loci
-__host__ __device__ constexpr uint32_t det_dict_cap(int H) { return (LDS_ACC_DOUBLES / TILE_WAVES - 1) / H; }
+__host__ __device__ constexpr uint32_t det_dict_cap(int H, bool weighted) { return (lds_acc_doubles(weighted) / TILE_WAVES - 1) / H; }
 constexpr uint32_t SLOT_DIRECT = 0x80000000u;
 constexpr int HEAVY_SLOTS = 16;                // loci with more slots get a whole wave in the gather (measured 1, 4, 16, 64)
 

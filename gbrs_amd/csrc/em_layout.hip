@@ -834,9 +834,9 @@ int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L, uint32_t H, uint6
         GBRS_HIP_CHECK(hipStreamSynchronize(s));
         return GBRS_OK;
     };
-    out.d_max = std::min<uint32_t>(1024, LDS_THETA_DOUBLES / H);
+    out.d_max = std::min<uint32_t>(1024, lds_theta_doubles(merge || count != nullptr) / H);
     out.deterministic = deterministic;
-    if (deterministic) out.d_max = std::min<uint32_t>(out.d_max, det_dict_cap(H));
+    if (deterministic) out.d_max = std::min<uint32_t>(out.d_max, det_dict_cap(H, merge || count != nullptr));
     if (out.d_max <= (uint32_t)max_row_words(H))
         return fail(GBRS_ERR_UNSUPPORTED, "the deterministic tile layout has no room for a row's loci at H = %u", H);
     const uint32_t dseg = out.d_max - max_row_words(H);
