@@ -14,10 +14,9 @@ except Exception as e:
 PY
 }
 C5="--rows 25000000 --haps 16 --loci 200000"
-build "-DGBRS_ESTEP_UB=2"; bench base_c2 0; bench base_c2_merged 1; bench base_c5 0 "$C5"
-B="-DGBRS_ESTEP_UB=1 -DGBRS_RAW_PD=4 -DGBRS_LDS_DOUBLES=3072 -DGBRS_NO_MASK_ZLO -DGBRS_ESTEP_WAVES=6"
-build "$B"; bench w6_c2 0; bench w6_c2_merged 1; bench w6_c5 0 "$C5"
-build "$B -DGBRS_RAW_PD=6"; bench w6_pd6_c2 0
-build "-DGBRS_ESTEP_UB=1 -DGBRS_RAW_PD=4 -DGBRS_LDS_DOUBLES=2560 -DGBRS_NO_MASK_ZLO -DGBRS_ESTEP_WAVES=6"; bench w6_lds2560_c2 0; bench w6_lds2560_c5 0 "$C5"
+build "-DGBRS_DUMMY=1"; bench base_c2 0; bench base_c5 0 "$C5"
+build "-DGBRS_BIT_CVT"; bench bitcvt_c2 0; bench bitcvt_c5 0 "$C5"; bench bitcvt_c2_merged 1
+build "-DGBRS_RAW_PD=6"; bench pd6_c2 0
+build "-DGBRS_RAW_PD=2"; bench pd2_c2 0
 rm -f gbrs_amd/csrc/build/em.o gbrs_amd/csrc/build/em_layout.o gbrs_amd/csrc/build/hmm.o
 GBRS_HIPCC_EXTRA="" python -c "import __graft_entry__ as g; g.build()" > /dev/null 2>&1
