@@ -259,11 +259,15 @@ def _read_chunks_parallel(path, d, ftype, space):
         addr = np.ascontiguousarray(tab[:, 2])
         stored = np.ascontiguousarray(tab[:, 3])
         pos = {f: k for k, f in enumerate(filters)}
-        _native.check(lib_native.gbrs_decode_chunks(
+        st = lib_native.gbrs_decode_chunks(
             os.fsencode(path), len(todo), _native.ptr(addr), _native.ptr(stored), _native.ptr(start), _native.ptr(mask),
             chunk, size, n, pos.get(H5Z_FILTER_SHUFFLE, -1), pos.get(H5Z_FILTER_DEFLATE, -1), _native.ptr(out),
-            int(os.environ.get('GBRS_IO_THREADS', 0))))
-        return out
+            int(os.environ.get('GBRS_IO_THREADS', 0)))
+        if st == _native.GBRS_OK:
+            return out
+        if st != _native.GBRS_ERR_UNSUPPORTED:          # a damaged file is an error; a missing inflate library is not
+            _native.check(st)
+        out[:] = 0
     return _decode_chunks_python(path, todo, filters, chunk, size, n, out)
 
 

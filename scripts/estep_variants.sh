@@ -3,7 +3,7 @@
 OUT=${1:-gpurun_out/variants}; mkdir -p $OUT
 build() { GBRS_HIPCC_EXTRA="$1" python -c "import __graft_entry__ as g; g.build()" > $OUT/build.log 2>&1 || echo "BUILD FAILED: $1"; }
 bench() {  # name, bench flags, [extra bench args]
-  timeout -k 10 200 python bench.py --steps 50 --warmup 5 --no-e2e --no-cpu-baseline --no-hmm --no-merged-line --flags $2 $3 > $OUT/$1.log 2>&1
+  timeout -k 10 200 python bench.py --steps 30 --warmup 3 --no-e2e --no-cpu-baseline --no-hmm --no-merged-line --flags $2 $3 > $OUT/$1.log 2>&1
   python - "$1" "$OUT/$1.log" <<'PY'
 import json, sys
 try:
@@ -14,9 +14,7 @@ except Exception as e:
 PY
 }
 C5="--rows 25000000 --haps 16 --loci 200000"
-build "-DGBRS_DUMMY=1"; bench base_c2 0; bench base_c5 0 "$C5"
-build "-DGBRS_BIT_CVT"; bench bitcvt_c2 0; bench bitcvt_c5 0 "$C5"; bench bitcvt_c2_merged 1
-build "-DGBRS_RAW_PD=6"; bench pd6_c2 0
-build "-DGBRS_RAW_PD=2"; bench pd2_c2 0
+build "-DGBRS_FTAB16=1"; bench ftab16_on_c5 0 "$C5"; bench ftab16_on_c5_b 0 "$C5"
+build "-DGBRS_FTAB16=0"; bench ftab16_off_c5 0 "$C5"; bench ftab16_off_c5_b 0 "$C5"
 rm -f gbrs_amd/csrc/build/em.o gbrs_amd/csrc/build/em_layout.o gbrs_amd/csrc/build/hmm.o
 GBRS_HIPCC_EXTRA="" python -c "import __graft_entry__ as g; g.build()" > /dev/null 2>&1
