@@ -15,7 +15,8 @@ PY
 }
 C5="--rows 25000000 --haps 16 --loci 200000"
 build ""; bench new_c2 0; bench new_c2_b 0; bench new_c5 0 "$C5"; bench new_c2_merge 0 "--merge"
-build "-DGBRS_THETA_PLANES=0"; bench rowmajor_c2 0; bench rowmajor_c5 0 "$C5"; bench rowmajor_c2_merge 0 "--merge"
-build "-DGBRS_PLAIN_RECIP"; bench plainrecip_c2 0
+build "-DGBRS_NO_PARK"; bench nopark_c2 0; bench nopark_c5 0 "$C5"
+build "-DGBRS_RAW_PD=6"; bench pd6_c2 0
+build "-DGBRS_RAW_PD=8"; bench pd8_c2 0
 rm -f gbrs_amd/csrc/build/em.o gbrs_amd/csrc/build/em_layout.o gbrs_amd/csrc/build/hmm.o
 GBRS_HIPCC_EXTRA="" python -c "import __graft_entry__ as g; g.build()" > /dev/null 2>&1
