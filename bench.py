@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--cpu-iters", type=int, default=60, help="oracle iterations timed for cpu_baseline (stops at 25 s)")
     ap.add_argument("--hmm-samples", type=int, default=1)
     ap.add_argument("--hmm-batch", type=int, default=64, help="second HMM measurement with this many samples in one launch (0 = skip)")
+    ap.add_argument("--hmm-batch-large", type=int, default=256,
+                    help="third HMM measurement at a batch that fills the chip (the alpha / backward sweeps run 16 samples per wavefront on MFMA there; 0 = skip)")
     ap.add_argument("--hmm-reps", type=int, default=5)
     ap.add_argument("--hmm-haps", type=int, default=8, help="founder haplotypes of the HMM measurement (16 = config 5's 136 states)")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: one engine per GPU, all-reduce not overlapped with the E-step")
@@ -425,6 +427,10 @@ def hmm_bench(args, torch, ns=None, with_cpu=True):
     if with_cpu and args.hmm_batch > 0 and args.hmm_batch != ns:
         b = hmm_bench(args, torch, ns=args.hmm_batch, with_cpu=False)
         out["batched"] = {k: b[k] for k in ("value", "unit", "ms_per_pass", "n_samples", "wall_clock", "kernels_ms", "roofline")}
+    if with_cpu and args.hmm_batch_large > 0 and args.hmm_batch_large not in (ns, args.hmm_batch) and HH == 8:
+        b = hmm_bench(args, torch, ns=args.hmm_batch_large, with_cpu=False)
+        out["batched_large"] = {k: b[k] for k in ("value", "unit", "ms_per_pass", "n_samples", "wall_clock", "kernels_ms", "roofline")}
+        out["batched_large"]["note"] = "alpha and backward sweeps: 16 samples per wavefront on v_mfma_f64_16x16x4 (from 96 samples on); delta chain: vector max-plus"
     if with_cpu and not args.no_cpu_baseline:
         from oracle import hmm_oracle
         # the whole single-sample workload when it has 8 founders (about 10 s of oracle time), else a slice

@@ -11,6 +11,7 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <climits>
 #include <cmath>
 #include <cstdlib>
 #include <functional>
@@ -1387,6 +1388,255 @@ backward_wave_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *_
             step(o + u, u == 0, tr[u], pe_r[u], tr[(u + NSET - 1) % NSET], pe_r[(u + NSET - 1) % NSET]);
 }
 
+// ------------------------------------------------------------------------------------------
+// Large sample batches, 36 states: the alpha and backward sweeps of 16 samples per wavefront on
+// v_mfma_f64_16x16x4_f64 (D[16x16] += A[16x4] * B[4x16]).  A step is x = M y with M the 36x36 block of the
+// gene and y one column per sample, so the samples are the N dimension and nothing is broadcast through LDS.
+//
+// Operand maps (one f64 per lane): A[i = lane & 15][k = lane >> 4], B[k = lane >> 4][n = lane & 15];
+// D: register r of lane (g = lane >> 4, n = lane & 15) is D[row g + 4r][n].  Three row blocks of 16 cover 48
+// slots, nine k blocks of 4 the summation, and the point of the arrangement: register r of row block rb is
+// exactly the B operand of k block kb = 4 rb + r of the next step (k slot 4 kb + g = 16 rb + 4 r + g = its
+// row), so a step's result feeds the next one without any lane movement.  Lane (g, n) owns the slots
+// 4 q + g, q = 0..8, of sample n; slot 4 q + g holds state 9 g + q (mf_state), so a lane's nine states are
+// 72 contiguous bytes of every per-state row it loads or stores.
+// Slots 36..39 (third row block, register 1) are rows of ones: the vector's sum Z arrives in every lane
+// group out of the same products; slots 40..47 are zero rows.  mfma_blocks_kernel lays the 27 A operands of
+// every transition block out in lane order, two operands per 16-byte load.
+// The f64 MFMA rate of this chip equals its vector rate (one 16x16x4 = 16 passes = 64 cycles, measured 30 ns:
+// scripts/probes/mfma_f64_rate.hip), so the gain is the instruction count: 27 MFMAs + ~50 vector
+// instructions per step and 16 samples instead of ~140 vector instructions per step and sample.
+// Samples past the end shadow the last sample: same inputs, same results, and they store them to the same
+// places - no predicate anywhere in the loop.
+// Measured (profiles/r02_hmm_mfma_batches.txt): launched alone a sweep takes 1.25 us per step against the
+// 0.83 us of its 27 MFMAs; side by side with the delta chain every sweep slows down about twofold, at any batch
+// size and in either form - f64 MFMA and vector f64 share the double-precision units, so the three chains add
+// their times up wherever they share SIMDs.  At 64 samples (160 + 160 + 640 wavefronts) this form therefore
+// ties with the vector sweeps (6.2 vs 6.1 ms per pass); from about 96 samples on, when the chip is full, its
+// fourfold smaller instruction count wins (256 samples: 17.0 vs 25.9 ms).  hmm_launch switches at HMM_MFMA_MIN.
+// ------------------------------------------------------------------------------------------
+typedef double mfma_d4 __attribute__((ext_vector_type(4)));
+struct __attribute__((aligned(8))) mf_pair { double x, y; };     // 16 bytes at 8-byte alignment (a lane's row piece starts at 72 g)
+constexpr int MF_S = 36, MF_RB = 3, MF_KB = 9, MF_OPS = MF_RB * MF_KB, MF_PAIRS = (MF_OPS + 1) / 2;
+constexpr int MF_BLK = MF_PAIRS * 128;                           // doubles per block: [pair][lane][2]
+constexpr int MF_Q = 9;                                          // states per lane
+__host__ __device__ constexpr int mf_state(int slot) { return 9 * (slot & 3) + (slot >> 2); }
+
+// operand w = kb * 3 + rb of block b: fwd = exp(T)[to = row][from = k] (alpha), bwd = its transpose (backward)
+__global__ void mfma_blocks_kernel(int64_t n_blocks, const double *__restrict__ t, double *__restrict__ fwd,
+                                   double *__restrict__ bwd) {
+    const int64_t total = n_blocks * MF_BLK;
+    for (int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; x < total;
+         x += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = x / MF_BLK;
+        const int at = (int)(x - b * MF_BLK);
+        const int w = 2 * (at / 128) + (at & 1), l = (at >> 1) & 63;
+        double vf = 0.0, vb = 0.0;
+        if (w < MF_OPS) {
+            const int kb = w / MF_RB, rb = w % MF_RB;
+            const int out = 16 * rb + (l & 15), in = mf_state(4 * kb + (l >> 4));      // k slot <= 35
+            if (out < MF_S) {
+                vf = exp(t[b * (MF_S * MF_S) + mf_state(out) * MF_S + in]);
+                vb = exp(t[b * (MF_S * MF_S) + in * MF_S + mf_state(out)]);
+            } else if (out < MF_S + 4) {
+                vf = vb = 1.0;
+            }
+        }
+        fwd[x] = vf;
+        bwd[x] = vb;
+    }
+}
+
+__device__ __forceinline__ void mfma_load_block(const double *__restrict__ blk, int lane, double (&a)[2 * MF_PAIRS]) {
+    const double2 *src = reinterpret_cast<const double2 *>(blk) + lane;
+#pragma unroll
+    for (int p = 0; p < MF_PAIRS; ++p) {
+        const double2 v = src[p * 64];
+        a[2 * p] = v.x;
+        a[2 * p + 1] = v.y;
+    }
+}
+
+// a lane's nine states of one per-state row (72 contiguous bytes)
+__device__ __forceinline__ void mfma_load_row(const double *__restrict__ row9, double (&v)[MF_Q]) {
+    const mf_pair *src = reinterpret_cast<const mf_pair *>(row9);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const mf_pair pr = src[m];
+        v[2 * m] = pr.x;
+        v[2 * m + 1] = pr.y;
+    }
+    v[8] = row9[8];
+}
+__device__ __forceinline__ void mfma_store_row(double *__restrict__ row9, const double (&v)[MF_Q]) {
+    mf_pair *dst = reinterpret_cast<mf_pair *>(row9);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) dst[m] = mf_pair{v[2 * m], v[2 * m + 1]};
+    row9[8] = v[8];
+}
+
+// D = M y for the three row blocks (third first: it carries Z, whose reciprocal the rest waits for)
+__device__ __forceinline__ void mfma_matvec(const double (&a)[2 * MF_PAIRS], const double (&y)[MF_Q], mfma_d4 &d0, mfma_d4 &d1,
+                                            mfma_d4 &d2) {
+    d0 = d1 = d2 = mfma_d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int kb = 0; kb < MF_KB; ++kb) {
+        d2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kb * 3 + 2], y[kb], d2, 0, 0, 0);
+        d0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kb * 3 + 0], y[kb], d0, 0, 0, 0);
+        d1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kb * 3 + 1], y[kb], d1, 0, 0, 0);
+    }
+}
+
+__device__ __forceinline__ double mfma_own(const mfma_d4 &d0, const mfma_d4 &d1, const mfma_d4 &d2, int q) {
+    return q < 4 ? d0[q] : q < 8 ? d1[q - 4] : d2[0];
+}
+
+// alpha sweep (forward_wave_kernel role 0, same stored quantities: x, 1/Z)
+template <int NSET>
+__global__ void __launch_bounds__(64)
+alpha_mfma_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *__restrict__ chroms,
+                  const int32_t *__restrict__ order, const double *__restrict__ amat,
+                  const double *__restrict__ eprob, const double *__restrict__ peprob,
+                  const double *__restrict__ init_vec, double *__restrict__ xsum, double *__restrict__ invz) {
+    constexpr int S = MF_S;
+    const ChromDesc cd = chroms[order[blockIdx.y]];
+    const int n = cd.n_genes;
+    if (n <= 0) return;
+    const int lane = threadIdx.x, g = lane >> 4;
+    const int sample = min((int)blockIdx.x * 16 + (lane & 15), n_samples - 1);
+    const int64_t g0 = (int64_t)sample * genes_per_sample + cd.gene_off;
+    const int n_ord = min(n, cd.n_trans + 1) - 1;       // step i = o + 1 needs block o
+    const int last_o = max(n_ord - 1, 0);
+    const double *BLK = amat + cd.trans_off * (int64_t)MF_BLK;
+    const double *pe_row = peprob + g0 * S + 9 * g;     // + i * S: my states of gene i
+    double *x_row = xsum + g0 * S + 9 * g;
+    double *iz = invz + g0;
+    double y[MF_Q];
+    {
+        double e0[MF_Q], iv[MF_Q], x0[MF_Q];
+        mfma_load_row(eprob + g0 * S + 9 * g, e0);
+        mfma_load_row(init_vec + 9 * g, iv);
+#pragma unroll
+        for (int q = 0; q < MF_Q; ++q) {
+            y[q] = exp(iv[q] + e0[q]);
+            x0[q] = exp(iv[q]);                          // so that log(x) + e reproduces init + e
+        }
+        mfma_store_row(x_row, x0);
+    }
+    double a[NSET][2 * MF_PAIRS], pe[NSET][MF_Q];
+#pragma unroll
+    for (int u = 0; u < NSET; ++u) {
+        const int ou = min(u, last_o);
+        if (n_ord > 0) {
+            mfma_load_block(BLK + (int64_t)HMM_BLK(ou) * MF_BLK, lane, a[u]);
+            mfma_load_row(pe_row + (int64_t)(ou + 1) * S, pe[u]);
+        }
+    }
+    auto step = [&](int o, const double (&ac)[2 * MF_PAIRS], const double (&pc)[MF_Q], double (&an)[2 * MF_PAIRS], double (&pn)[MF_Q]) {
+        mfma_d4 d0, d1, d2;
+        mfma_matvec(ac, y, d0, d1, d2);
+        double pe_now[MF_Q];
+#pragma unroll
+        for (int q = 0; q < MF_Q; ++q) pe_now[q] = pc[q];
+        // refill the set the previous step released (clamped index: past the end it re-reads the last block)
+        const int of = min(o + NSET - 1, last_o);
+        mfma_load_block(BLK + (int64_t)HMM_BLK(of) * MF_BLK, lane, an);
+        mfma_load_row(pe_row + (int64_t)(of + 1) * S, pn);
+        const double inv_z = fast_recip_pos(d2[1]);            // Z of the previous vector
+        if (g == 0) iz[o] = inv_z;
+        double x[MF_Q];
+#pragma unroll
+        for (int q = 0; q < MF_Q; ++q) {
+            x[q] = mfma_own(d0, d1, d2, q) * inv_z + TINY;
+            y[q] = x[q] * pe_now[q];
+        }
+        mfma_store_row(x_row + (int64_t)(o + 1) * S, x);
+    };
+    int o = 0;
+    for (; o + NSET <= n_ord; o += NSET) {
+#pragma unroll
+        for (int u = 0; u < NSET; ++u) step(o + u, a[u], pe[u], a[(u + NSET - 1) % NSET], pe[(u + NSET - 1) % NSET]);
+    }
+#pragma unroll
+    for (int u = 0; u < NSET - 1; ++u)
+        if (o + u < n_ord) step(o + u, a[u], pe[u], a[(u + NSET - 1) % NSET], pe[(u + NSET - 1) % NSET]);
+    // Z of the last vector: my nine states, then the four lane groups of my sample
+    double z = 0.0;
+#pragma unroll
+    for (int q = 0; q < MF_Q; ++q) z += y[q];
+    z += __shfl_xor(z, 16, 64);
+    z += __shfl_xor(z, 32, 64);
+    if (g == 0) iz[n_ord] = fast_recip_pos(z);
+}
+
+// free-running backward sweep (backward_wave_kernel's quantities, rescaled on every step: bscale is general)
+template <int NSET>
+__global__ void __launch_bounds__(64)
+backward_mfma_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *__restrict__ chroms,
+                     const int32_t *__restrict__ order, const double *__restrict__ amat_t,
+                     const double *__restrict__ peprob, double *__restrict__ bhat, double *__restrict__ bscale) {
+    constexpr int S = MF_S;
+    const ChromDesc cd = chroms[order[blockIdx.y]];
+    const int n = cd.n_genes;
+    if (n <= 0) return;
+    const int lane = threadIdx.x, g = lane >> 4;
+    const int sample = min((int)blockIdx.x * 16 + (lane & 15), n_samples - 1);
+    const int64_t g0 = (int64_t)sample * genes_per_sample + cd.gene_off;
+    const double *BLK = amat_t + cd.trans_off * (int64_t)MF_BLK;
+    const double *pe_row = peprob + g0 * S + 9 * g;
+    double *b_row = bhat + g0 * S + 9 * g;
+    double *bs = bscale + g0;
+    double w[MF_Q];                                   // pe_{i+1} * bt_{i+1}
+    {
+        double one[MF_Q];
+#pragma unroll
+        for (int q = 0; q < MF_Q; ++q) one[q] = 1.0;
+        mfma_load_row(pe_row + (int64_t)(n - 1) * S, w);
+        mfma_store_row(b_row + (int64_t)(n - 1) * S, one);
+        if (g == 0) bs[n - 1] = 1.0;
+    }
+    // order o <-> gene i = n-2-o, transition block i (the host checked n_trans >= n-1)
+    const int n_ord = n - 1;
+    const int last_o = max(n_ord - 1, 0);
+    double a[NSET][2 * MF_PAIRS], pe[NSET][MF_Q];
+#pragma unroll
+    for (int u = 0; u < NSET; ++u) {
+        const int i = n - 2 - min(u, last_o);
+        if (n_ord > 0) {
+            mfma_load_block(BLK + (int64_t)HMM_BLK(i) * MF_BLK, lane, a[u]);
+            mfma_load_row(pe_row + (int64_t)i * S, pe[u]);
+        }
+    }
+    auto step = [&](int o, const double (&ac)[2 * MF_PAIRS], const double (&pc)[MF_Q], double (&an)[2 * MF_PAIRS], double (&pn)[MF_Q]) {
+        const int i = n - 2 - o;
+        mfma_d4 d0, d1, d2;
+        mfma_matvec(ac, w, d0, d1, d2);
+        double pe_now[MF_Q];
+#pragma unroll
+        for (int q = 0; q < MF_Q; ++q) pe_now[q] = pc[q];
+        const int in = n - 2 - min(o + NSET - 1, last_o);
+        mfma_load_block(BLK + (int64_t)HMM_BLK(in) * MF_BLK, lane, an);
+        mfma_load_row(pe_row + (int64_t)in * S, pn);
+        const double r = fast_recip_pos(d2[1]);
+        if (g == 0) bs[i] = r;
+        double bh[MF_Q];
+#pragma unroll
+        for (int q = 0; q < MF_Q; ++q) {
+            bh[q] = mfma_own(d0, d1, d2, q) * r;
+            w[q] = bh[q] * pe_now[q];
+        }
+        mfma_store_row(b_row + (int64_t)i * S, bh);
+    };
+    int o = 0;
+    for (; o + NSET <= n_ord; o += NSET) {
+#pragma unroll
+        for (int u = 0; u < NSET; ++u) step(o + u, a[u], pe[u], a[(u + NSET - 1) % NSET], pe[(u + NSET - 1) % NSET]);
+    }
+#pragma unroll
+    for (int u = 0; u < NSET - 1; ++u)
+        if (o + u < n_ord) step(o + u, a[u], pe[u], a[(u + NSET - 1) % NSET], pe[(u + NSET - 1) % NSET]);
+}
+
 // log C_i of backward_wave_kernel's comment for one (chromosome, sample): a suffix sum over genes
 __global__ void __launch_bounds__(256)
 beta_corr_kernel(int64_t genes_per_sample, const ChromDesc *__restrict__ chroms,
@@ -1633,6 +1883,7 @@ struct gbrs_hmm {
     DevBuf<double> tprob, pprob, pprob_t, init_vec;   // log T, exp(T), exp(T) transposed per block
     DevBuf<double> tprob_q;                   // S = 36 / 136: log T in the chain kernels' lane order (pprob, pprob_t too)
     bool quad = false;                        // tables are in lane order
+    DevBuf<double> amat_f, amat_b;            // S = 36, large batches: the MFMA operands of exp(T) and its transpose (made on first use)
     DevBuf<double> expr, avecs, eprob, peprob, xsum, bhat, alpha, beta, gamma, delta, scaler, invz;
     DevBuf<double> bscale, bcorr;             // free-running backward: per-gene scale and log correction
     DevBuf<uint8_t> has_avec;
@@ -1726,6 +1977,12 @@ int hmm_make_logs(gbrs_hmm *h) {
 #ifndef HMM_NSET_B
 #define HMM_NSET_B 3      // register sets of the HMM_SB-samples-per-wave recursions
 #endif
+#ifndef HMM_MFMA_MIN
+#define HMM_MFMA_MIN 96   // 36 states, at least this many samples: alpha and backward sweeps of 16 samples per wave on MFMA (see the kernels' comment)
+#endif
+#ifndef HMM_NSET_M
+#define HMM_NSET_M 3      // register sets (transition blocks in flight) of the MFMA sweeps
+#endif
 
 // SS_WAVE > 0: the single-wave chain kernels for that (even, <= 64) state count; otherwise KMAX / MAXT /
 // EXACT select the quad chains (EXACT, S = 4*KMAX > 64) or the generic multi-wave kernels.
@@ -1773,12 +2030,36 @@ int hmm_launch(gbrs_hmm *h) {
             auto k_alpha = batched ? &forward_wave_kernel<SS, HMM_NSET_B, HMM_SB, 0, 18> : &forward_wave_kernel<SS, HMM_NSET, 1, 0, HMM_HOIST_A>;
             auto k_delta = batched ? &forward_wave_kernel<SS, HMM_NSET_B, HMM_SB, 1, 18> : &forward_wave_kernel<SS, HMM_NSET, 1, 1, HMM_HOIST_D>;
             auto k_back = batched ? &backward_wave_kernel<SS, HMM_NSET_B, HMM_SB> : &backward_wave_kernel<SS, HMM_NSET, 1>;
+            // GBRS_TUNING_HMM_MFMA = smallest batch that takes the MFMA sweeps (0: never) - the parity tests run them at 16
+            int mfma_min = HMM_MFMA_MIN;
+            if (const char *env = std::getenv("GBRS_TUNING_HMM_MFMA"); env) mfma_min = std::atoi(env) > 0 ? std::atoi(env) : INT_MAX;
+            const bool mfma = SS == MF_S && h->n_samples >= mfma_min && h->total_trans > 0;
+            if (mfma && !h->amat_f.p) {
+                GBRS_TRY(h->amat_f.alloc((size_t)h->total_trans * MF_BLK));
+                GBRS_TRY(h->amat_b.alloc((size_t)h->total_trans * MF_BLK));
+                hipLaunchKernelGGL(mfma_blocks_kernel, dim3(4096), dim3(256), 0, sa, h->total_trans, h->tprob.p,
+                                   h->amat_f.p, h->amat_b.p);
+                GBRS_HIP_CHECK(hipEventRecord(h->ev[1], sa));        // one-off table work stays outside the run's timing
+            }
+            const dim3 mfma_grid((h->n_samples + 15) / 16, h->n_chrom);
             launch_alpha = [=](hipStream_t st) {
+                if (mfma) {
+                    hipLaunchKernelGGL((alpha_mfma_kernel<HMM_NSET_M>), mfma_grid, dim3(64), 0, st, h->n_samples, h->total_genes,
+                                       h->d_chroms.p, h->d_order.p, h->amat_f.p, h->eprob.p, h->peprob.p, h->init_vec.p,
+                                       h->xsum.p, h->invz.p);
+                    return;
+                }
                 hipLaunchKernelGGL(k_alpha, wave_grid, dim3(64), 0, st, h->n_samples, h->total_genes,
                                    h->d_chroms.p, h->d_order.p, h->tprob_q.p, h->pprob.p, h->eprob.p, h->peprob.p,
                                    h->init_vec.p, h->xsum.p, h->invz.p, h->delta.p, h->last_state.p);
             };
             launch_back = [=](hipStream_t st) {
+                if (mfma) {
+                    hipLaunchKernelGGL((backward_mfma_kernel<HMM_NSET_M>), mfma_grid, dim3(64), 0, st, h->n_samples,
+                                       h->total_genes, h->d_chroms.p, h->d_order.p, h->amat_b.p, h->peprob.p, h->bhat.p,
+                                       h->bscale.p);
+                    return;
+                }
                 hipLaunchKernelGGL(k_back, wave_grid, dim3(64), 0, st, h->n_samples, h->total_genes,
                                    h->d_chroms.p, h->d_order.p, h->pprob_t.p, h->peprob.p, h->bhat.p, h->bscale.p);
             };

@@ -131,15 +131,17 @@ def test_hmm_full_size_properties():
     hmm.close()
 
 
-@pytest.mark.parametrize("n_samples", [1, 4, 5, 25])
+@pytest.mark.parametrize("n_samples", [1, 4, 5, 16, 25, 40])
 @pytest.mark.parametrize("minus_one", [False, True], ids=["tprob_n", "tprob_n_minus_1"])
-def test_hmm_sample_batches_and_short_chromosomes(n_samples, minus_one):
-    """8 founders (the single-wave kernels): distinct samples in one launch, including batch sizes
+def test_hmm_sample_batches_and_short_chromosomes(n_samples, minus_one, monkeypatch):
+    """8 founders (the single-wave kernels; from 16 samples on this test sends the alpha and backward sweeps
+    through the 16-samples-per-wavefront MFMA kernels that large batches use): distinct samples in one launch, including batch sizes
     that leave a partly filled wave, chromosomes of 1, 2, 3 genes and lengths around the prefetch
     ring and backtrace chunk sizes, both tprob-length conventions; every sample against the oracle."""
     from gbrs_amd import synth
     from gbrs_amd.hmm import DiplotypeHMM
     from oracle import hmm_oracle
+    monkeypatch.setenv("GBRS_TUNING_HMM_MFMA", "16")
     lens = [1, 2, 3, 4, 5, 7, 63, 64, 65, 129, 200]
     probs = [synth.make_hmm_problem(H=8, genes_per_chrom=lens, seed=1234 + s, tprob_len_minus_one=minus_one)
              for s in range(n_samples)]
@@ -162,6 +164,42 @@ def test_hmm_sample_batches_and_short_chromosomes(n_samples, minus_one):
             np.testing.assert_array_equal(r["states"], res[c]["states"], err_msg=f"sample {s} chrom {c}")
             np.testing.assert_array_equal(r["calls"], res[c]["calls"], err_msg=f"sample {s} chrom {c}")
             for k in ("alpha", "beta", "delta", "scaler"):
+                np.testing.assert_allclose(r[k], res[c][k], rtol=1e-9, atol=1e-9, err_msg=f"{k} sample {s} chrom {c}")
+            np.testing.assert_allclose(r["gamma"], res[c]["gamma"], rtol=1e-8, atol=1e-300)
+    hmm.close()
+
+
+@pytest.mark.parametrize("n_samples", [3, 21])
+def test_hmm_do_tables_sample_batches(n_samples, monkeypatch):
+    """DO-like transition tables (entries down to exp(-69), structural zeros, a near-deterministic chain) and
+    sparsely expressed samples, single-sample kernels (3) and the 16-samples-per-wave MFMA sweeps (21):
+    every sample against the oracle."""
+    from gbrs_amd import synth
+    from gbrs_amd.hmm import DiplotypeHMM
+    from oracle import hmm_oracle
+    monkeypatch.setenv("GBRS_TUNING_HMM_MFMA", "16")
+    lens = [1, 2, 17, 64, 150]
+    probs = [synth.make_hmm_problem(H=8, genes_per_chrom=lens, seed=4321 + s, style="do",
+                                    expressed_fraction=0.9 if s % 3 else 0.3) for s in range(n_samples)]
+    p0 = probs[0]
+    chroms = p0.chroms
+    hmm = DiplotypeHMM(8, chroms, [len(p0.gene_ids[c]) for c in chroms], [p0.tprob[c] for c in chroms])
+    ex, av, ha = [], [], []
+    for c in chroms:
+        ids = p0.gene_ids[c]
+        ex.append(np.array([[p.expr[g] for g in ids] for p in probs]))
+        ha.append(np.array([g in p0.avecs for g in ids], dtype=np.uint8))
+        av.append(np.array([p0.avecs.get(g, np.zeros((8, 8))) for g in ids]))
+    hmm.set_expression(ex, av, ha, 1.5, 0.12)
+    hmm.run()
+    want = ("gamma", "states", "calls", "alpha", "beta", "scaler")
+    for s, p in enumerate(probs):
+        res = hmm_oracle.reconstruct_arrays(p0.hap_names, chroms, p0.gene_ids, p0.tprob, p.expr, p0.avecs)
+        for ci, c in enumerate(chroms):
+            r = hmm.get(ci, sample=s, want=want)
+            np.testing.assert_array_equal(r["calls"], res[c]["calls"], err_msg=f"sample {s} chrom {c}")
+            np.testing.assert_array_equal(r["states"], res[c]["states"], err_msg=f"sample {s} chrom {c}")
+            for k in ("alpha", "beta", "scaler"):
                 np.testing.assert_allclose(r[k], res[c][k], rtol=1e-9, atol=1e-9, err_msg=f"{k} sample {s} chrom {c}")
             np.testing.assert_allclose(r["gamma"], res[c]["gamma"], rtol=1e-8, atol=1e-300)
     hmm.close()
