@@ -7,7 +7,7 @@ python bench.py > $O/bench_default.log 2> $O/bench_default.err
 python bench.py --no-e2e --no-hmm --no-cpu-baseline --no-merged-line --flags 32 > $O/bench_deterministic_C2.log 2>&1
 python bench.py --no-e2e --rows 25000000 --haps 16 --loci 200000 --steps 20 --warmup 2 --no-hmm --no-cpu-baseline --no-merged-line > $O/bench_C5_shard_25M_x16.log 2>&1
 python bench.py --no-e2e --rows 200000 --steps 2 --warmup 1 --no-cpu-baseline --no-merged-line --hmm-haps 16 --hmm-batch 8 > $O/bench_hmm_16founders.log 2>&1
-python bench.py --gpus 2 --backend gloo --steps 10 --warmup 2 --no-cpu-baseline > $O/bench_gloo_2ranks.log 2>&1
+python bench.py --gpus 2 --backend gloo --steps 10 --warmup 2 --no-cpu-baseline --hmm-batch-large 0 > $O/bench_gloo_2ranks.log 2>&1
 python bench.py --no-e2e --no-hmm --no-cpu-baseline --no-merged-line --rccl-selftest --no-overlap > $O/bench_rccl_selftest_single.log 2>&1
 python bench.py --no-e2e --no-hmm --no-cpu-baseline --no-merged-line --rccl-selftest --force-overlap-path > $O/bench_rccl_selftest_pipelined.log 2>&1
 export TMPDIR=/tmp R=$PWD; cd /tmp
