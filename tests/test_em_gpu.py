@@ -369,7 +369,11 @@ def _random_rows_problem(R, H, L, seed, min_loci, max_loci, with_count):
 @pytest.mark.parametrize("R,H,L,lo,hi,cnt", [(4000, 8, 3000, 1, 12, False),      # cold tiles, rows up to 12 words
                                              (600, 8, 400, 20, 70, True),        # long rows (> 32 loci), weighted
                                              (500, 16, 300, 10, 40, False),      # H = 16: long above 16 loci
-                                             (20000, 8, 20000, 1, 3, False)])    # many distinct lists: dictionary cuts
+                                             (20000, 8, 20000, 1, 3, False),     # many distinct lists: dictionary cuts
+                                             (3000, 3, 500, 1, 6, False),        # generic haplotype counts: locus-major theta,
+                                             (2000, 5, 300, 1, 9, True),         #   integer-built 0/1 doubles
+                                             (1500, 2, 200, 1, 4, False),
+                                             (800, 1, 100, 1, 3, True)])
 def test_em_unstructured_rows_vs_oracle(R, H, L, lo, hi, cnt):
     from gbrs_amd.engine import EmEngine
     from oracle.em_oracle import EMOracle
@@ -378,7 +382,7 @@ def test_em_unstructured_rows_vs_oracle(R, H, L, lo, hi, cnt):
     o.prepare(0.0, eff)
     theta0 = o.theta.copy()
     o.run(tol=0.0, max_iters=4)
-    for flags in (0, 1, 2):                                      # tiles, tiles + merge, csc
+    for flags in (0, 1, 2, 32):                                  # tiles, tiles + merge, csc, deterministic tiles
         eng = EmEngine.from_host(R, L, H, indptr, indices, count, eff, flags=flags)
         eng.prepare(0.0)
         close(eng.theta(), theta0)
