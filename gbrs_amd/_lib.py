@@ -24,7 +24,7 @@ EXPORTS = [
     "gbrs_hmm_get", "gbrs_hmm_info", "gbrs_hmm_destroy", "gbrs_interpolate", "gbrs_genoprob_dosage",
     "gbrs_compress_create", "gbrs_compress_get", "gbrs_compress_destroy",
     "gbrs_format_double", "gbrs_write_locus_table", "gbrs_parse_length_table",
-    "gbrs_decode_chunks", "gbrs_inflate_backend",
+    "gbrs_decode_chunks", "gbrs_inflate_backend", "gbrs_zip_directory", "gbrs_npz_stack", "gbrs_zip_read_members",
 ]
 
 GBRS_OK = 0
@@ -124,12 +124,8 @@ def load():
         "gbrs_compress_create": [u64, u32, u32, pp, pp, vp, i32, pp, C.POINTER(u64), vp],
         "gbrs_compress_get": [vp, pp, pp, vp],
         "gbrs_compress_destroy": [vp],
-        "gbrs_format_double": [dbl, C.c_char_p],
-        "gbrs_decode_chunks": [C.c_char_p, i64, vp, vp, vp, vp, u64, u32, u64, i32, i32, vp, i32],
-        "gbrs_inflate_backend": [],
-        "gbrs_parse_length_table": [C.c_char_p, i64, C.c_char_p, vp, i64, C.c_char_p, vp, i32, dbl, vp],
-        "gbrs_write_locus_table": [C.c_char_p, C.c_char_p, vp, i64, i32, i64, i64, vp, C.c_char_p, vp, C.c_char_p, vp, vp],
     }
+    sigs.update(_host_signatures())
     for name, args in sigs.items():
         fn = getattr(lib, name)
         fn.restype = i32
@@ -140,6 +136,21 @@ def load():
         raise ImportError("libgbrs_hip.so ABI version mismatch")
     _lib = lib
     return lib
+
+
+def _host_signatures():
+    """The host-only entry points of the library (gbrs_amd/csrc/hostio.hip)."""
+    vp, i32, u32, u64, i64, dbl = C.c_void_p, C.c_int, C.c_uint32, C.c_uint64, C.c_int64, C.c_double
+    return {
+        "gbrs_format_double": [dbl, C.c_char_p],
+        "gbrs_decode_chunks": [C.c_char_p, i64, vp, vp, vp, vp, u64, u32, u64, i32, i32, vp, i32],
+        "gbrs_inflate_backend": [],
+        "gbrs_zip_directory": [vp, u64, u64, vp, vp, vp, vp, vp, u64, C.POINTER(u64), C.POINTER(u64)],
+        "gbrs_npz_stack": [vp, u64, i64, vp, vp, vp, vp, vp, u64, u64, vp, vp, i32],
+        "gbrs_zip_read_members": [vp, u64, i64, vp, vp, vp, vp, vp, i32],
+        "gbrs_parse_length_table": [C.c_char_p, i64, C.c_char_p, vp, i64, C.c_char_p, vp, i32, dbl, vp],
+        "gbrs_write_locus_table": [C.c_char_p, C.c_char_p, vp, i64, i32, i64, i64, vp, C.c_char_p, vp, C.c_char_p, vp, vp],
+    }
 
 
 def check(status):

@@ -104,12 +104,26 @@ typedef int (*uncompress_fn)(unsigned char *, unsigned long *, const unsigned ch
 typedef void *(*ld_alloc_fn)(void);
 typedef void (*ld_free_fn)(void *);
 typedef int (*ld_inflate_fn)(void *, const void *, size_t, void *, size_t, size_t *);
+// zlib's streaming interface, for raw deflate streams (zip members): z_stream is opaque here except for the
+// leading fields the caller sets, so the struct below mirrors zlib.h's layout on LP64
+struct ZStream {
+    const unsigned char *next_in; unsigned int avail_in; unsigned long total_in;
+    unsigned char *next_out; unsigned int avail_out; unsigned long total_out;
+    const char *msg; void *state; void *zalloc; void *zfree; void *opaque; int data_type; unsigned long adler; unsigned long reserved;
+};
+typedef int (*z_init2_fn)(ZStream *, int, const char *, int);
+typedef int (*z_inflate_fn)(ZStream *, int);
+typedef int (*z_end_fn)(ZStream *);
 
 struct Inflaters {
     uncompress_fn z_uncompress = nullptr;
     ld_alloc_fn ld_alloc = nullptr;
     ld_free_fn ld_free = nullptr;
     ld_inflate_fn ld_inflate = nullptr;
+    ld_inflate_fn ld_inflate_raw = nullptr;       // libdeflate_deflate_decompress: no zlib wrapper (zip members)
+    z_init2_fn z_init2 = nullptr;
+    z_inflate_fn z_inflate = nullptr;
+    z_end_fn z_end = nullptr;
     Inflaters() {
         // libdeflate (about three times zlib's inflate speed) when the machine has it, zlib otherwise;
         // both are looked up at run time so the library has no link-time dependency on either
@@ -120,14 +134,18 @@ struct Inflaters {
                 ld_alloc = (ld_alloc_fn)dlsym(h, "libdeflate_alloc_decompressor");
                 ld_free = (ld_free_fn)dlsym(h, "libdeflate_free_decompressor");
                 ld_inflate = (ld_inflate_fn)dlsym(h, "libdeflate_zlib_decompress");
-                if (ld_alloc && ld_free && ld_inflate) break;
-                ld_alloc = nullptr; ld_free = nullptr; ld_inflate = nullptr;
+                ld_inflate_raw = (ld_inflate_fn)dlsym(h, "libdeflate_deflate_decompress");
+                if (ld_alloc && ld_free && ld_inflate && ld_inflate_raw) break;
+                ld_alloc = nullptr; ld_free = nullptr; ld_inflate = nullptr; ld_inflate_raw = nullptr;
             }
         }
         const char *z_names[] = {"libz.so.1", "libz.so", "/opt/conda/lib/libz.so.1"};
         for (const char *n : z_names)
             if (void *h = dlopen(n, RTLD_NOW | RTLD_LOCAL)) {
                 z_uncompress = (uncompress_fn)dlsym(h, "uncompress");
+                z_init2 = (z_init2_fn)dlsym(h, "inflateInit2_");
+                z_inflate = (z_inflate_fn)dlsym(h, "inflate");
+                z_end = (z_end_fn)dlsym(h, "inflateEnd");
                 if (z_uncompress) break;
             }
     }
@@ -137,6 +155,31 @@ static const Inflaters &inflaters() {
     static const Inflaters inf;
     return inf;
 }
+
+// one raw deflate stream -> exactly out_bytes bytes; ld = this thread's libdeflate decompressor or null
+static bool inflate_raw(const Inflaters &inf, void *ld, const unsigned char *in, size_t in_bytes, unsigned char *out,
+                        size_t out_bytes) {
+    if (ld && inf.ld_inflate_raw) {
+        size_t n = 0;
+        if (inf.ld_inflate_raw(ld, in, in_bytes, out, out_bytes, &n) == 0 && n == out_bytes) return true;
+    }
+    if (inf.z_init2 && inf.z_inflate && inf.z_end && in_bytes <= 0xFFFFFFFFu && out_bytes <= 0xFFFFFFFFu) {
+        ZStream zs;
+        std::memset(&zs, 0, sizeof(zs));
+        if (inf.z_init2(&zs, -15, "1.2.11", (int)sizeof(ZStream)) != 0) return false;
+        zs.next_in = in; zs.avail_in = (unsigned int)in_bytes;
+        zs.next_out = out; zs.avail_out = (unsigned int)out_bytes;
+        const int rc = inf.z_inflate(&zs, 4 /* Z_FINISH */);
+        const bool ok = rc == 1 /* Z_STREAM_END */ && zs.total_out == out_bytes;
+        inf.z_end(&zs);
+        return ok;
+    }
+    return false;
+}
+
+static uint16_t rd16(const unsigned char *p) { return (uint16_t)(p[0] | (p[1] << 8)); }
+static uint32_t rd32(const unsigned char *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+static uint64_t rd64(const unsigned char *p) { return (uint64_t)rd32(p) | ((uint64_t)rd32(p + 4) << 32); }
 
 }  // namespace gbrs
 
@@ -231,6 +274,181 @@ int gbrs_decode_chunks(const char *path, int64_t n_chunks, const uint64_t *file_
     if (failed.load() == 1) return fail(GBRS_ERR_INVALID, "short read from %s", path);
     if (failed.load() == 2) return fail(GBRS_ERR_INVALID, "a chunk of %s does not inflate to the chunk size", path);
     if (failed.load() == 3) return fail(GBRS_ERR_INVALID, "a chunk of %s is shorter than the chunk size", path);
+    return GBRS_OK;
+}
+
+int gbrs_zip_directory(const uint8_t *buf, uint64_t len, uint64_t cap, uint16_t *method, uint64_t *csize,
+                       uint64_t *usize, uint64_t *header_off, char *names, uint64_t names_cap, uint64_t *n_members,
+                       uint64_t *names_len) {
+    using gbrs::fail;
+    using gbrs::rd16; using gbrs::rd32; using gbrs::rd64;
+    if (!buf || !n_members || !names_len) return fail(GBRS_ERR_INVALID, "bad argument");
+    *n_members = 0;
+    *names_len = 0;
+    if (len < 22) return fail(GBRS_ERR_INVALID, "not a zip file");
+    // end-of-central-directory record: the last 22 bytes + an optional comment of up to 65,535 bytes
+    const uint64_t lowest = len > 22 + 65535 ? len - 22 - 65535 : 0;
+    uint64_t eocd = len - 22;
+    for (;; --eocd) {
+        if (rd32(buf + eocd) == 0x06054b50u) break;
+        if (eocd == lowest) return fail(GBRS_ERR_INVALID, "no end-of-central-directory record");
+    }
+    const uint16_t disk = rd16(buf + eocd + 4), cd_disk = rd16(buf + eocd + 6), n_here = rd16(buf + eocd + 8),
+                   n_total = rd16(buf + eocd + 10);
+    uint64_t cd_off = rd32(buf + eocd + 16), n = n_total;
+    if (disk || cd_disk || n_here != n_total) return fail(GBRS_ERR_UNSUPPORTED, "multi-disk zip file");
+    if (n_total == 0xFFFFu || cd_off == 0xFFFFFFFFu) {
+        // zip64: the locator sits right before the end record and points at the zip64 end record
+        if (eocd < 20 || rd32(buf + eocd - 20) != 0x07064b50u) return fail(GBRS_ERR_UNSUPPORTED, "zip64 locator missing");
+        const uint64_t z = rd64(buf + eocd - 20 + 8);
+        if (z + 56 > len || rd32(buf + z) != 0x06064b50u) return fail(GBRS_ERR_INVALID, "bad zip64 end record");
+        n = rd64(buf + z + 32);
+        cd_off = rd64(buf + z + 48);
+    }
+    uint64_t pos = cd_off, nlen_total = 0;
+    for (uint64_t k = 0; k < n; ++k) {
+        if (pos + 46 > len || rd32(buf + pos) != 0x02014b50u) return fail(GBRS_ERR_INVALID, "bad central directory entry %llu", (unsigned long long)k);
+        const uint16_t m = rd16(buf + pos + 10), nlen = rd16(buf + pos + 28), xlen = rd16(buf + pos + 30), clen = rd16(buf + pos + 32);
+        uint64_t cs = rd32(buf + pos + 20), us = rd32(buf + pos + 24), ho = rd32(buf + pos + 42);
+        if (pos + 46 + nlen + xlen + clen > len) return fail(GBRS_ERR_INVALID, "central directory runs past the file");
+        if (cs == 0xFFFFFFFFu || us == 0xFFFFFFFFu || ho == 0xFFFFFFFFu) {
+            // zip64 extended information: the 64-bit values of the saturated fields, in this order
+            const uint8_t *x = buf + pos + 46 + nlen;
+            uint64_t at = 0;
+            bool found = false;
+            while (at + 4 <= xlen) {
+                const uint16_t tag = rd16(x + at), ln = rd16(x + at + 2);
+                if (at + 4 + ln > xlen) break;
+                if (tag == 1) {
+                    uint64_t q = at + 4;
+                    const uint64_t end = at + 4 + ln;
+                    if (us == 0xFFFFFFFFu && q + 8 <= end) { us = rd64(x + q); q += 8; }
+                    if (cs == 0xFFFFFFFFu && q + 8 <= end) { cs = rd64(x + q); q += 8; }
+                    if (ho == 0xFFFFFFFFu && q + 8 <= end) { ho = rd64(x + q); q += 8; }
+                    found = true;
+                    break;
+                }
+                at += 4 + (uint64_t)ln;
+            }
+            if (!found) return fail(GBRS_ERR_INVALID, "zip64 sizes missing for entry %llu", (unsigned long long)k);
+        }
+        if (k < cap) {
+            if (!method || !csize || !usize || !header_off) return fail(GBRS_ERR_INVALID, "bad argument");
+            method[k] = m; csize[k] = cs; usize[k] = us; header_off[k] = ho;
+            if (names && nlen_total + nlen + 1 <= names_cap) {
+                std::memcpy(names + nlen_total, buf + pos + 46, nlen);
+                names[nlen_total + nlen] = '\n';
+            }
+        }
+        nlen_total += (uint64_t)nlen + 1;
+        pos += 46 + (uint64_t)nlen + xlen + clen;
+    }
+    *n_members = n;
+    *names_len = nlen_total;
+    return GBRS_OK;
+}
+
+int gbrs_zip_read_members(const uint8_t *buf, uint64_t len, int64_t n, const uint64_t *header_off, const uint16_t *method,
+                          const uint64_t *csize, const uint64_t *usize, uint8_t *const *out, int32_t threads) {
+    using gbrs::fail;
+    using gbrs::rd16; using gbrs::rd32;
+    if (!buf || n < 0 || (n && (!header_off || !method || !csize || !usize || !out))) return fail(GBRS_ERR_INVALID, "bad argument");
+    const gbrs::Inflaters &inf = gbrs::inflaters();
+    unsigned nt = threads > 0 ? (unsigned)threads : std::thread::hardware_concurrency();
+    if (const char *e = std::getenv("GBRS_IO_THREADS"); threads <= 0 && e && std::atoi(e) > 0) nt = (unsigned)std::atoi(e);
+    nt = std::max(1u, std::min({nt, 64u, (unsigned)std::max<int64_t>(n, 1)}));
+    // largest members first: a member is one deflate stream, so the biggest one bounds the wall time
+    std::vector<int64_t> order((size_t)n);
+    for (int64_t k = 0; k < n; ++k) order[(size_t)k] = k;
+    std::sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return csize[a] > csize[b]; });
+    std::atomic<int64_t> next{0};
+    std::atomic<int> failed{0};
+    auto work = [&]() {
+        void *ld = inf.ld_inflate_raw ? inf.ld_alloc() : nullptr;
+        for (;;) {
+            const int64_t i = next.fetch_add(1);
+            if (i >= n || failed.load()) break;
+            const int64_t k = order[(size_t)i];
+            const uint64_t ho = header_off[k];
+            if (!out[k] || ho + 30 > len || rd32(buf + ho) != 0x04034b50u) { failed = 1; break; }
+            const uint64_t data = ho + 30 + rd16(buf + ho + 26) + rd16(buf + ho + 28);
+            if (data + csize[k] > len) { failed = 1; break; }
+            if (method[k] == 0) {
+                if (csize[k] != usize[k]) { failed = 2; break; }
+                std::memcpy(out[k], buf + data, usize[k]);
+            } else if (method[k] == 8) {
+                if (!gbrs::inflate_raw(inf, ld, buf + data, csize[k], out[k], usize[k])) { failed = 2; break; }
+            } else {
+                failed = 3;
+                break;
+            }
+        }
+        if (ld) inf.ld_free(ld);
+    };
+    {
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < nt; ++t) th.emplace_back(work);
+        work();
+        for (auto &x : th) x.join();
+    }
+    if (failed.load() == 1) return fail(GBRS_ERR_INVALID, "bad local header in the zip file");
+    if (failed.load() == 2) return fail(GBRS_ERR_INVALID, "a member does not inflate to its recorded size");
+    if (failed.load() == 3) return fail(GBRS_ERR_UNSUPPORTED, "compression method other than stored / deflate");
+    return GBRS_OK;
+}
+
+int gbrs_npz_stack(const uint8_t *buf, uint64_t len, int64_t n, const uint64_t *header_off, const uint16_t *method,
+                   const uint64_t *csize, const uint64_t *usize, const uint8_t *npy_header, uint64_t npy_header_len,
+                   uint64_t item_bytes, uint8_t *out, uint8_t *needs_fallback, int32_t threads) {
+    using gbrs::fail;
+    using gbrs::rd16; using gbrs::rd32;
+    if (!buf || n < 0 || (n && (!header_off || !method || !csize || !usize || !out || !needs_fallback)) || !npy_header)
+        return fail(GBRS_ERR_INVALID, "bad argument");
+    const gbrs::Inflaters &inf = gbrs::inflaters();
+    unsigned nt = threads > 0 ? (unsigned)threads : std::thread::hardware_concurrency();
+    if (const char *e = std::getenv("GBRS_IO_THREADS"); threads <= 0 && e && std::atoi(e) > 0) nt = (unsigned)std::atoi(e);
+    nt = std::max(1u, std::min({nt, 64u, (unsigned)std::max<int64_t>(n / 128, 1)}));
+    std::atomic<int64_t> next{0};
+    std::atomic<int> failed{0};
+    constexpr int64_t GRAIN = 64;
+    auto work = [&]() {
+        std::vector<unsigned char> plain;
+        void *ld = inf.ld_inflate_raw ? inf.ld_alloc() : nullptr;
+        for (;;) {
+            const int64_t k0 = next.fetch_add(GRAIN);
+            if (k0 >= n || failed.load()) break;
+            for (int64_t k = k0; k < std::min(n, k0 + GRAIN); ++k) {
+                needs_fallback[k] = 1;
+                const uint64_t ho = header_off[k];
+                if (ho + 30 > len || rd32(buf + ho) != 0x04034b50u) { failed = 1; break; }
+                const uint64_t data = ho + 30 + rd16(buf + ho + 26) + rd16(buf + ho + 28);
+                if (data + csize[k] > len) { failed = 1; break; }
+                if (usize[k] != npy_header_len + item_bytes) continue;      // another shape or dtype: the caller's business
+                const unsigned char *img = nullptr;
+                if (method[k] == 0) {
+                    if (csize[k] != usize[k]) continue;
+                    img = buf + data;
+                } else if (method[k] == 8) {
+                    plain.resize(usize[k]);
+                    if (!gbrs::inflate_raw(inf, ld, buf + data, csize[k], plain.data(), usize[k])) continue;   // python decides
+                    img = plain.data();
+                } else {
+                    continue;
+                }
+                if (std::memcmp(img, npy_header, npy_header_len) != 0) continue;
+                std::memcpy(out + (size_t)k * item_bytes, img + npy_header_len, item_bytes);
+                needs_fallback[k] = 0;
+            }
+        }
+        if (ld) inf.ld_free(ld);
+    };
+    {
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < nt; ++t) th.emplace_back(work);
+        work();
+        for (auto &x : th) x.join();
+    }
+    if (failed.load()) return fail(GBRS_ERR_INVALID, "bad local header in the zip file");
     return GBRS_OK;
 }
 

@@ -252,7 +252,7 @@ def _read_chunks_parallel(path, d, ftype, space):
     except ImportError:
         lib_native = None
     if lib_native is not None:
-        # pread + inflate + un-shuffle on C++ threads straight into `out` (libgbrs_hip's host-side helper)
+        # pread + inflate + un-shuffle on C++ threads straight into `out` (the library's host-side helper)
         tab = np.array(todo, dtype=np.uint64).reshape(len(todo), 4)
         start = np.ascontiguousarray(tab[:, 0])
         mask = np.ascontiguousarray(tab[:, 1].astype(np.uint32))

@@ -340,6 +340,28 @@ int gbrs_parse_length_table(const char *text, int64_t text_len, const char *name
                             int64_t n_loci, const char *haps, const int64_t *hap_off, int32_t n_haps,
                             double read_length, double *eff_out);
 
+/* `.npz` inputs of `gbrs reconstruct` (gbrs/gbrs_utils.py:420-441 opens avecs.npz with numpy.load and reads one
+ * member per gene, :490 - zipfile re-parses the member's header and CRC-checks it on every access).
+ * gbrs_zip_directory reads the central directory of a zip image (buf/len = the mapped file) once: member k's
+ * compression method (0 stored, 8 deflate), compressed and plain sizes and local-header offset, and the member
+ * names as one blob with an LF after each name.  Arrays hold `cap` members and `names_cap` bytes; the member count
+ * and the blob size come back in n_members / names_len, so a first call with cap = 0 sizes the second.
+ * GBRS_ERR_UNSUPPORTED: multi-disk archive (the caller falls back to zipfile). */
+int gbrs_zip_directory(const uint8_t *buf, uint64_t len, uint64_t cap, uint16_t *method, uint64_t *csize,
+                       uint64_t *usize, uint64_t *header_off, char *names, uint64_t names_cap, uint64_t *n_members,
+                       uint64_t *names_len);
+/* n members' plain contents (their .npy images), member k into out[k] (usize[k] bytes, caller allocated), copied or
+ * inflated on `threads` threads (0 = all cores), largest member first. */
+int gbrs_zip_read_members(const uint8_t *buf, uint64_t len, int64_t n, const uint64_t *header_off, const uint16_t *method,
+                          const uint64_t *csize, const uint64_t *usize, uint8_t *const *out, int32_t threads);
+/* n equally shaped .npy members (the per-gene 8 x 8 blocks) -> out[k * item_bytes ...], on `threads` threads
+ * (0 = all cores): a member whose .npy image is exactly npy_header followed by item_bytes of data is copied
+ * (stored) or inflated (raw deflate) into place; any other member gets needs_fallback[k] = 1 and is left to the
+ * caller. */
+int gbrs_npz_stack(const uint8_t *buf, uint64_t len, int64_t n, const uint64_t *header_off, const uint16_t *method,
+                   const uint64_t *csize, const uint64_t *usize, const uint8_t *npy_header, uint64_t npy_header_len,
+                   uint64_t item_bytes, uint8_t *out, uint8_t *needs_fallback, int32_t threads);
+
 #ifdef __cplusplus
 }
 #endif

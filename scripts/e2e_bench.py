@@ -150,9 +150,12 @@ def write_reconstruct_inputs(workdir, genes_tpm):
             avecs[g[i]] = a / a.sum(axis=1, keepdims=True)
     paths = dict(tprob=os.path.join(workdir, "tranprob.npz"), avecs=os.path.join(workdir, "avecs.npz"),
                  gpos=os.path.join(workdir, "ref.gene_pos.ordered.npz"), fai=os.path.join(workdir, "ref.fa.fai"))
-    np.savez(paths["tprob"], **tprob)
-    np.savez(paths["avecs"], **avecs)
-    np.savez(paths["gpos"], **gpos)
+    # deflated members, as the reference writes these files (np.savez_compressed: gbrs_utils.py:293, :379); the
+    # container is written by gbrs_amd.npzfast.savez_compressed only because it deflates the members on all cores
+    from gbrs_amd.npzfast import savez_compressed
+    savez_compressed(paths["tprob"], tprob)
+    savez_compressed(paths["avecs"], avecs)
+    savez_compressed(paths["gpos"], gpos)
     return paths, len(ids)
 
 

@@ -1,5 +1,6 @@
 // Driver for the sanitizer build of gbrs_amd/csrc/hostio.hip (host-side file I/O helpers of libgbrs_hip):
-// exercises the number formatter, the report writer, the length-table parser and the chunk decoder,
+// exercises the number formatter, the report writer, the length-table parser, the chunk decoder and the zip /
+// npz helpers,
 // including malformed inputs, under AddressSanitizer + UndefinedBehaviorSanitizer.  Exit code 0 = clean.
 #include <cinttypes>
 #include <cmath>
@@ -163,6 +164,98 @@ int main(int argc, char **argv) {
                                  chunk, 4, n, 0, 1, out.data(), 2) < 0);
         CHECK(gbrs_decode_chunks((dir + "/missing.bin").c_str(), 0, nullptr, nullptr, nullptr, nullptr, chunk, 4, n, 0, 1,
                                  out.data(), 1) < 0);
+    }
+    // ---- gbrs_zip_directory / gbrs_npz_stack: a hand-made archive of stored .npy members, then truncations,
+    //      random corruption of every region and absurd offsets - nothing may read outside the image
+    {
+        auto put16 = [](std::vector<unsigned char> &v, uint32_t x) { v.push_back(x & 255); v.push_back((x >> 8) & 255); };
+        auto put32 = [&](std::vector<unsigned char> &v, uint32_t x) { put16(v, x & 0xFFFF); put16(v, x >> 16); };
+        const int n = 40;
+        const std::string npy_header = std::string("\x93NUMPY\x01\x00\x76\x00", 10) + std::string(118, ' ');   // 128 bytes, contents immaterial here
+        const uint64_t item = 64;
+        std::vector<unsigned char> zip, cd;
+        std::vector<uint64_t> offs;
+        for (int k = 0; k < n; ++k) {
+            char name[32];
+            std::snprintf(name, sizeof(name), "gene%04d.npy", k);
+            const uint32_t nlen = (uint32_t)std::strlen(name), size = (uint32_t)(npy_header.size() + item);
+            offs.push_back(zip.size());
+            put32(zip, 0x04034b50u); put16(zip, 20); put16(zip, 0); put16(zip, 0); put16(zip, 0); put16(zip, 0x21);
+            put32(zip, 0); put32(zip, size); put32(zip, size); put16(zip, nlen); put16(zip, 0);
+            zip.insert(zip.end(), name, name + nlen);
+            zip.insert(zip.end(), npy_header.begin(), npy_header.end());
+            for (uint64_t b = 0; b < item; ++b) zip.push_back((unsigned char)(k + b));
+            put32(cd, 0x02014b50u); put16(cd, 20); put16(cd, 20); put16(cd, 0); put16(cd, 0); put16(cd, 0); put16(cd, 0x21);
+            put32(cd, 0); put32(cd, size); put32(cd, size); put16(cd, nlen); put16(cd, 0); put16(cd, 0); put16(cd, 0); put16(cd, 0);
+            put32(cd, 0); put32(cd, (uint32_t)offs.back());
+            cd.insert(cd.end(), name, name + nlen);
+        }
+        const uint32_t cd_off = (uint32_t)zip.size(), cd_size = (uint32_t)cd.size();
+        zip.insert(zip.end(), cd.begin(), cd.end());
+        put32(zip, 0x06054b50u); put16(zip, 0); put16(zip, 0); put16(zip, n); put16(zip, n); put32(zip, cd_size); put32(zip, cd_off); put16(zip, 0);
+
+        std::vector<uint16_t> method(n);
+        std::vector<uint64_t> cs(n), us(n), ho(n);
+        std::vector<char> names(4096);
+        uint64_t count = 0, nbytes = 0;
+        CHECK(gbrs_zip_directory(zip.data(), zip.size(), 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, &count, &nbytes) == 0);
+        CHECK(count == (uint64_t)n && nbytes == (uint64_t)n * 13);
+        CHECK(gbrs_zip_directory(zip.data(), zip.size(), n, method.data(), cs.data(), us.data(), ho.data(), names.data(), names.size(),
+                                 &count, &nbytes) == 0);
+        CHECK(std::strncmp(names.data(), "gene0000.npy\ngene0001.npy\n", 26) == 0 && ho[7] == offs[7] && us[7] == 192 && method[7] == 0);
+        std::vector<unsigned char> out(n * item, 0), fb(n, 9);
+        CHECK(gbrs_npz_stack(zip.data(), zip.size(), n, ho.data(), method.data(), cs.data(), us.data(),
+                             (const uint8_t *)npy_header.data(), npy_header.size(), item, out.data(), fb.data(), 3) == 0);
+        for (int k = 0; k < n; ++k) CHECK(fb[k] == 0 && out[k * item + 5] == (unsigned char)(k + 5));
+        {
+            std::vector<std::vector<unsigned char>> imgs(n, std::vector<unsigned char>(192));
+            std::vector<uint8_t *> ptrs(n);
+            for (int k = 0; k < n; ++k) ptrs[k] = imgs[k].data();
+            CHECK(gbrs_zip_read_members(zip.data(), zip.size(), n, ho.data(), method.data(), cs.data(), us.data(), ptrs.data(), 3) == 0);
+            for (int k = 0; k < n; ++k) CHECK(std::memcmp(imgs[k].data(), npy_header.data(), 128) == 0 && imgs[k][128 + 9] == (unsigned char)(k + 9));
+            method[2] = 8;                                            // not a deflate stream
+            CHECK(gbrs_zip_read_members(zip.data(), zip.size(), n, ho.data(), method.data(), cs.data(), us.data(), ptrs.data(), 2) < 0);
+            method[2] = 12;
+            CHECK(gbrs_zip_read_members(zip.data(), zip.size(), n, ho.data(), method.data(), cs.data(), us.data(), ptrs.data(), 2) < 0);
+            method[2] = 0;
+            ho[1] = zip.size() - 3;
+            CHECK(gbrs_zip_read_members(zip.data(), zip.size(), n, ho.data(), method.data(), cs.data(), us.data(), ptrs.data(), 2) < 0);
+            ho[1] = offs[1];
+        }
+        std::string other = npy_header;
+        other[20] = 'x';                                              // another header: every member goes to the caller
+        CHECK(gbrs_npz_stack(zip.data(), zip.size(), n, ho.data(), method.data(), cs.data(), us.data(), (const uint8_t *)other.data(),
+                             other.size(), item, out.data(), fb.data(), 1) == 0);
+        for (int k = 0; k < n; ++k) CHECK(fb[k] == 1);
+        method[3] = 8;                                                // claims deflate: the bytes are no deflate stream
+        CHECK(gbrs_npz_stack(zip.data(), zip.size(), n, ho.data(), method.data(), cs.data(), us.data(),
+                             (const uint8_t *)npy_header.data(), npy_header.size(), item, out.data(), fb.data(), 2) == 0);
+        CHECK(fb[3] == 1 && fb[4] == 0);
+        method[3] = 0;
+        ho[5] = zip.size() + 77;                                      // offsets outside the image are errors, not reads
+        CHECK(gbrs_npz_stack(zip.data(), zip.size(), n, ho.data(), method.data(), cs.data(), us.data(),
+                             (const uint8_t *)npy_header.data(), npy_header.size(), item, out.data(), fb.data(), 2) < 0);
+        ho[5] = offs[5];
+        cs[6] = zip.size();
+        CHECK(gbrs_npz_stack(zip.data(), zip.size(), n, ho.data(), method.data(), cs.data(), us.data(),
+                             (const uint8_t *)npy_header.data(), npy_header.size(), item, out.data(), fb.data(), 2) < 0);
+        // every truncation of the tail, and random byte damage anywhere: any status, no out-of-bounds access
+        for (size_t cut = 1; cut < 200 && cut < zip.size(); ++cut) {
+            std::vector<unsigned char> t(zip.begin(), zip.end() - (long)cut);
+            (void)gbrs_zip_directory(t.data(), t.size(), n, method.data(), cs.data(), us.data(), ho.data(), names.data(), names.size(),
+                                     &count, &nbytes);
+        }
+        for (int trial = 0; trial < 3000; ++trial) {
+            std::vector<unsigned char> t = zip;
+            for (int hits = 0; hits < 1 + trial % 4; ++hits) t[rng() % t.size()] = (unsigned char)rng();
+            std::vector<uint16_t> m2(n);
+            std::vector<uint64_t> c2(n), u2(n), h2(n);
+            if (gbrs_zip_directory(t.data(), t.size(), n, m2.data(), c2.data(), u2.data(), h2.data(), names.data(), names.size(),
+                                   &count, &nbytes) == 0 && count == (uint64_t)n)
+                (void)gbrs_npz_stack(t.data(), t.size(), n, h2.data(), m2.data(), c2.data(), u2.data(),
+                                     (const uint8_t *)npy_header.data(), npy_header.size(), item, out.data(), fb.data(), 2);
+        }
+        CHECK(gbrs_zip_directory(zip.data(), 10, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, &count, &nbytes) < 0);
     }
     std::printf("hostio sanitizer driver: ok (inflate backend %d)\n", gbrs_inflate_backend());
     return 0;
