@@ -210,6 +210,13 @@ def reconstruct(expression_file: str, tprob_file: str, avec_file: str = None, gp
     t0 = clock()
     logger.info('Loading chromosome information')
     genome = list(get_chromosome_info(data_dir))
+    # the transition tables are the big read (0.4 GB of deflate streams at DO size): it starts now on the library's
+    # threads and is collected when the tables are needed, after the small files have been parsed
+    from concurrent.futures import ThreadPoolExecutor
+    tprob = FastNpz(tprob_file)
+    chroms = [c for c in genome if c in tprob]                  # chromosomes without a table are skipped (:495)
+    reader = ThreadPoolExecutor(max_workers=1)
+    tables_pending = reader.submit(tprob.read_many, chroms)
     logger.info(f'Loading alignment specificity: {avec_file}')
     avecs = FastNpz(avec_file)
     logger.info(f'Loading gene meta data: {gpos_file}')
@@ -218,11 +225,10 @@ def reconstruct(expression_file: str, tprob_file: str, avec_file: str = None, gp
     haplotypes, expr_row, expr_table = read_gene_tpm(expression_file)
     num_haps = len(haplotypes)
     diplotypes = [a + b for a, b in combinations_with_replacement(haplotypes, 2)]
-    logger.info(f'Loading transition probabilities: {tprob_file}')
-    tprob = FastNpz(tprob_file)
-    chroms = [c for c in genome if c in tprob]                  # chromosomes without a table are skipped (:495)
     per_chrom = [chromosome_inputs(gene_order[c], expr_row, expr_table, avecs, num_haps) for c in chroms]
-    tables = tprob.read_many(chroms)                            # stored members: views of the page cache, no copy
+    logger.info(f'Loading transition probabilities: {tprob_file}')
+    tables = tables_pending.result()                            # stored members: views of the page cache, no copy
+    reader.shutdown(wait=False)
     avecs.close()
     marks['load'] = clock() - t0
 
