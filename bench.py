@@ -35,8 +35,10 @@ F64_VECTOR_PEAK_TFLOPS = 78.6   # MI355X_MICROARCH.md: FP64 vector peak
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    # a run of a few milliseconds ends before the chip has settled on its clock: 50 steps after 5 read 5-10 % lower
+    # than 500 after 50 (profiles/r02_estep_experiments.txt, item 8); the defaults measure the settled loop (65 ms)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=50)
     ap.add_argument("--rows", type=int, default=40_000_000, help="reads per GPU")
     ap.add_argument("--haps", type=int, default=8)
     ap.add_argument("--loci", type=int, default=120_000)
