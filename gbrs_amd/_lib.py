@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(_HERE, "libgbrs_hip.so")
 
 # names every build must export (checked by tests/test_abi.py against include/gbrs_hip.h)
 EXPORTS = [
-    "gbrs_last_error", "gbrs_abi_version", "gbrs_device_count",
+    "gbrs_last_error", "gbrs_abi_version", "gbrs_device_count", "gbrs_warm_up",
     "gbrs_em_create", "gbrs_em_create_device", "gbrs_em_set_initial_values", "gbrs_em_prepare", "gbrs_em_step", "gbrs_em_run",
     "gbrs_em_get", "gbrs_em_set_theta", "gbrs_em_group_sums", "gbrs_em_estep_partial",
     "gbrs_em_finish_step", "gbrs_em_prepare_partial", "gbrs_em_finish_prepare", "gbrs_em_stream",
@@ -93,6 +93,8 @@ def load():
     lib.gbrs_last_error.argtypes = []
     lib.gbrs_abi_version.restype = i32
     lib.gbrs_device_count.restype = i32
+    lib.gbrs_warm_up.restype = i32
+    lib.gbrs_warm_up.argtypes = [i32]
     sigs = {
         "gbrs_em_create": [u64, u32, u32, pp, pp, vp, vp, i32, u32, pp],
         "gbrs_em_create_device": [u64, u32, u32, pp, pp, vp, vp, i32, u32, pp],
@@ -185,7 +187,7 @@ def raw_table(addresses):
     return tab
 
 
-def warm_up_device_async():
+def warm_up_device_async(device=0):
     """Start the HIP runtime (library load, hipInit, device context: ~0.15-0.3 s in a fresh process) on a
     background thread so that it overlaps with reading the input files; ctypes releases the GIL during
     the call.  Returns the thread (join() is optional: the first real call blocks on the runtime's own
@@ -194,7 +196,7 @@ def warm_up_device_async():
 
     def _go():
         try:
-            load().gbrs_device_count()
+            load().gbrs_warm_up(int(device))
         except Exception:      # noqa: BLE001 - the foreground call will report the problem
             pass
     t = threading.Thread(target=_go, name='gbrs-hip-init', daemon=True)

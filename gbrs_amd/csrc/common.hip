@@ -33,10 +33,27 @@ int select_device(int device) {
 
 }  // namespace gbrs
 
+// One trivial launch per translation unit: every .hip file carries its own code object, which the runtime loads on
+// the first launch of one of its kernels (~20 ms for the largest).
+namespace gbrs { void warm_em(hipStream_t); void warm_layout(hipStream_t); void warm_hmm(hipStream_t); }
+
 extern "C" {
 
 const char *gbrs_last_error(void) { return gbrs::g_err; }
 int gbrs_abi_version(void) { return GBRS_ABI_VERSION; }
+
+int gbrs_warm_up(int device) {
+    GBRS_TRY(gbrs::select_device(device));
+    int *d = nullptr, h = 0;
+    GBRS_HIP_CHECK(hipMalloc(&d, sizeof(int)));
+    GBRS_HIP_CHECK(hipMemset(d, 0, sizeof(int)));
+    gbrs::warm_em(nullptr);
+    gbrs::warm_layout(nullptr);
+    gbrs::warm_hmm(nullptr);
+    GBRS_HIP_CHECK(hipMemcpy(&h, d, sizeof(int), hipMemcpyDeviceToHost));     // also sets up the staging path of small copies
+    GBRS_HIP_CHECK(hipFree(d));
+    return GBRS_OK;
+}
 
 int gbrs_device_count(void) {
     int n = 0;

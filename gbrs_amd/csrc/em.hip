@@ -1434,3 +1434,9 @@ int gbrs_em_destroy(gbrs_em_t *em) {
 }
 
 }  // extern "C"
+
+// gbrs_warm_up (common.hip): loads this file's code object
+namespace gbrs {
+__global__ void warm_em_kernel() {}
+void warm_em(hipStream_t st) { hipLaunchKernelGGL(warm_em_kernel, dim3(1), dim3(64), 0, st); }
+}  // namespace gbrs

@@ -1118,3 +1118,9 @@ int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L, uint32_t H, uint6
 }
 
 }  // namespace gbrs
+
+// gbrs_warm_up (common.hip): loads this file's code object
+namespace gbrs {
+__global__ void warm_layout_kernel() {}
+void warm_layout(hipStream_t st) { hipLaunchKernelGGL(warm_layout_kernel, dim3(1), dim3(64), 0, st); }
+}  // namespace gbrs

@@ -2448,3 +2448,9 @@ int gbrs_hmm_destroy(gbrs_hmm_t *h) {
 }
 
 }  // extern "C"
+
+// gbrs_warm_up (common.hip): loads this file's code object
+namespace gbrs {
+__global__ void warm_hmm_kernel() {}
+void warm_hmm(hipStream_t st) { hipLaunchKernelGGL(warm_hmm_kernel, dim3(1), dim3(64), 0, st); }
+}  // namespace gbrs

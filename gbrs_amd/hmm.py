@@ -206,7 +206,7 @@ def reconstruct(expression_file: str, tprob_file: str, avec_file: str = None, gp
                          ('Expression Threshold', expr_threshold), ('Sigma', sigma), ('Outbase', outbase)):
         logger.info(f'{label}: {value}')
 
-    _lib.warm_up_device_async()            # HIP start-up overlaps with reading the files
+    _lib.warm_up_device_async(device)      # HIP start-up overlaps with reading the files
     t0 = clock()
     logger.info('Loading chromosome information')
     genome = list(get_chromosome_info(data_dir))

@@ -111,7 +111,7 @@ def quantify(alignment_file: str, group_file: str = None, length_file: str = Non
         logger.info(f'{label}: {value}')
 
     from . import _lib
-    _lib.warm_up_device_async()            # HIP start-up overlaps with reading the files
+    _lib.warm_up_device_async(device)      # HIP start-up overlaps with reading the files
     t0 = clock()
     logger.info(f'Loading EMASE file: {alignment_file}')
     aln_mat = load_alignment(alignment_file, grpfile=group_file)

@@ -48,6 +48,10 @@ const char *gbrs_last_error(void);
 int gbrs_abi_version(void);
 /* Number of visible HIP devices, or a negative status. */
 int gbrs_device_count(void);
+/* Optional: pays the process's one-time device costs now (runtime start-up, context, loading the library's code
+ * objects, the first small copy) - about 0.1-0.3 s that otherwise land in the first create call.  The Python host
+ * calls it on a thread while the input files are read. */
+int gbrs_warm_up(int device);
 
 /* ------------------------------------------------------------------------------------------
  * EM: EMASE Model 4 over the alignment incidence tensor.

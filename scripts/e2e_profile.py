@@ -52,5 +52,7 @@ for name, argv in cmds.items():
     with open(os.path.join(out, f"{name}_cprofile.txt"), "w") as fh:
         pstats.Stats(prof, stream=fh).sort_stats("cumulative").print_stats(45)
     os.remove(prof)
+r = subprocess.run([sys.executable, os.path.join(ROOT, 'scripts', 'cold_create_probe.py'), os.path.join(work, 'sample.h5')], env=env, capture_output=True, text=True)
+open(os.path.join(out, 'create_stages.txt'), 'w').write(r.stderr)
 import shutil
 shutil.rmtree(work, ignore_errors=True)
