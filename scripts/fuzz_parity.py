@@ -30,7 +30,7 @@ def em_case(rng):
     o.prepare(pc, eff)
     theta0 = o.theta.copy()
     n_o = o.run(tol=tol, max_iters=iters)
-    for flags in (0, 1, 2, 16, 17, 16 | 4, 8):
+    for flags in (0, 1, 2, 16, 17, 16 | 4, 8, 32):
         eng = EmEngine.from_host(R, L, H, indptr, indices, count, eff, flags=flags)
         eng.prepare(pc)
         np.testing.assert_allclose(eng.theta(), theta0, rtol=1e-9, atol=1e-300)
@@ -59,10 +59,11 @@ def hmm_case(rng):
     H = int(rng.choice([2, 3, 4, 5, 7, 8, 8, 8, 9, 16]))
     nch = int(rng.integers(1, 6))
     lens = [int(x) for x in rng.integers(1, 90 if H == 16 else 400, size=nch)]
-    ns = int(rng.choice([1, 1, 2, 4, 5, 7, 25]))
+    ns = int(rng.choice([1, 1, 2, 4, 5, 7, 16, 25, 40]))      # from 16 on: the MFMA sweeps (GBRS_TUNING_HMM_MFMA below)
+    style = str(rng.choice(["benign", "do"])) if H == 8 else "benign"
     minus_one = bool(rng.integers(0, 2))
     seed = int(rng.integers(1, 1 << 30))
-    probs = [synth.make_hmm_problem(H=H, genes_per_chrom=lens, seed=seed + s, tprob_len_minus_one=minus_one)
+    probs = [synth.make_hmm_problem(H=H, genes_per_chrom=lens, seed=seed + s, tprob_len_minus_one=minus_one, style=style)
              for s in range(ns)]
     p0 = probs[0]
     chroms = p0.chroms
@@ -86,10 +87,11 @@ def hmm_case(rng):
                 np.testing.assert_allclose(r[k], res[c][k], rtol=1e-9, atol=1e-9)
             np.testing.assert_allclose(r["gamma"], res[c]["gamma"], rtol=1e-8, atol=1e-300)
     hmm.close()
-    return f"HMM H={H} lens={lens} samples={ns} tprob_n-1={minus_one}"
+    return f"HMM H={H} lens={lens} samples={ns} tprob_n-1={minus_one} tables={style}"
 
 
 def main():
+    os.environ.setdefault("GBRS_TUNING_HMM_MFMA", "16")
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     rng = np.random.default_rng(int(os.environ.get("FUZZ_SEED", "20241008")))
     t0 = time.time()
