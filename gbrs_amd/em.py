@@ -177,6 +177,8 @@ class EMfactory:
             _print_progress(self.err_history, stamps[:self.num_iters])
 
     # ------------------------------------------------------------------ reports
+    report_pool = None      # a ReportPool: report_* hand their files to it instead of writing them before returning
+
     def _level(self, grp_wise, which):
         """(row names, H x n values) of theta (which=0) or of the expected read counts (which=1) at
         isoform or gene level."""
@@ -188,7 +190,7 @@ class EMfactory:
     def report_read_counts(self, filename, grp_wise=False, reorder='as-is', notes=None):
         """Expected read counts of the last E-step as a TSV table (file format of EMfactory.py:289-331)."""
         names, values = self._level(grp_wise, 1)
-        write_locus_table(filename, self.probability.hname, names, values, reorder, notes)
+        write_locus_table(filename, self.probability.hname, names, values, reorder, notes, pool=self.report_pool)
 
     def report_depths(self, filename, tpm=True, grp_wise=False, reorder='as-is', notes=None) -> None:
         """Depths (theta) as a TSV table, scaled to TPM on request (file format of EMfactory.py:333-380).
@@ -199,7 +201,7 @@ class EMfactory:
             values *= 1000000.0 / values.sum()
             if not grp_wise:
                 self._theta_dirty = True
-        write_locus_table(filename, self.probability.hname, names, values, reorder, notes)
+        write_locus_table(filename, self.probability.hname, names, values, reorder, notes, pool=self.report_pool)
 
     def export_posterior_probability(self, filename: str, title: str = 'Posterior Probability') -> None:
         """The reference saves with incidence_only=True (EMfactory.py:392 ->
@@ -277,11 +279,13 @@ def _blob_cached(names):
     return hit[1]
 
 
-def write_locus_table(filename, hap_names, row_names, values, reorder='as-is', notes=None):
+def write_locus_table(filename, hap_names, row_names, values, reorder='as-is', notes=None, pool=None):
     """`locus <haplotypes...> total [notes]` table: one line per locus (or gene) with the per-haplotype
     values, their sum and, when `notes` maps names to text, that text.  Numbers are written in their
     shortest round-trip form, which is what str(numpy.float64) gives in the reference's writers; the
-    text is produced by libgbrs_hip's gbrs_write_locus_table (1.5 M numbers per sample at DO size)."""
+    text is produced by libgbrs_hip's gbrs_write_locus_table (1.5 M numbers per sample at DO size).
+    `pool` (a ReportPool) takes the formatting and writing onto a thread: the caller goes on to the next report and
+    collects errors with pool.finish(); `values` must not change until then."""
     values = np.asarray(values, dtype=np.float64)
     totals = values.sum(axis=0)
     order = None
@@ -305,7 +309,35 @@ def write_locus_table(filename, hap_names, row_names, values, reorder='as-is', n
     if notes is not None:
         note_blob, note_off = _blob([str(notes[n]) for n in names])
     head = '\t'.join(['locus', *hap_names, 'total'] + (['notes'] if notes is not None else [])) + '\n'
-    _lib.check(_lib.load().gbrs_write_locus_table(
-        os.fsencode(filename), head.encode(), _lib.ptr(values), n_rows, n_haps, values.strides[1] // item,
-        values.strides[0] // item, _lib.ptr(totals), name_blob, _lib.ptr(name_off), note_blob,
-        _lib.ptr(note_off) if note_off is not None else None, _lib.ptr(order) if order is not None else None))
+
+    def emit():       # every array the call reads is held by this closure
+        _lib.check(_lib.load().gbrs_write_locus_table(
+            os.fsencode(filename), head.encode(), _lib.ptr(values), n_rows, n_haps, values.strides[1] // item,
+            values.strides[0] // item, _lib.ptr(totals), name_blob, _lib.ptr(name_off), note_blob,
+            _lib.ptr(note_off) if note_off is not None else None, _lib.ptr(order) if order is not None else None))
+    if pool is None:
+        emit()
+    else:
+        pool.submit(emit)
+
+
+class ReportPool:
+    """Report files written behind the caller's back: `gbrs quantify` leaves four tables of 10^5 lines each, and the
+    numbers of the next one can be fetched from the device while the previous one is formatted and written."""
+
+    def __init__(self):
+        from concurrent.futures import ThreadPoolExecutor
+        self._pool = ThreadPoolExecutor(max_workers=4)
+        self._pending = []
+
+    def submit(self, fn):
+        self._pending.append(self._pool.submit(fn))
+
+    def finish(self):
+        """Wait for every table; the first failure is raised here."""
+        pending, self._pending = self._pending, []
+        try:
+            for f in pending:
+                f.result()
+        finally:
+            self._pool.shutdown(wait=True)

@@ -76,6 +76,16 @@ def _write_expression_reports(em, outbase, with_groups, isoform_notes, gene_note
         logger.info(f'Generating {label}: {path}')
         writer(filename=path, **kw)
 
+    from .em import ReportPool
+    em.report_pool = ReportPool()           # the tables are formatted and written while the next one is being fetched
+    try:
+        _emit_reports(emit, em, with_groups, isoform_notes, gene_notes, report_posterior)
+    finally:
+        pool, em.report_pool = em.report_pool, None
+        pool.finish()
+
+
+def _emit_reports(emit, em, with_groups, isoform_notes, gene_notes, report_posterior):
     emit('isoform TPMs', 'isoforms.tpm', em.report_depths, tpm=True, notes=isoform_notes)
     emit('isoform Read Counts', 'isoforms.expected_read_counts', em.report_read_counts, notes=isoform_notes)
     if report_posterior:
