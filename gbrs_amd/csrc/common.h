@@ -36,6 +36,20 @@ int select_device(int device);
 // RAII device buffer (raw hipMalloc.  A stream-ordered pool - hipMallocAsync with an unbounded release
 // threshold - was measured for the layout builder's temporaries: no gain over hipMalloc once a first
 // build has run, and a second build next to a live handle took 0.4 s in the pool, so it is not used.)
+// hipFree, or - inside a DeferFrees scope on this thread - a note to free the block when the scope ends.  On some
+// hosts of this pool a hipMalloc that follows a large hipFree stalls for 0.1-0.2 s (measured in the layout build:
+// 0.06 -> 111 ms and 0.3 -> 217 ms for two allocations that follow a release), so a one-off build that walks through
+// several multi-gigabyte temporaries keeps them until it is done instead of handing them back one by one (up to
+// 96 GB of them; beyond that blocks are freed as they go).
+void deferred_free(void *p, size_t bytes);
+struct DeferFrees {
+    DeferFrees();
+    ~DeferFrees();
+    DeferFrees(const DeferFrees &) = delete;
+    DeferFrees &operator=(const DeferFrees &) = delete;
+    bool outer;
+};
+
 template <typename T>
 struct DevBuf {
     T *p = nullptr;
@@ -45,7 +59,7 @@ struct DevBuf {
     DevBuf &operator=(const DevBuf &) = delete;
     ~DevBuf() { release(); }
     void release() {
-        if (p) (void)hipFree(p);
+        if (p) deferred_free(p, n * sizeof(T));
         p = nullptr;
         n = 0;
     }

@@ -1,6 +1,9 @@
 // Error channel and device selection shared by the EM and HMM translation units.
 #include "common.h"
 
+#include <cstdlib>
+#include <vector>
+
 namespace gbrs {
 
 static thread_local char g_err[1024] = "";
@@ -10,6 +13,33 @@ void set_error(const char *fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+namespace {
+thread_local std::vector<void *> *g_deferred = nullptr;
+thread_local size_t g_deferred_bytes = 0;
+constexpr size_t DEFER_CAP = (size_t)96 << 30;
+}
+void deferred_free(void *p, size_t bytes) {
+    if (g_deferred && g_deferred_bytes + bytes <= DEFER_CAP) {
+        g_deferred->push_back(p);
+        g_deferred_bytes += bytes;
+    } else {
+        (void)hipFree(p);
+    }
+}
+DeferFrees::DeferFrees() : outer(g_deferred == nullptr) {
+    static const bool off = [] { const char *e = std::getenv("GBRS_TUNING_EAGER_FREE"); return e && std::atoi(e) != 0; }();
+    if (outer && !off) g_deferred = new std::vector<void *>();
+    else outer = false;
+}
+DeferFrees::~DeferFrees() {
+    if (!outer) return;
+    std::vector<void *> *v = g_deferred;
+    g_deferred = nullptr;
+    g_deferred_bytes = 0;
+    for (void *p : *v) (void)hipFree(p);
+    delete v;
 }
 
 int fail(int status, const char *fmt, ...) {
