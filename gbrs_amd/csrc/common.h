@@ -43,8 +43,11 @@ int select_device(int device);
 // 96 GB of them; beyond that blocks are freed as they go).
 void deferred_free(void *p, size_t bytes);
 struct DeferFrees {
-    DeferFrees();
+    // sink: where the collected blocks go when the scope ends (their new owner frees them later, e.g. with the
+    // handle); nullptr = hipFree them there and then
+    explicit DeferFrees(std::vector<void *> *sink = nullptr);
     ~DeferFrees();
+    std::vector<void *> *sink;
     DeferFrees(const DeferFrees &) = delete;
     DeferFrees &operator=(const DeferFrees &) = delete;
     bool outer;

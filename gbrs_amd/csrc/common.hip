@@ -28,7 +28,7 @@ void deferred_free(void *p, size_t bytes) {
         (void)hipFree(p);
     }
 }
-DeferFrees::DeferFrees() : outer(g_deferred == nullptr) {
+DeferFrees::DeferFrees(std::vector<void *> *sink_) : sink(sink_), outer(g_deferred == nullptr) {
     static const bool off = [] { const char *e = std::getenv("GBRS_TUNING_EAGER_FREE"); return e && std::atoi(e) != 0; }();
     if (outer && !off) g_deferred = new std::vector<void *>();
     else outer = false;
@@ -38,7 +38,9 @@ DeferFrees::~DeferFrees() {
     std::vector<void *> *v = g_deferred;
     g_deferred = nullptr;
     g_deferred_bytes = 0;
-    for (void *p : *v) (void)hipFree(p);
+    if (sink) sink->insert(sink->end(), v->begin(), v->end());
+    else
+        for (void *p : *v) (void)hipFree(p);
     delete v;
 }
 

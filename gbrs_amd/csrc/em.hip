@@ -979,7 +979,8 @@ int em_create_impl(uint64_t R, uint32_t L, uint32_t H, const uint32_t *const *in
         // the CSC copy and the per-row denominators are only needed by layout 0 (and, until
         // gbrs_em_set_initial_values has run, when the caller announced stored values)
         em->keep_csc = (flags & GBRS_EM_KEEP_CSC) != 0;
-        if (!em->keep_csc) {
+        if (!em->keep_csc) {                  // (kept on the device until the handle goes: common.h, DeferFrees)
+            DeferFrees with_the_layout(&em->tl.retired);
             em->ent_row.release();
             em->den.release();
         }

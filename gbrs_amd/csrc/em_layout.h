@@ -18,6 +18,8 @@
 #pragma once
 #include "common.h"
 
+#include <vector>
+
 namespace gbrs {
 
 constexpr int TILE_THREADS = 512;              // 8 waves per workgroup
@@ -83,6 +85,15 @@ struct TileLayout {
     DevBuf<uint32_t> long_loc, long_mask;
     DevBuf<double> long_weight;      // n_long
     DevBuf<double> acc_extra;        // L*H, global-atomic target of the long-row kernel
+    // build temporaries, given back to the device with the layout (common.h, DeferFrees): a process that handles one
+    // sample never pays for returning them, one that handles many pays at gbrs_em_destroy
+    std::vector<void *> retired;
+    TileLayout() = default;
+    TileLayout(const TileLayout &) = delete;
+    TileLayout &operator=(const TileLayout &) = delete;
+    ~TileLayout() {
+        for (void *p : retired) (void)hipFree(p);
+    }
 };
 
 // ent_row / col_ptr: the concatenated CSC arrays already on the device (column c = h*L + l).

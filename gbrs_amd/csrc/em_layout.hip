@@ -823,7 +823,7 @@ int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L, uint32_t H, uint6
     if (H > 16) return fail(GBRS_ERR_INVALID, "the tiled layout packs the haplotype mask in 16 bits (H <= 16)");
     if (N >= 0xFFFFFFFFull || L >= (1u << 27))
         return fail(GBRS_ERR_INVALID, "the tiled layout needs N < 2^32 entries and L < 2^27 loci per handle");
-    DeferFrees keep_temporaries;       // (common.h) freed together when the build returns
+    DeferFrees keep_temporaries(&out.retired);       // (common.h) the temporaries leave with the layout
     StageTimer stg("layout");
     Scratch sc;
     DevBuf<BuildFlags> d_flags;
@@ -1115,7 +1115,7 @@ int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L, uint32_t H, uint6
     }
     stg.mark("12 heavy / light lists");
     GBRS_HIP_CHECK(hipGetLastError());
-    return GBRS_OK;
+return GBRS_OK;
 }
 
 }  // namespace gbrs
