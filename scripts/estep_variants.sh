@@ -3,7 +3,7 @@
 OUT=${1:-gpurun_out/variants}; mkdir -p $OUT
 build() { GBRS_HIPCC_EXTRA="$1" python -c "import __graft_entry__ as g; g.build()" > $OUT/build.log 2>&1 || echo "BUILD FAILED: $1"; }
 bench() {  # name, bench flags, [extra bench args]
-  timeout -k 10 200 python bench.py --steps 30 --warmup 3 --no-e2e --no-cpu-baseline --no-hmm --no-merged-line --flags $2 $3 > $OUT/$1.log 2>&1
+  timeout -k 10 200 python bench.py --steps 200 --warmup 20 --no-e2e --no-cpu-baseline --no-hmm --no-merged-line --flags $2 $3 > $OUT/$1.log 2>&1
   python - "$1" "$OUT/$1.log" <<'PY'
 import json, sys
 try:
@@ -14,9 +14,9 @@ except Exception as e:
 PY
 }
 C5="--rows 25000000 --haps 16 --loci 200000"
-build ""; bench new_c2 0; bench new_c2_b 0; bench new_c5 0 "$C5"; bench new_c2_merge 0 "--merge"
-build "-DGBRS_NO_PARK"; bench nopark_c2 0; bench nopark_c5 0 "$C5"
+build ""; bench base_c2 0; bench base_c2_b 0; bench base_c5 0 "$C5"; bench base_c2_merge 0 "--merge"
 build "-DGBRS_RAW_PD=6"; bench pd6_c2 0
-build "-DGBRS_RAW_PD=8"; bench pd8_c2 0
+build "-DGBRS_FTAB=0"; bench noftab_c2 0
+build "-DGBRS_THETA_PLANES=0"; bench rowmajor_c2 0; bench rowmajor_c5 0 "$C5"
 rm -f gbrs_amd/csrc/build/em.o gbrs_amd/csrc/build/em_layout.o gbrs_amd/csrc/build/hmm.o
 GBRS_HIPCC_EXTRA="" python -c "import __graft_entry__ as g; g.build()" > /dev/null 2>&1
