@@ -536,7 +536,9 @@ def main():
                                 **({"device_id": torch.device(f"cuda:{local}")} if args.backend == "nccl" else {}))
     import __graft_entry__
     if rank == 0:
-        __graft_entry__.build()
+        import contextlib
+        with contextlib.redirect_stdout(sys.stderr):      # stdout carries the one JSON line and nothing else
+            __graft_entry__.build()
     if world > 1:
         dist.barrier()
 
