@@ -23,7 +23,9 @@ import numpy as np
 
 class AlignmentPropertyMatrix:
     def __init__(self, shape=None, indptr=None, indices=None, count=None, haplotype_names=None,
-                 locus_names=None, grpfile=None, h5file=None, npzfile=None, values=None):
+                 locus_names=None, grpfile=None, h5file=None, npzfile=None, values=None, on_names=None):
+        """`on_names(self)` (optional) is called once the haplotype and locus names are known - for an HDF5 file that is
+        before the large index arrays are decoded, so the caller can parse name-keyed side files meanwhile."""
         self.hname = None
         self.lname = None
         self.lid = None
@@ -32,11 +34,45 @@ class AlignmentPropertyMatrix:
         self.num_groups = 0
         self.count = None
         self.values = None          # per-haplotype float64 arrays aligned with indices, or None = all ones
+        groups_thread = None
         if h5file is not None:
             from . import emase_h5
-            emase_h5.load_into(self, h5file)
+            if grpfile is not None or on_names is not None:
+                # the group file is parsed while the index arrays are decoded (native code, no interpreter lock)
+                import threading
+                box = {}
+
+                def parse_groups():
+                    try:
+                        if self.lname is None:
+                            raise RuntimeError('Locus IDs are not available.')
+                        self.lid = dict(zip(self.lname, np.arange(len(self.lname))))
+                        self.load_groups(grpfile)
+                    except BaseException as ex:      # noqa: BLE001 - re-raised on the calling thread below
+                        box['error'] = ex
+
+                def start():
+                    nonlocal groups_thread
+                    self.num_loci, self.num_haplotypes, self.num_reads = self.shape
+                    if on_names is not None:
+                        on_names(self)
+                    if grpfile is not None:
+                        groups_thread = threading.Thread(target=parse_groups, name='gbrs-groups')
+                        groups_thread.start()
+                try:
+                    emase_h5.load_into(self, h5file, on_names=start)
+                finally:
+                    if groups_thread is not None:
+                        groups_thread.join()
+                if 'error' in box:
+                    raise box['error']
+            else:
+                emase_h5.load_into(self, h5file)
         elif npzfile is not None:
             self._load_npz(npzfile)
+            if on_names is not None:
+                self.num_loci, self.num_haplotypes, self.num_reads = self.shape
+                on_names(self)
         else:
             if shape is None or len(shape) != 3 or (np.array(shape) < 1).any():
                 raise RuntimeError('The shape must be a tuple of three positive integers.')
@@ -60,7 +96,7 @@ class AlignmentPropertyMatrix:
                     raise RuntimeError('The number of names does not match to the matrix shape.')
                 self.lname = list(locus_names)
         self._finish_init()
-        if grpfile is not None:
+        if grpfile is not None and groups_thread is None:
             self.load_groups(grpfile)
 
     def _finish_init(self):
@@ -75,7 +111,7 @@ class AlignmentPropertyMatrix:
             raise RuntimeError('The length of count does not match to the matrix shape.')
         if self.values is not None and [len(v) for v in self.values] != [len(i) for i in self.indices]:
             raise RuntimeError('The stored values do not match the index arrays.')
-        if self.lname is not None:
+        if self.lname is not None and (self.lid is None or len(self.lid) != self.num_loci):
             self.lid = dict(zip(self.lname, np.arange(self.num_loci)))
         self.finalized = True
 
@@ -177,8 +213,8 @@ class AlignmentPropertyMatrix:
         emase_h5.save(self, h5file, **kw)
 
 
-def load_alignment(path, grpfile=None):
+def load_alignment(path, grpfile=None, on_names=None):
     """Open an EMASE alignment file by extension (.npz mirror or PyTables-layout HDF5)."""
     if str(path).endswith('.npz'):
-        return AlignmentPropertyMatrix(npzfile=path, grpfile=grpfile)
-    return AlignmentPropertyMatrix(h5file=path, grpfile=grpfile)
+        return AlignmentPropertyMatrix(npzfile=path, grpfile=grpfile, on_names=on_names)
+    return AlignmentPropertyMatrix(h5file=path, grpfile=grpfile, on_names=on_names)

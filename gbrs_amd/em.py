@@ -79,14 +79,18 @@ class EMfactory:
         (EMfactory.py:27-111)."""
         apm = self.probability
         if lenfile is not None:
-            self.target_lengths = read_length_file(apm, lenfile, read_length)
-            if not np.all(self.target_lengths > 0.0):
-                raise RuntimeError('There exist transcripts missing length information.')
+            self.set_target_lengths(read_length_file(apm, lenfile, read_length))
         self.close()
         self._create()
         _lib.check(_lib.load().gbrs_em_prepare(self._h, float(pseudocount)))
         self._theta = None
         self._theta_dirty = False
+
+    def set_target_lengths(self, lengths):
+        """Effective lengths (H x L) as read_length_file returns them, with prepare()'s check (EMfactory.py:88-90)."""
+        self.target_lengths = lengths
+        if not np.all(self.target_lengths > 0.0):
+            raise RuntimeError('There exist transcripts missing length information.')
 
     def _require(self):
         if self._h is None:

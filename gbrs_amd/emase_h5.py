@@ -402,11 +402,13 @@ def _coo_to_csc(coor, data, R, L):
     return indptr, rows.astype(np.uint32), vals
 
 
-def load_into(apm, path):
+def load_into(apm, path, on_names=None):
     """Fill an AlignmentPropertyMatrix from an EMASE h5 file (Sparse3DMatrix.py:42-102,
     AlignmentPropertyMatrix.py:70-83).  Stored values other than 1 end up in `apm.values` (they set the
     starting point of the EM: EMfactory.prepare normalises them, EMfactory.py:95-98); an incidence-only
-    file, or one whose values are all 1, leaves `apm.values` None."""
+    file, or one whose values are all 1, leaves `apm.values` None.  `on_names` (optional) is called as soon as the
+    haplotype and locus names are known, before the large index arrays are decoded (the caller parses its group
+    file on a thread meanwhile: the decode runs in native code without the interpreter lock)."""
     lib = _load()
     f = lib.H5Fopen(os.fsencode(path), H5F_ACC_RDONLY, H5P_DEFAULT)
     if f < 0:
@@ -439,6 +441,12 @@ def load_into(apm, path):
                              for x in (hname.ravel() if isinstance(hname, np.ndarray) else hname)]
             except AttributeError:
                 apm.hname = None
+            if lib.H5Lexists(root, b'lname', H5P_DEFAULT) > 0:
+                ln = _read_dataset(root, 'lname')
+                apm.lname = ln.ravel().astype('U').tolist() if ln.dtype.kind == 'S' else \
+                    [x.decode() if isinstance(x, (bytes, np.bytes_)) else str(x) for x in ln.ravel()]
+            if on_names is not None:
+                on_names()
             apm.indptr, apm.indices, values = [], [], []
             for h in range(H):
                 g = _check(lib.H5Gopen2(f, f'/h{h}'.encode(), H5P_DEFAULT), f'open /h{h}')
@@ -459,10 +467,6 @@ def load_into(apm, path):
                 apm.values = [np.ones(len(apm.indices[h])) if v is None else v for h, v in enumerate(values)]
             if lib.H5Lexists(root, b'count', H5P_DEFAULT) > 0:
                 apm.count = np.ascontiguousarray(_read_dataset(root, 'count', path), dtype=np.float64)
-            if lib.H5Lexists(root, b'lname', H5P_DEFAULT) > 0:
-                ln = _read_dataset(root, 'lname')
-                apm.lname = ln.ravel().astype('U').tolist() if ln.dtype.kind == 'S' else \
-                    [x.decode() if isinstance(x, (bytes, np.bytes_)) else str(x) for x in ln.ravel()]
         finally:
             lib.H5Gclose(root)
     finally:

@@ -124,7 +124,17 @@ def quantify(alignment_file: str, group_file: str = None, length_file: str = Non
     _lib.warm_up_device_async(device)      # HIP start-up overlaps with reading the files
     t0 = clock()
     logger.info(f'Loading EMASE file: {alignment_file}')
-    aln_mat = load_alignment(alignment_file, grpfile=group_file)
+    # the length table only needs the names, which an HDF5 file yields before its index arrays are decoded: it is
+    # parsed on a thread meanwhile (the decode is native code and holds no interpreter lock)
+    from concurrent.futures import ThreadPoolExecutor
+    from .em import read_length_file
+    side = ThreadPoolExecutor(max_workers=1)
+    lengths_pending = []
+
+    def names_known(apm):
+        if length_file is not None:
+            lengths_pending.append(side.submit(read_length_file, apm, length_file, 100))
+    aln_mat = load_alignment(alignment_file, grpfile=group_file, on_names=names_known)
     marks['load'] = clock() - t0
 
     t0 = clock()
@@ -142,7 +152,12 @@ def quantify(alignment_file: str, group_file: str = None, length_file: str = Non
     logger.info('Running EMASE')
     t0 = clock()
     em = EMfactory(aln_mat, device=device, merge_identical_rows=merge_identical_rows)
-    em.prepare(pseudocount=pseudocount, lenfile=length_file)
+    if lengths_pending:
+        em.set_target_lengths(lengths_pending[0].result())
+        em.prepare(pseudocount=pseudocount)
+    else:
+        em.prepare(pseudocount=pseudocount, lenfile=length_file)
+    side.shutdown(wait=False)
     marks['em_setup'] = clock() - t0
     t0 = clock()
     em.run(model=multiread_model, tol=tolerance, max_iters=max_iters, verbose=True)
