@@ -24,7 +24,7 @@ EXPORTS = [
     "gbrs_hmm_get", "gbrs_hmm_info", "gbrs_hmm_destroy", "gbrs_interpolate", "gbrs_genoprob_dosage",
     "gbrs_compress_create", "gbrs_compress_get", "gbrs_compress_destroy",
     "gbrs_format_double", "gbrs_write_locus_table", "gbrs_parse_length_table",
-    "gbrs_decode_chunks", "gbrs_inflate_backend", "gbrs_zip_directory", "gbrs_npz_stack", "gbrs_zip_read_members",
+    "gbrs_decode_chunks", "gbrs_inflate_backend", "gbrs_zip_directory", "gbrs_npz_stack", "gbrs_zip_read_members", "gbrs_parse_number_table",
 ]
 
 GBRS_OK = 0
@@ -150,6 +150,7 @@ def _host_signatures():
         "gbrs_zip_directory": [vp, u64, u64, vp, vp, vp, vp, vp, u64, C.POINTER(u64), C.POINTER(u64)],
         "gbrs_npz_stack": [vp, u64, i64, vp, vp, vp, vp, vp, u64, u64, vp, vp, i32],
         "gbrs_zip_read_members": [vp, u64, i64, vp, vp, vp, vp, vp, i32],
+        "gbrs_parse_number_table": [C.c_char_p, i64, i64, i32, vp],
         "gbrs_parse_length_table": [C.c_char_p, i64, C.c_char_p, vp, i64, C.c_char_p, vp, i32, dbl, vp],
         "gbrs_write_locus_table": [C.c_char_p, C.c_char_p, vp, i64, i32, i64, i64, vp, C.c_char_p, vp, C.c_char_p, vp, vp],
     }

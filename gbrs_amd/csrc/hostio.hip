@@ -452,6 +452,32 @@ int gbrs_npz_stack(const uint8_t *buf, uint64_t len, int64_t n, const uint64_t *
     return GBRS_OK;
 }
 
+int gbrs_parse_number_table(const char *text, int64_t text_len, int64_t n_rows, int32_t n_cols, double *out) {
+    using gbrs::fail;
+    if (!text || text_len < 0 || n_rows < 0 || n_cols <= 0 || (n_rows && !out)) return fail(GBRS_ERR_INVALID, "bad argument");
+    const char *p = text, *end = text + text_len;
+    for (int64_t r = 0; r < n_rows; ++r) {
+        while (p < end && *p != '\t' && *p != '\n') ++p;                 // the row's label
+        for (int32_t c = 0; c < n_cols; ++c) {
+            if (p >= end || *p != '\t') return 1;
+            ++p;
+            double v;
+            const auto res = std::from_chars(p, end, v);
+            if (res.ec != std::errc() || res.ptr == p) return 1;          // inf / nan spellings, blanks, ...: the caller's parser
+            out[r * n_cols + c] = v;
+            p = res.ptr;
+        }
+        if (p < end && *p == '\r') ++p;
+        if (p < end) {
+            if (*p != '\n') return 1;
+            ++p;
+        } else if (r + 1 < n_rows) {
+            return 1;
+        }
+    }
+    return p == end ? GBRS_OK : 1;
+}
+
 int gbrs_format_double(double v, char *out32) {
     if (!out32) return gbrs::fail(GBRS_ERR_INVALID, "out is NULL");
     const int n = gbrs::format_repr(v, out32);

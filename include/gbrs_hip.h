@@ -344,6 +344,11 @@ int gbrs_parse_length_table(const char *text, int64_t text_len, const char *name
                             int64_t n_loci, const char *haps, const int64_t *hap_off, int32_t n_haps,
                             double read_length, double *eff_out);
 
+/* The numbers of a `label TAB v1 TAB ... TAB vn` table (the genes.tpm report `gbrs reconstruct` reads,
+ * gbrs/gbrs_utils.py:450-459): text holds exactly n_rows such lines (header removed), out receives n_rows x n_cols
+ * doubles.  Returns 0, or 1 when a line is not of that plain form (the caller then parses it its own way). */
+int gbrs_parse_number_table(const char *text, int64_t text_len, int64_t n_rows, int32_t n_cols, double *out);
+
 /* `.npz` inputs of `gbrs reconstruct` (gbrs/gbrs_utils.py:420-441 opens avecs.npz with numpy.load and reads one
  * member per gene, :490 - zipfile re-parses the member's header and CRC-checks it on every access).
  * gbrs_zip_directory reads the central directory of a zip image (buf/len = the mapped file) once: member k's

@@ -165,6 +165,22 @@ int main(int argc, char **argv) {
         CHECK(gbrs_decode_chunks((dir + "/missing.bin").c_str(), 0, nullptr, nullptr, nullptr, nullptr, chunk, 4, n, 0, 1,
                                  out.data(), 1) < 0);
     }
+    // ---- gbrs_parse_number_table: plain tables, every malformed shape is "not plain" (1), never a read past the text
+    {
+        const std::string t = "g1\t1.5\t0.0\t2e-3\ng2\t-4\t5\t6.25\n";
+        double v[6];
+        CHECK(gbrs_parse_number_table(t.data(), (int64_t)t.size(), 2, 3, v) == 0);
+        CHECK(v[0] == 1.5 && v[2] == 2e-3 && v[3] == -4.0 && v[5] == 6.25);
+        const std::string no_nl = t.substr(0, t.size() - 1);
+        CHECK(gbrs_parse_number_table(no_nl.data(), (int64_t)no_nl.size(), 2, 3, v) == 0);
+        CHECK(gbrs_parse_number_table(t.data(), (int64_t)t.size(), 2, 2, v) == 1);       // too many columns
+        CHECK(gbrs_parse_number_table(t.data(), (int64_t)t.size(), 3, 3, v) == 1);       // a row short
+        CHECK(gbrs_parse_number_table(t.data(), (int64_t)t.size(), 1, 3, v) == 1);       // a row too many
+        const std::string bad = "g1\t1.5\tabc\t2\n";
+        CHECK(gbrs_parse_number_table(bad.data(), (int64_t)bad.size(), 1, 3, v) == 1);
+        for (size_t cut = 0; cut < t.size(); ++cut) (void)gbrs_parse_number_table(t.data(), (int64_t)cut, 2, 3, v);
+        CHECK(gbrs_parse_number_table(nullptr, 0, 1, 1, v) < 0);
+    }
     // ---- gbrs_zip_directory / gbrs_npz_stack: a hand-made archive of stored .npy members, then truncations,
     //      random corruption of every region and absurd offsets - nothing may read outside the image
     {

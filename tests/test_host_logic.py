@@ -140,3 +140,29 @@ def test_genotype_mask_parsing(tmp_path):
     m2, cg2, ct2 = diplotype_mask(apm, {k: v for k, v in calls.items() if k != "G0000001"})
     assert cg2["G0000001"] is None and ct2[apm.lname[groups[1][0]]] is None
     assert not m2[:, groups[1]].any()
+
+
+def test_read_gene_tpm_native_and_fallback_agree(tmp_path):
+    """genes.tpm through the library's number parser (plain tables) and through the Python path (a line it declines)."""
+    import numpy as np
+    from gbrs_amd import hmm
+    rng = np.random.default_rng(5)
+    vals = rng.gamma(1.0, 5.0, size=(500, 8)) * (rng.random((500, 8)) < 0.5)
+    p = tmp_path / "genes.tpm"
+    with open(p, "w") as fh:
+        fh.write("locus\t" + "\t".join("ABCDEFGH") + "\ttotal\n")
+        for i, row in enumerate(vals):
+            fh.write(f"G{i:05d}\t" + "\t".join(repr(float(x)) for x in row) + "\t" + repr(float(row.sum())) + "\n")
+    haps, rows, table = hmm.read_gene_tpm(str(p))
+    assert haps == list("ABCDEFGH") and rows["G00007"] == 7
+    np.testing.assert_array_equal(table, vals)
+    with open(p, "a") as fh:                               # "inf" is not what from_chars takes here: Python path
+        fh.write("GINF\t" + "\t".join(["inf"] * 8) + "\tinf\n")
+    haps2, rows2, table2 = hmm.read_gene_tpm(str(p))
+    assert rows2["GINF"] == 500 and np.isinf(table2[-1]).all()
+    np.testing.assert_array_equal(table2[:-1], vals)
+    with open(p, "a") as fh:
+        fh.write("GSHORT\t1.0\n")
+    import pytest
+    with pytest.raises(ValueError):
+        hmm.read_gene_tpm(str(p))
