@@ -1413,7 +1413,9 @@ backward_wave_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *_
 // size and in either form - f64 MFMA and vector f64 share the double-precision units, so the three chains add
 // their times up wherever they share SIMDs.  At 64 samples (160 + 160 + 640 wavefronts) this form therefore
 // ties with the vector sweeps (6.2 vs 6.1 ms per pass); from about 96 samples on, when the chip is full, its
-// fourfold smaller instruction count wins (256 samples: 17.0 vs 25.9 ms).  hmm_launch switches at HMM_MFMA_MIN.
+// fourfold smaller instruction count wins (256 samples: 17.0 vs 25.9 ms).  With the delta chain on
+// delta_lanes_kernel (below) the tie at 64 samples turns into a small win (7.07 vs 7.31 ms per pass with the
+// emission), so hmm_launch switches both at 64 samples (HMM_MFMA_MIN, HMM_DLANES_MIN).
 // ------------------------------------------------------------------------------------------
 typedef double mfma_d4 __attribute__((ext_vector_type(4)));
 struct __attribute__((aligned(8))) mf_pair { double x, y; };     // 16 bytes at 8-byte alignment (a lane's row piece starts at 72 g)
@@ -1635,6 +1637,134 @@ backward_mfma_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *_
 #pragma unroll
     for (int u = 0; u < NSET - 1; ++u)
         if (o + u < n_ord) step(o + u, a[u], pe[u], a[(u + NSET - 1) % NSET], pe[(u + NSET - 1) % NSET]);
+}
+
+// ------------------------------------------------------------------------------------------
+// Sample batches, 36 states: the delta (max-plus) chain with the samples on the lanes.  A workgroup of nine wavefronts
+// carries 16 samples of one chromosome; each 16-lane row of a wavefront owns ONE target state (row r of wavefront w:
+// state 4w + r) and its lanes are the 16 samples.  Every lane keeps its sample's 36 previous values in registers (LDS,
+// [sample][state], b128 reads) and a row's 36 transition entries sit 16 to a register across the row's lanes and enter
+// the additions through the DPP row broadcast of v_fmac_f64 (row_newbcast:k; of the double-precision arithmetic only
+// v_fmac_f64 has a DPP form, v_add_f64 / v_max_f64 are VOP3-only, so the sum is entry * 1.0 + previous, one rounding
+// of the exact sum like the addition; each lane uses each previous value once, so the accumulate-in-place costs no
+// copy): 36 (add, max) pairs per lane and step, no copy of the table per sample, no broadcast of the vector, and 16-sample groups so that even a 64-sample
+// batch spreads over 80 CUs.  (Tried before, 64 samples per workgroup: uniform global loads of the entries -
+// s_load_dwordx16, ~0.5 us each on a miss: 21 us per step; the block staged in LDS and read with uniform addresses: a
+// 16-byte broadcast read returns 1 KB to the register file, ~24 cycles: 6.8 us per step; the DPP form with four
+// and twelve wavefronts per 64 samples: 4-6 and 3.3 us per step - one workgroup per CU, a third of the chip at 256
+// samples, and every double-precision instruction waiting on the one before it.)  Adds and maxima only, in any order:
+// the values are those of the other forms bit for bit.
+// ------------------------------------------------------------------------------------------
+constexpr int DL_WAVES = MF_S / 4, DL_SAMPLES = 16, DL_STRIDE = MF_S + 2;      // 38 doubles per sample: b128 reads of 16 lanes on 64 distinct banks
+constexpr int DL_GROUPS = (MF_S + 15) / 16;                                     // 36 entries per row and step, 3 registers
+constexpr int DL_AHEAD = 4;                                                     // steps between a fetch and its use
+
+// x + (lane N of my 16-lane row of t), in one instruction: v_fmac_f64 is the one double-precision operation with a DPP
+// form (row_newbcast only), so the sum is written t * 1.0 + x - one rounding of the exact sum, the value v_add_f64 gives.
+template <int N>
+__device__ __forceinline__ double add_row_bcast(double x, double t, double one) {
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(x) : "v"(t), "v"(one), "n"(N));
+    return x;
+}
+
+// max over k of dp[k] + T[j][k]: four from-states at a time (independent instructions next to each other: a dependent
+// double-precision instruction waits several issue slots), four running maxima
+template <int K>
+__device__ __forceinline__ void dl_from(const double (&t)[DL_GROUPS], const double (&dp)[MF_S], double one, double (&m)[4]) {
+    const double a0 = add_row_bcast<(K + 0) % 16>(dp[K + 0], t[(K + 0) / 16], one);
+    const double a1 = add_row_bcast<(K + 1) % 16>(dp[K + 1], t[(K + 1) / 16], one);
+    const double a2 = add_row_bcast<(K + 2) % 16>(dp[K + 2], t[(K + 2) / 16], one);
+    const double a3 = add_row_bcast<(K + 3) % 16>(dp[K + 3], t[(K + 3) / 16], one);
+    if constexpr (K == 0) {
+        m[0] = a0; m[1] = a1; m[2] = a2; m[3] = a3;
+    } else {
+        m[0] = fmax(m[0], a0); m[1] = fmax(m[1], a1); m[2] = fmax(m[2], a2); m[3] = fmax(m[3], a3);
+    }
+    if constexpr (K + 4 < MF_S) dl_from<K + 4>(t, dp, one, m);
+}
+
+__global__ void __launch_bounds__(64 * DL_WAVES)
+delta_lanes_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *__restrict__ chroms,
+                   const int32_t *__restrict__ order, const double *__restrict__ tprob, const double *__restrict__ eprob,
+                   const double *__restrict__ init_vec, double *__restrict__ delta, int32_t *__restrict__ last_state) {
+    constexpr int S = MF_S, BLK = S * S;
+    __shared__ __attribute__((aligned(16))) double dbuf[2][DL_SAMPLES][DL_STRIDE];
+    const int chrom = order[blockIdx.y];
+    const ChromDesc cd = chroms[chrom];
+    const int n = cd.n_genes;
+    if (n <= 0) return;
+    const int tid = threadIdx.x, c = tid & 15, j = tid >> 4;     // sample slot, target state (row-uniform)
+    const int sample_raw = blockIdx.x * DL_SAMPLES + c;
+    const int sample = min(sample_raw, n_samples - 1);           // slots past the end shadow the last sample (same values, same stores)
+    const int64_t g0 = (int64_t)sample * genes_per_sample + cd.gene_off;
+    const int n_ord = min(n, cd.n_trans + 1) - 1;               // step i = o + 1 needs block o
+    const int last_o = max(n_ord - 1, 0);
+    const double *e_at = eprob + g0 * S + j;                    // + i * S: my state of gene i
+    double *d_at = delta + g0 * S + j;
+    // row j of a block is 36 consecutive entries; register g of slot c holds entry 16 g + c
+    const double *TB = tprob + cd.trans_off * (int64_t)BLK + (int64_t)j * S + c;
+    const int third = c < S - 32 ? 32 : S - 1 - c;
+    auto fetch_row = [&](int o, double (&t)[DL_GROUPS]) {
+        const double *src = TB + (int64_t)HMM_BLK(o) * BLK;
+        t[0] = src[0];
+        t[1] = src[16];
+        t[2] = src[third];                                      // entries 32..35 in slots 0..3; the other slots re-read entry 35, unused
+    };
+    // the entries and the emission of a step are fetched DL_AHEAD steps before it: a step is shorter than a trip to HBM
+    double t_ring[DL_AHEAD][DL_GROUPS], e_ring[DL_AHEAD];
+    double one = 1.0;
+    asm volatile("" : "+v"(one));                            // a register operand for the DPP form
+    auto fetch_step = [&](int o, int slot) {                   // step i = o + 1; clamped: past the end it re-reads the last one
+        const int oc = min(o, last_o);
+        e_ring[slot] = e_at[(int64_t)(oc + 1) * S];
+        fetch_row(oc, t_ring[slot]);
+    };
+    {
+        const double d0 = init_vec[j] + e_at[0];
+        dbuf[0][c][j] = d0;
+        d_at[0] = d0;
+        if (n_ord > 0) {
+#pragma unroll
+            for (int u = 0; u < DL_AHEAD; ++u) fetch_step(u, u);
+        }
+    }
+    __syncthreads();
+    int cur = 0;
+    auto step = [&](int o, int u) {                            // u: a constant after unrolling (the ring is in registers)
+        double dp[S];
+        const mf_pair *src = reinterpret_cast<const mf_pair *>(&dbuf[cur][c][0]);
+#pragma unroll
+        for (int k2 = 0; k2 < S / 2; ++k2) {
+            const mf_pair pr = src[k2];
+            dp[2 * k2] = pr.x;
+            dp[2 * k2 + 1] = pr.y;
+        }
+        double m[4];
+        dl_from<0>(t_ring[u], dp, one, m);
+        const double dn = fmax(fmax(m[0], m[1]), fmax(m[2], m[3])) + e_ring[u];
+        fetch_step(o + DL_AHEAD, u);                            // after the last use of the slot: its registers are free again
+        dbuf[cur ^ 1][c][j] = dn;
+        d_at[(int64_t)(o + 1) * S] = dn;
+        cur ^= 1;
+        __syncthreads();
+    };
+    int ob = 0;
+    for (; ob + DL_AHEAD <= n_ord; ob += DL_AHEAD) {           // whole groups: no branch between a fetch and its use
+#pragma unroll
+        for (int u = 0; u < DL_AHEAD; ++u) step(ob + u, u);
+    }
+#pragma unroll
+    for (int u = 0; u < DL_AHEAD - 1; ++u)
+        if (ob + u < n_ord) step(ob + u, u);                    // block-uniform
+    if (j == 0 && sample_raw < n_samples) {                     // sid = argmax delta[:, n-1] (first max)
+        double bv = dbuf[cur][c][0];
+        int bk = 0;
+        for (int s2 = 1; s2 < S; ++s2) {
+            const double v = dbuf[cur][c][s2];
+            if (v > bv) { bv = v; bk = s2; }
+        }
+        last_state[(int64_t)sample_raw * gridDim.y + chrom] = bk;
+    }
 }
 
 // log C_i of backward_wave_kernel's comment for one (chromosome, sample): a suffix sum over genes
@@ -1978,7 +2108,11 @@ int hmm_make_logs(gbrs_hmm *h) {
 #define HMM_NSET_B 3      // register sets of the HMM_SB-samples-per-wave recursions
 #endif
 #ifndef HMM_MFMA_MIN
-#define HMM_MFMA_MIN 96   // 36 states, at least this many samples: alpha and backward sweeps of 16 samples per wave on MFMA (see the kernels' comment)
+#define HMM_MFMA_MIN 64   // 36 states, at least this many samples: alpha and backward sweeps of 16 samples per wave on MFMA (see the kernels' comment)
+#endif
+#ifndef HMM_DLANES_MIN
+#define HMM_DLANES_MIN 64 // 36 states, at least this many samples: delta chain with the samples on the lanes (measured with the MFMA sweeps beside it:
+                          // 8-32 samples the one-state-per-lane kernels win, 64 a wash, 128: 10.3 vs 12.1 ms, 256: 19.4 vs 22.1 ms)
 #endif
 #ifndef HMM_NSET_M
 #define HMM_NSET_M 3      // register sets (transition blocks in flight) of the MFMA sweeps
@@ -2063,7 +2197,17 @@ int hmm_launch(gbrs_hmm *h) {
                 hipLaunchKernelGGL(k_back, wave_grid, dim3(64), 0, st, h->n_samples, h->total_genes,
                                    h->d_chroms.p, h->d_order.p, h->pprob_t.p, h->peprob.p, h->bhat.p, h->bscale.p);
             };
+            // GBRS_TUNING_HMM_DLANES = smallest batch that takes the samples-on-lanes delta chain (0: never)
+            int dl_min = HMM_DLANES_MIN;
+            if (const char *env = std::getenv("GBRS_TUNING_HMM_DLANES"); env) dl_min = std::atoi(env) > 0 ? std::atoi(env) : INT_MAX;
+            const bool dlanes = SS == MF_S && h->n_samples >= dl_min && h->total_trans > 0;
             launch_delta = [=](hipStream_t st) {
+                if (dlanes) {
+                    hipLaunchKernelGGL(delta_lanes_kernel, dim3((h->n_samples + DL_SAMPLES - 1) / DL_SAMPLES, h->n_chrom), dim3(64 * DL_WAVES), 0, st,
+                                       h->n_samples, h->total_genes, h->d_chroms.p, h->d_order.p, h->tprob.p, h->eprob.p,
+                                       h->init_vec.p, h->delta.p, h->last_state.p);
+                    return;
+                }
                 hipLaunchKernelGGL(k_delta, wave_grid, dim3(64), 0, st, h->n_samples, h->total_genes,
                                    h->d_chroms.p, h->d_order.p, h->tprob_q.p, h->pprob.p, h->eprob.p, h->peprob.p,
                                    h->init_vec.p, h->xsum.p, h->invz.p, h->delta.p, h->last_state.p);

@@ -92,6 +92,7 @@ def hmm_case(rng):
 
 def main():
     os.environ.setdefault("GBRS_TUNING_HMM_MFMA", "16")
+    os.environ.setdefault("GBRS_TUNING_HMM_DLANES", "16")
     budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
     rng = np.random.default_rng(int(os.environ.get("FUZZ_SEED", "20241008")))
     t0 = time.time()

@@ -1,10 +1,11 @@
 #!/bin/bash
 # Batched HMM line of bench.py under the tuning switches (GPU box).
-# Usage: scripts/hmm_batch_variants.sh OUTDIR BATCH MFMA_MIN [MFMA_MIN ...]   (GBRS_TUNING_HMM_MFMA: smallest batch on the MFMA sweeps, 0 = never)
+# Usage: scripts/hmm_batch_variants.sh OUTDIR BATCH "MFMA_MIN DLANES_MIN" [...]   (GBRS_TUNING_HMM_MFMA / _DLANES: smallest batch on the
+# MFMA sweeps / the samples-on-lanes delta chain, 0 = never)
 OUT=${1:-gpurun_out/hmmb}; B=${2:-64}; shift 2; mkdir -p $OUT
-for M in "$@"; do
-  GBRS_TUNING_HMM_MFMA=$M timeout -k 10 300 python bench.py --rows 200000 --steps 2 --warmup 1 --no-cpu-baseline --no-merged-line --no-e2e --hmm-batch $B --hmm-batch-large 0 --hmm-reps 3 > $OUT/b${B}_m${M}.log 2>&1
-  python - $OUT/b${B}_m${M}.log $B "min $M" <<'PY'
+for V in "$@"; do set -- $V; M=$1; D=${2:-0}
+  GBRS_TUNING_HMM_DLANES=$D GBRS_TUNING_HMM_MFMA=$M timeout -k 10 300 python bench.py --rows 200000 --steps 2 --warmup 1 --no-cpu-baseline --no-merged-line --no-e2e --hmm-batch $B --hmm-batch-large 0 --hmm-reps 3 > $OUT/b${B}_m${M}_d${D}.log 2>&1
+  python - $OUT/b${B}_m${M}_d${D}.log $B "min $M dlanes $D" <<'PY'
 import json, sys
 try:
     d = json.loads(open(sys.argv[1]).read().strip().split("\n")[-1])["hmm"]["batched"]

@@ -142,6 +142,7 @@ def test_hmm_sample_batches_and_short_chromosomes(n_samples, minus_one, monkeypa
     from gbrs_amd.hmm import DiplotypeHMM
     from oracle import hmm_oracle
     monkeypatch.setenv("GBRS_TUNING_HMM_MFMA", "16")
+    monkeypatch.setenv("GBRS_TUNING_HMM_DLANES", "16")       # and the samples-on-lanes delta chain
     lens = [1, 2, 3, 4, 5, 7, 63, 64, 65, 129, 200]
     probs = [synth.make_hmm_problem(H=8, genes_per_chrom=lens, seed=1234 + s, tprob_len_minus_one=minus_one)
              for s in range(n_samples)]
@@ -178,6 +179,7 @@ def test_hmm_do_tables_sample_batches(n_samples, monkeypatch):
     from gbrs_amd.hmm import DiplotypeHMM
     from oracle import hmm_oracle
     monkeypatch.setenv("GBRS_TUNING_HMM_MFMA", "16")
+    monkeypatch.setenv("GBRS_TUNING_HMM_DLANES", "16")       # and the samples-on-lanes delta chain
     lens = [1, 2, 17, 64, 150]
     probs = [synth.make_hmm_problem(H=8, genes_per_chrom=lens, seed=4321 + s, style="do",
                                     expressed_fraction=0.9 if s % 3 else 0.3) for s in range(n_samples)]
