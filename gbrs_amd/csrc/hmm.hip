@@ -1651,7 +1651,7 @@ backward_mfma_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *_
 // batch spreads over 80 CUs.  (Tried before, 64 samples per workgroup: uniform global loads of the entries -
 // s_load_dwordx16, ~0.5 us each on a miss: 21 us per step; the block staged in LDS and read with uniform addresses: a
 // 16-byte broadcast read returns 1 KB to the register file, ~24 cycles: 6.8 us per step; the DPP form with four
-// and twelve wavefronts per 64 samples: 4-6 and 3.3 us per step - one workgroup per CU, a third of the chip at 256
+// and twelve wavefronts per 64 samples: 6.4 and 4.3 us per step - one workgroup per CU, a third of the chip at 256
 // samples, and every double-precision instruction waiting on the one before it.)  Adds and maxima only, in any order:
 // the values are those of the other forms bit for bit.
 // ------------------------------------------------------------------------------------------
