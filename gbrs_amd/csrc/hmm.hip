@@ -1657,7 +1657,10 @@ backward_mfma_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *_
 // ------------------------------------------------------------------------------------------
 constexpr int DL_WAVES = MF_S / 4, DL_SAMPLES = 16, DL_STRIDE = MF_S + 2;      // 38 doubles per sample: b128 reads of 16 lanes on 64 distinct banks
 constexpr int DL_GROUPS = (MF_S + 15) / 16;                                     // 36 entries per row and step, 3 registers
-constexpr int DL_AHEAD = 4;                                                     // steps between a fetch and its use
+#ifndef HMM_DL_AHEAD
+#define HMM_DL_AHEAD 4
+#endif
+constexpr int DL_AHEAD = HMM_DL_AHEAD;                                          // steps between a fetch and its use
 
 // x + (lane N of my 16-lane row of t), in one instruction: v_fmac_f64 is the one double-precision operation with a DPP
 // form (row_newbcast only), so the sum is written t * 1.0 + x - one rounding of the exact sum, the value v_add_f64 gives.
