@@ -271,23 +271,48 @@ def em_bench_pipelined(args, rank, world, torch, dist, state):
     from gbrs_amd.dist import PipelinedShardedEM
     dev = f"cuda:{torch.cuda.current_device()}"
     engs = state["engs"]
-    stream = torch.cuda.current_stream().cuda_stream
-    for e in engs:
-        e.set_stream(stream)
-    views = {}
+    # Every range runs on a stream of its own: E-step -> all-reduce -> M-step are ordered on that stream and nothing
+    # orders the two ranges against each other, so the device overlaps the collective of one with the E-step of
+    # the other by itself.  The collective is issued in line (no handle, no wait) on the one default group:
+    # its communicator serialises the two ranges' all-reduces in issue order, the same on every rank, and
+    # that serialisation is also what staggers the ranges (measured with a one-rank RCCL group,
+    # scripts/pipelined_host_cost.py: 114 us per iteration against 184 us for async handles on one stream,
+    # whose event hops between the compute and the collective stream cost ~10 us each).
+    torch.cuda.synchronize()                          # the engines were built on the default stream
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for e, st in zip(engs, streams):
+        e.set_stream(st.cuda_stream)
+    views, turn = {}, {}
 
-    class _Done:                                   # world == 1 (--force-overlap-path): nothing to exchange
+    class _Done:                                   # the collective is already in the range's stream
         def wait(self):
             pass
 
+    class _OnStream:                               # an engine that says whose buffer the next all-reduce is
+        def __init__(self, eng, st):
+            self._eng, self._st = eng, st
+
+        def __getattr__(self, name):
+            return getattr(self._eng, name)
+
+        def estep_partial(self):
+            turn["stream"] = self._st
+            return self._eng.estep_partial()
+
+        def prepare_partial(self):
+            turn["stream"] = self._st
+            return self._eng.prepare_partial()
+
     def start_allreduce(ptr, n):
         if world == 1 and not args.rccl_selftest:
-            return _Done()
+            return _Done()                         # --force-overlap-path alone: nothing to exchange
         if ptr not in views:
             views[ptr] = torch.as_tensor(DevArray(ptr, n), device=dev)
-        return dist.all_reduce(views[ptr], async_op=True)
+        with torch.cuda.stream(turn["stream"]):
+            dist.all_reduce(views[ptr])
+        return _Done()
 
-    drv = PipelinedShardedEM(engs[0], engs[1], start_allreduce)
+    drv = PipelinedShardedEM(_OnStream(engs[0], streams[0]), _OnStream(engs[1], streams[1]), start_allreduce)
     drv.prepare(0.0)
 
     def barrier():

@@ -147,7 +147,10 @@ class PipelinedShardedEM:
         E_a  AR_a | E_b  AR_b | wait AR_a  M_a  E_a'  AR_a' | wait AR_b  M_b  E_b'  AR_b' | ...
 
     `start_allreduce(buffer, n)` starts the in-place sum of the engine's partial buffer across ranks
-    and returns an object whose wait() orders the engine's stream after it.  pseudocount must be 0
+    and returns an object whose wait() orders the engine's stream after it.  (bench.py gives every engine a
+    HIP stream of its own and issues the collective in line on that stream - wait() is then a no-op and the
+    two ranges overlap on the device without any handle: 114 us instead of 184 us per iteration with a
+    one-rank RCCL group, scripts/pipelined_host_cost.py.)  pseudocount must be 0
     (its renormalisation couples the ranges); the stopping rule is evaluated on the host every
     `check_every` iterations, so a run may go up to check_every - 1 iterations past the reference's
     stopping point - use ShardedEM when the iteration count has to match."""
