@@ -560,7 +560,7 @@ int em_estep(gbrs_em *em, bool materialize = false) {
 
 // Gather + M-step in one launch (tile layout, H a power of two, single GPU): an element of a locus
 // with at most one slot takes A straight from `acc` (written by the tile epilogue), a locus with a
-// few slots sums them in place, and the loci with many slots get one wavefront each (the trailing
+// few slots sums them in place, and the loci with many slots get one workgroup each (the leading
 // workgroups), which reduces the slots in fixed order and applies the M-step to that locus itself.
 // No intermediate A vector is written for the gathered loci and there is one launch less per step.
 constexpr int MSTEP_EPT = 4;       // elements per thread of the elementwise workgroups
@@ -575,6 +575,7 @@ mstep_gather_kernel(uint32_t L, uint32_t H, uint32_t HP, uint32_t heavy_blocks, 
                     double *__restrict__ tot_new, double *__restrict__ msums, uint32_t cap,
                     const EmScalars *__restrict__ sc) {
     __shared__ double lds[16];
+    __shared__ double heavy_part[RED_THREADS / 64][16];
     if (sc->stop) return;
     double t = 0.0, tn = 0.0;
     // the heavy workgroups come first in the grid: their long dependent chains (hundreds of slots per
@@ -585,16 +586,20 @@ mstep_gather_kernel(uint32_t L, uint32_t H, uint32_t HP, uint32_t heavy_blocks, 
         // parallelism, not fewer instructions
         const uint64_t n = (uint64_t)L * H;
         const uint64_t i0 = (uint64_t)(blockIdx.x - heavy_blocks) * MSTEP_EPT * blockDim.x + threadIdx.x;
-        uint32_t cls[MSTEP_EPT];
+        uint32_t cls[MSTEP_EPT], kb[MSTEP_EPT], ke[MSTEP_EPT];
         double av[MSTEP_EPT], tv[MSTEP_EPT], lv[MSTEP_EPT];
 #pragma unroll
         for (int e = 0; e < MSTEP_EPT; ++e) {
             const uint64_t i = i0 + (uint64_t)e * blockDim.x;
             cls[e] = 3;
+            kb[e] = ke[e] = 0;
             av[e] = tv[e] = 0.0;
             lv[e] = 1.0;
             if (i < n) {
-                cls[e] = locus_class[(uint32_t)(i / H)];
+                const uint32_t l = (uint32_t)(i / H);
+                cls[e] = locus_class[l];
+                kb[e] = slot_ptr[l];                      // with the first batch of loads, not after the class is known
+                ke[e] = slot_ptr[l + 1];
                 tv[e] = theta[i];
                 av[e] = acc[i];                           // one slot: stored by its tile; none: stays 0
                 if (acc_extra) av[e] += acc_extra[i];
@@ -608,10 +613,20 @@ mstep_gather_kernel(uint32_t L, uint32_t H, uint32_t HP, uint32_t heavy_blocks, 
             double te = 0.0, tne = 0.0;
             if (i < n && cls[e] != 3) {                   // class 3: the heavy workgroups
                 double a = av[e];
-                if (cls[e] == 2) {                        // a few slots: summed in place
+                if (cls[e] == 2) {                        // a few slots: summed in place, in slot order, four loads in flight
                     a = acc_extra ? acc_extra[i] : 0.0;
-                    const uint32_t k0 = slot_ptr[l], k1 = slot_ptr[l + 1];
-                    for (uint32_t k = k0; k < k1; ++k) a += slot_sums[(size_t)k * H + h];
+                    const double *sp = slot_sums + h;
+                    uint32_t k = kb[e];
+                    const uint32_t k1 = ke[e];
+                    for (; k + 3 < k1; k += 4) {
+                        const double s0 = sp[(size_t)k * H], s1 = sp[(size_t)(k + 1) * H], s2 = sp[(size_t)(k + 2) * H],
+                                     s3 = sp[(size_t)(k + 3) * H];
+                        a += s0;
+                        a += s1;
+                        a += s2;
+                        a += s3;
+                    }
+                    for (; k < k1; ++k) a += sp[(size_t)k * H];
                 }
                 te = tv[e];
                 const double c = te * a;
@@ -632,17 +647,19 @@ mstep_gather_kernel(uint32_t L, uint32_t H, uint32_t HP, uint32_t heavy_blocks, 
             tn += tne;
         }
     } else {
-        const uint32_t hv = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+        // one workgroup per many-slot locus: the largest loci of a deep sample have hundreds of slots whose rows
+        // were written by tiles all over the chip a moment ago - every load is a ~0.6 us miss, so the time of the
+        // whole launch is the number of dependent rounds of its largest locus (one wavefront per locus: 23
+        // rounds for 730 slots; four wavefronts: 6)
+        const uint32_t hv = blockIdx.x;
         if (hv < n_heavy) {
             const uint32_t l = heavy_loci[hv];
-            const int lane = threadIdx.x & 63;
-            const uint32_t h = lane & (HP - 1), sub = lane / HP, nsub = 64 / HP;
+            const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+            const uint32_t h = threadIdx.x & (HP - 1), sub = threadIdx.x / HP, nsub = blockDim.x / HP;
             const uint32_t k0 = slot_ptr[l], k1 = slot_ptr[l + 1];
             double a = 0.0;
             if (h < H) {
-                // GATHER_CHAINS independent chains per lane over the locus's consecutive slot rows: the rows
-                // were written by tiles all over the chip a moment ago, every load is a ~0.6 us miss, and
-                // the largest loci have hundreds of slots
+                // GATHER_CHAINS independent chains per lane over the locus's consecutive slot rows
                 double ac[GATHER_CHAINS];
 #pragma unroll
                 for (int c = 0; c < GATHER_CHAINS; ++c) ac[c] = 0.0;
@@ -659,23 +676,30 @@ mstep_gather_kernel(uint32_t L, uint32_t H, uint32_t HP, uint32_t heavy_blocks, 
                 a = ac[0];
             }
             for (uint32_t off = HP; off < 64; off <<= 1) a += __shfl_xor(a, off, WAVE);
-            if (sub == 0 && h < H) {
-                const size_t i = (size_t)l * H + h;
-                if (acc_extra) a += acc_extra[i];
-                t = theta[i];
-                const double c = t * a;
-                tn = eff_len ? c / eff_len[i] : c;
-                counts[i] = c;
-                theta[i] = tn;
-            }
-            double tp = t, tq = tn;                       // lanes 0 .. H-1 hold the locus, the others 0
-            for (uint32_t off = 1; off < HP; off <<= 1) {
-                tp += __shfl_xor(tp, off, WAVE);
-                tq += __shfl_xor(tq, off, WAVE);
-            }
-            if (lane == 0) {
-                tot_prev[l] = tp;
-                tot_new[l] = tq;
+            if (lane < (int)HP) heavy_part[wv][lane] = a;        // the wavefronts' partial sums, added in a fixed order
+            __syncthreads();
+            if (wv == 0) {
+                a = 0.0;
+                if (lane < (int)HP)
+                    for (uint32_t w2 = 0; w2 < blockDim.x / 64; ++w2) a += heavy_part[w2][lane];
+                if (lane < (int)HP && h < H) {
+                    const size_t i = (size_t)l * H + h;
+                    if (acc_extra) a += acc_extra[i];
+                    t = theta[i];
+                    const double c = t * a;
+                    tn = eff_len ? c / eff_len[i] : c;
+                    counts[i] = c;
+                    theta[i] = tn;
+                }
+                double tp = t, tq = tn;                       // lanes 0 .. H-1 hold the locus, the others 0
+                for (uint32_t off = 1; off < HP; off <<= 1) {
+                    tp += __shfl_xor(tp, off, WAVE);
+                    tq += __shfl_xor(tq, off, WAVE);
+                }
+                if (lane == 0) {
+                    tot_prev[l] = tp;
+                    tot_new[l] = tq;
+                }
             }
         }
     }
@@ -750,7 +774,7 @@ int em_launch_mstep_gather(gbrs_em *em) {
     while (HP < em->H) HP <<= 1;
     const uint64_t n = (uint64_t)em->L * em->H;
     const unsigned elem_blocks = (unsigned)((n + (uint64_t)RED_THREADS * MSTEP_EPT - 1) / ((uint64_t)RED_THREADS * MSTEP_EPT));
-    const unsigned heavy_blocks = (unsigned)((tl.n_heavy + RED_THREADS / 64 - 1) / (RED_THREADS / 64));
+    const unsigned heavy_blocks = (unsigned)tl.n_heavy;         // one workgroup per many-slot locus
     em->msum_blocks = elem_blocks + heavy_blocks;
     hipLaunchKernelGGL(mstep_gather_kernel, dim3(elem_blocks + heavy_blocks), dim3(RED_THREADS), 0, em->stream, em->L,
                        em->H, HP, heavy_blocks, (uint32_t)tl.n_heavy, tl.slot_ptr.p, tl.heavy_loci.p,
@@ -933,7 +957,7 @@ int em_create_impl(uint64_t R, uint32_t L, uint32_t H, const uint32_t *const *in
     GBRS_TRY(em->tot_prev.alloc(L));
     GBRS_TRY(em->tot_new.alloc(L));
     GBRS_TRY(em->partials.alloc(3 * RED_BLOCKS));
-    em->msum_cap = (uint32_t)(((uint64_t)L * H + RED_THREADS - 1) / RED_THREADS + (L + 3) / 4 + RED_BLOCKS);
+    em->msum_cap = (uint32_t)(((uint64_t)L * H + RED_THREADS - 1) / RED_THREADS + L + RED_BLOCKS);   // elementwise workgroups + one per many-slot locus
     GBRS_TRY(em->msums.alloc(2 * (size_t)em->msum_cap + ERR_BLOCKS));
     GBRS_TRY(em->scalars.alloc(1));
     GBRS_HIP_CHECK(hipMemset(em->scalars.p, 0, sizeof(EmScalars)));
