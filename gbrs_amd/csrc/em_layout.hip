@@ -975,7 +975,20 @@ int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L, uint32_t H, uint6
     hipLaunchKernelGGL(row_len_kernel, dim3(grid_for(M)), dim3(256), 0, s, M, hrow.p, rowstart.p, ploc.p, npm.p, dnew.p);
     GBRS_TRY(exclusive_scan(sc, npm.p, wordoff.p, M, s));
     GBRS_TRY(inclusive_scan(sc, dnew.p, dincl.p, M, s));
-    hipLaunchKernelGGL(tile_flag_kernel, dim3(grid_for(M)), dim3(256), 0, s, M, (uint32_t)TILE_WORDS, dseg, npm.p,
+    // tile size: the large one if the sample still fills TILE_ROUNDS_MIN rounds of the chip's resident E-step workgroups
+    // (3 per CU) with it (em_layout.h); GBRS_TUNING_TILE_WORDS overrides
+    uint32_t tile_words = TILE_WORDS;
+    {
+        uint32_t total_words = 0;
+        GBRS_TRY(fetch_last_plus(wordoff.p, npm.p, M, total_words, s));
+        int dev = 0, n_cu = 0;
+        GBRS_HIP_CHECK(hipGetDevice(&dev));
+        GBRS_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
+        if ((uint64_t)total_words >= (uint64_t)TILE_WORDS_LARGE * TILE_ROUNDS_MIN * 3u * (uint64_t)n_cu) tile_words = TILE_WORDS_LARGE;
+        if (const char *env = std::getenv("GBRS_TUNING_TILE_WORDS"); env && std::atoi(env) >= 64)
+            tile_words = (uint32_t)std::min(std::atoi(env), GBRS_TILE_CAP - 64);
+    }
+    hipLaunchKernelGGL(tile_flag_kernel, dim3(grid_for(M)), dim3(256), 0, s, M, tile_words, dseg, npm.p,
                        wordoff.p, dincl.p, tflag.p);
     GBRS_TRY(inclusive_scan(sc, tflag.p, tincl.p, M, s));
     uint32_t T32 = 0;
