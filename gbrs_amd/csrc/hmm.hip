@@ -771,8 +771,13 @@ __device__ __forceinline__ double2 load_pinned(const char *uniform_base, unsigne
 template <int SS>
 __device__ __forceinline__ void load_lane(const double *__restrict__ block, int lane, double (&dst)[SS]) {
     const char *src = reinterpret_cast<const char *>(block) + lane * 16;
+#if defined(HMM_ABLATE_HALF_LOADS)
+    constexpr int NLOAD = SS / 4;                        // timing only: the second half keeps what it had
+#else
+    constexpr int NLOAD = SS / 2;
+#endif
 #pragma unroll
-    for (int m = 0; m < SS / 2; ++m) {
+    for (int m = 0; m < NLOAD; ++m) {
         const double2 v = *reinterpret_cast<const double2 *>(src + m * (SS * 16));
         dst[2 * m] = v.x;
         dst[2 * m + 1] = v.y;
@@ -851,6 +856,10 @@ forward_wave_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *__
     }
     auto prefetch = [&](int o, double (&pn)[SS], double (&em_n)[SB]) {
         const int of = min(o + NSET - 1, last_o);
+#if defined(HMM_ABLATE_LOADS)                            // timing-only builds (scripts/hmm_single_ablate.sh): the sets keep their first blocks
+        (void)pn; (void)em_n; (void)of;
+        return;
+#endif
         load_lane<SS>(BLK + (int64_t)HMM_BLK(of) * SS * SS, jr, pn);
 #pragma unroll
         for (int b = 0; b < SB; ++b) em_n[b] = EM[(g0[b] + of + 1) * SS + jr];
@@ -868,10 +877,16 @@ forward_wave_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *__
         // Z of the vector in buf[.][cur] comes out of the same broadcast reads as the products:
         // every lane adds it up itself, no cross-lane operation
         auto finish = [&](int b, int i_prev, double z) {
+#if defined(HMM_ABLATE_RECIP)
+            const double inv_z = __hiloint2double(0x3FF00000 | (__double2hiint(z) & 0xFFFF), 0);
+#else
             const double inv_z = fast_recip_pos(z);
+#endif
+#if !defined(HMM_ABLATE_STORES)
             if (act && sv[b]) {
                 if (j == 0) invz[g0[b] + i_prev] = inv_z;
             }
+#endif
             return inv_z;
         };
         auto step = [&](int o, const double (&pc)[SS], const double (&pe)[SB], double (&pn)[SS], double (&pe_n)[SB]) {
@@ -919,7 +934,9 @@ forward_wave_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *__
                 const double x = ((s0 + s1) + (s2 + s3)) * inv_z + TINY;
                 y_own[b] = x * pe_now[b];
                 if (act) buf[b][cur ^ 1][j] = y_own[b];
+#if !defined(HMM_ABLATE_STORES)
                 if (act && sv[b]) xsum[(g0[b] + i) * SS + j] = x;
+#endif
             }
             cur ^= 1;
             wave_lds_fence();
@@ -989,7 +1006,9 @@ forward_wave_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *__
             }
             const double d = fmax(fmax(m0, m1), fmax(m2, m3)) + e_now[b];
             if (act) buf[b][cur ^ 1][j] = d;
+#if !defined(HMM_ABLATE_STORES)
             if (act && sv[b]) delta[(g0[b] + i) * SS + j] = d;
+#endif
         }
         cur ^= 1;
         wave_lds_fence();
