@@ -97,6 +97,34 @@ def test_em_c1_shape_vs_oracle():
         em.close()
 
 
+@pytest.mark.parametrize("tile_words", [64, 1000, 8128, 11008, 16320])
+def test_em_tile_sizes_vs_oracle(tile_words, monkeypatch):
+    """The tile size is a layout choice (8,128 or 11,008 words by sample size, em_layout.h): every size, from one batch
+    per tile to the capacity of the dictionary sort, gives the oracle's iteration count and values."""
+    from gbrs_amd import synth
+    from gbrs_amd.alignment import AlignmentPropertyMatrix
+    from gbrs_amd.em import EMfactory
+    from oracle.em_oracle import EMOracle
+    inc = synth.make_em_problem(R=60_000, H=8, L=900, seed=synth.SEED_BASE_EM + 7)
+    eff = inc.effective_length(100)
+    o = EMOracle(inc.num_rows, inc.num_loci, inc.num_haps, inc.indptr, inc.indices, None)
+    o.prepare(0.0, eff)
+    n = o.run(tol=1e-4, max_iters=999)
+    apm = AlignmentPropertyMatrix(shape=(inc.num_loci, inc.num_haps, inc.num_rows), indptr=inc.indptr,
+                                  indices=inc.indices, haplotype_names=inc.hap_names,
+                                  locus_names=inc.locus_names)
+    monkeypatch.setenv("GBRS_TUNING_TILE_WORDS", str(tile_words))
+    for kw in (LAYOUTS["tiles"], LAYOUTS["tiles_merged"], LAYOUTS["tiles_deterministic"]):
+        em = EMfactory(apm, **kw)
+        em.target_lengths = eff
+        em.prepare(0.0)
+        em.run(model=4, tol=1e-4, max_iters=999, verbose=False)
+        assert em.num_iters == n
+        close(em.allelic_expression, o.theta)
+        close(em.expected_read_counts(), o.expected_read_counts())
+        em.close()
+
+
 def test_em_properties_h8():
     """Size-independent properties on a DO-shaped (H=8) problem: conservation of read mass,
     row-permutation invariance, and EC-compression invariance (duplicated rows == count)."""
