@@ -170,6 +170,40 @@ def test_hmm_sample_batches_and_short_chromosomes(n_samples, minus_one, monkeypa
     hmm.close()
 
 
+def test_hmm_large_batch_default_dispatch():
+    """70 samples with the library's own thresholds (no tuning switch): the launch takes the MFMA sweeps and the
+    samples-on-lanes delta chain by itself (both from 64 samples on), with a partly filled last group of 16; every
+    sample against the oracle."""
+    from gbrs_amd import synth
+    from gbrs_amd.hmm import DiplotypeHMM
+    from oracle import hmm_oracle
+    n_samples = 70
+    lens = [1, 3, 17, 64, 90]
+    probs = [synth.make_hmm_problem(H=8, genes_per_chrom=lens, seed=4321 + s) for s in range(n_samples)]
+    p0 = probs[0]
+    chroms = p0.chroms
+    hmm = DiplotypeHMM(8, chroms, [len(p0.gene_ids[c]) for c in chroms], [p0.tprob[c] for c in chroms])
+    ex, av, ha = [], [], []
+    for c in chroms:
+        ids = p0.gene_ids[c]
+        ex.append(np.array([[p.expr[g] for g in ids] for p in probs]))
+        ha.append(np.array([g in p0.avecs for g in ids], dtype=np.uint8))
+        av.append(np.array([p0.avecs.get(g, np.zeros((8, 8))) for g in ids]))
+    hmm.set_expression(ex, av, ha, 1.5, 0.12)
+    hmm.run()
+    want = ("gamma", "states", "calls", "alpha", "beta", "delta", "scaler")
+    for s, p in enumerate(probs):
+        res = hmm_oracle.reconstruct_arrays(p0.hap_names, chroms, p0.gene_ids, p0.tprob, p.expr, p0.avecs)
+        for ci, c in enumerate(chroms):
+            r = hmm.get(ci, sample=s, want=want)
+            np.testing.assert_array_equal(r["states"], res[c]["states"], err_msg=f"sample {s} chrom {c}")
+            np.testing.assert_array_equal(r["calls"], res[c]["calls"], err_msg=f"sample {s} chrom {c}")
+            for k in ("alpha", "beta", "delta", "scaler"):
+                np.testing.assert_allclose(r[k], res[c][k], rtol=1e-9, atol=1e-9, err_msg=f"{k} sample {s} chrom {c}")
+            np.testing.assert_allclose(r["gamma"], res[c]["gamma"], rtol=1e-8, atol=1e-300)
+    hmm.close()
+
+
 @pytest.mark.parametrize("n_samples", [3, 21])
 def test_hmm_do_tables_sample_batches(n_samples, monkeypatch):
     """DO-like transition tables (entries down to exp(-69), structural zeros, a near-deterministic chain) and
