@@ -254,7 +254,7 @@ def pipelined_setup(args, rank, world, torch, dist):
             t0 = time.perf_counter()
             engs = [EmEngine.from_device(prob["R"], nl, prob["H"], [t.data_ptr() for t in ip],
                                          [t.data_ptr() for t in ix], None, el.data_ptr(), device=devno,
-                                         flags=args.flags)
+                                         flags=args.flags | 128)      # GBRS_EM_SIDE_BY_SIDE: tiles sized for the two ranges together
                     for ip, ix, el, nl in (half_a, half_b)]
             state = dict(engs=engs, t_gen=t_gen, t_create=time.perf_counter() - t0, N=prob["N"], l_split=l_split)
     except Exception as ex:                           # noqa: BLE001 - reported, then agreed on by all ranks

@@ -43,6 +43,7 @@ GBRS_EM_FORCE_INTERLEAVE = 8
 GBRS_EM_NO_STREAMS = 16
 GBRS_EM_DETERMINISTIC = 32
 GBRS_EM_KEEP_CSC = 64
+GBRS_EM_SIDE_BY_SIDE = 128
 
 
 class EmInfo(C.Structure):

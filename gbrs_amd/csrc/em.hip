@@ -997,7 +997,7 @@ int em_create_impl(uint64_t R, uint32_t L, uint32_t H, const uint32_t *const *in
         GBRS_TRY(build_tile_layout(em->tl, R, L, H, n, em->ent_row.p, em->col_ptr.p,
                                    count ? em->count.p : nullptr, (flags & GBRS_EM_MERGE_IDENTICAL_ROWS) != 0,
                                    row_order, (flags & GBRS_EM_DETERMINISTIC) != 0,
-                                   em->stream));
+                                   em->stream, (flags & GBRS_EM_SIDE_BY_SIDE) ? 2u : 1u));
         em->layout = 1;
         stg.mark("build_tile_layout");
         // the CSC copy and the per-row denominators are only needed by layout 0 (and, until

@@ -115,7 +115,7 @@ struct TileLayout {
 int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L, uint32_t H, uint64_t N,
                       const uint32_t *ent_row, const uint64_t *col_ptr, const double *count,
                       bool merge_identical_rows, int row_order /* 0 sorted, 1 interleaved, 2 streams */,
-                      bool deterministic, hipStream_t stream);
+                      bool deterministic, hipStream_t stream, unsigned side_by_side = 1 /* handles sharing the device */);
 
 // `gbrs compress`: equivalence classes of identical rows, in first-seen order.
 struct CompressResult {

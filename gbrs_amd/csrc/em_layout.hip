@@ -818,7 +818,7 @@ int compress_device(CompressResult &out, uint64_t R, uint32_t L, uint32_t H, uin
 
 int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L, uint32_t H, uint64_t N,
                       const uint32_t *ent_row, const uint64_t *col_ptr, const double *count,
-                      bool merge, int row_order, bool deterministic, hipStream_t s) {
+                      bool merge, int row_order, bool deterministic, hipStream_t s, unsigned side_by_side) {
     const bool interleave = row_order == 1, streams = row_order == 2;
     if (H > 16) return fail(GBRS_ERR_INVALID, "the tiled layout packs the haplotype mask in 16 bits (H <= 16)");
     if (N >= 0xFFFFFFFFull || L >= (1u << 27))
@@ -984,7 +984,9 @@ int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L, uint32_t H, uint6
         int dev = 0, n_cu = 0;
         GBRS_HIP_CHECK(hipGetDevice(&dev));
         GBRS_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
-        if ((uint64_t)total_words >= (uint64_t)TILE_WORDS_LARGE * TILE_ROUNDS_MIN * 3u * (uint64_t)n_cu) tile_words = TILE_WORDS_LARGE;
+        // (handles that run side by side - the locus ranges of one sample, GBRS_EM_SIDE_BY_SIDE - fill the rounds together)
+        if ((uint64_t)total_words * side_by_side >= (uint64_t)TILE_WORDS_LARGE * TILE_ROUNDS_MIN * 3u * (uint64_t)n_cu)
+            tile_words = TILE_WORDS_LARGE;
         if (const char *env = std::getenv("GBRS_TUNING_TILE_WORDS"); env && std::atoi(env) >= 64)
             tile_words = (uint32_t)std::min(std::atoi(env), GBRS_TILE_CAP - 64);
     }

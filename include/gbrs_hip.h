@@ -88,6 +88,9 @@ typedef struct gbrs_em gbrs_em_t;
 /* Keep the uploaded CSC arrays on the handle until gbrs_em_set_initial_values has run (files that
  * store alignment values other than 1). */
 #define GBRS_EM_KEEP_CSC 64u
+/* This handle is one of two locus ranges of one sample that run side by side on the device (the two engines of
+ * a rank in gbrs_amd/dist.py PipelinedShardedEM): the layout sizes its tiles for the two together. */
+#define GBRS_EM_SIDE_BY_SIDE 128u
 
 /*
  * Replaces: AlignmentPropertyMatrix(h5file=...) as consumed by EMfactory.__init__
