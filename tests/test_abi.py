@@ -21,6 +21,19 @@ def test_header_symbols_exported(hip_lib):
     assert hip_lib.gbrs_abi_version() == 2
 
 
+def test_header_constants_match_python_mirror():
+    """Every status code and gbrs_em_create flag of the header has the same value in gbrs_amd/_lib.py."""
+    from gbrs_amd import _lib
+    text = open(os.path.join(ROOT, "include", "gbrs_hip.h")).read()
+    consts = dict(re.findall(r"^#define\s+(GBRS_(?:EM|ERR|OK)[A-Z_]*)\s+\(?(-?\d+)u?\)?\s*$", text, flags=re.M))
+    consts.update(re.findall(r"^\s+(GBRS_(?:OK|ERR_[A-Z_]+))\s*=\s*(-?\d+),", text, flags=re.M))      # the status enum
+    assert {"GBRS_OK", "GBRS_ERR_FLOAT", "GBRS_EM_DETERMINISTIC", "GBRS_EM_KEEP_CSC", "GBRS_EM_SIDE_BY_SIDE"} <= set(consts)
+    for name, value in consts.items():
+        assert getattr(_lib, name) == int(value), name
+    flags = sorted(int(v) for k, v in consts.items() if k.startswith("GBRS_EM_") and int(v) > 0)
+    assert flags == [1 << i for i in range(len(flags))]          # distinct bits, none skipped
+
+
 def test_struct_sizes(tmp_path):
     """The ctypes mirrors of the info structs have the size and field offsets a C compiler gives the
     declarations in include/gbrs_hip.h (the header must also compile as plain C)."""
