@@ -29,19 +29,16 @@ constexpr int TILE_WAVES = TILE_THREADS / 64;
 #endif
 // Unpadded words per tile.  Larger tiles spread the tile prologue / epilogue (dictionary, theta gather, flush of the
 // sums) over more words, but a launch needs several rounds of tiles on the chip's resident workgroups to hide
-// its tail.  Measured on the C2 sample (52.4 M words; profiles/r02_estep_experiments.txt item 10): 5,800 words
-// 0.1101 ms, 8,128: 0.1020, 10,000-12,000: 0.0994-0.0999, 16,320 (5.1 rounds): 0.1015; the merged-rows form of the
-// same sample (10.7 M words) is 3 % slower at 11,000 than at 8,128 (1.5 rounds instead of 1.7).  build_tile_layout
-// takes the large size when it still leaves TILE_ROUNDS_MIN rounds.
+// its tail.  Measured on the C2 sample (52.4 M words; profiles/r02_estep_experiments.txt items 10, 12, 13): in locus
+// order 5,800 words 0.1101 ms, 8,128: 0.1020, 10,000-12,000: 0.0994-0.0999, 16,320 (5.1 rounds): 0.1015; with the
+// tiles launched largest first 11,008: 0.0949, 13,000: 0.0937, 14,500: 0.0933, 16,320: 0.0927; the merged-rows form
+// of the same sample (10.7 M words) is slower with tiles above 8,128 words (1.5 rounds instead of 1.7).
+// build_tile_layout takes the largest size between TILE_WORDS and TILE_WORDS_MAX that leaves TILE_ROUNDS_MIN rounds.
 #ifndef GBRS_TILE_WORDS
 #define GBRS_TILE_WORDS 8128
 #endif
-#ifndef GBRS_TILE_WORDS_LARGE
-#define GBRS_TILE_WORDS_LARGE 11008
-#endif
-constexpr int TILE_WORDS = GBRS_TILE_WORDS, TILE_WORDS_LARGE = GBRS_TILE_WORDS_LARGE, TILE_ROUNDS_MIN = 5;
-static_assert(TILE_WORDS <= GBRS_TILE_CAP - 64 && TILE_WORDS_LARGE <= GBRS_TILE_CAP - 64,
-              "a tile's padded words must fit the dictionary sort");
+constexpr int TILE_WORDS = GBRS_TILE_WORDS, TILE_WORDS_MAX = GBRS_TILE_CAP - 64, TILE_ROUNDS_MIN = 4;
+static_assert(TILE_WORDS <= TILE_WORDS_MAX, "a tile's padded words must fit the dictionary sort");
 // rows with more distinct loci than this go to the long-row path
 __host__ __device__ constexpr int pos_bits(int H) { return H <= 8 ? 5 : 4; }
 __host__ __device__ constexpr int max_row_words(int H) { return 1 << pos_bits(H); }
