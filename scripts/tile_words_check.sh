@@ -1,6 +1,7 @@
 #!/bin/bash
-# The other workloads (config-5 shard, merged rows, deterministic) at two tile sizes (GPU box).
-# Usage: scripts/tile_words_check.sh OUTDIR "DEFINES" ["DEFINES" ...]
+# The four EM workloads (config-5 shard, merged rows, deterministic, C2) under build variants (GPU box); run-time switches
+# such as GBRS_TUNING_TILE_WORDS / GBRS_TUNING_TILE_ORDER are inherited from the environment.
+# Usage: scripts/tile_words_check.sh OUTDIR "DEFINES" ["DEFINES" ...]      ("" = the default build)
 OUT=${1:-gpurun_out/tilecheck}; shift; mkdir -p $OUT
 I=0
 for DEF in "$@"; do I=$((I+1))

@@ -1,10 +1,10 @@
 #!/bin/bash
-# E-step time against the tile size (words per tile), C2 sample (GPU box).  Usage: [TILE_EXTRA=-DGBRS_TILE_CAP=16384] scripts/tile_words_variants.sh OUTDIR WORDS...
+# E-step time against the tile size (words per tile), C2 sample (GPU box).  Usage: scripts/tile_words_variants.sh OUTDIR WORDS...
+# (GBRS_TUNING_TILE_WORDS overrides build_tile_layout's rule at run time; GBRS_TUNING_TILE_ORDER=0 for the locus order)
 OUT=${1:-gpurun_out/tilewords}; shift; mkdir -p $OUT
+python -c "import __graft_entry__ as g; g.build()" > $OUT/build.log 2>&1 || { echo "BUILD FAILED"; exit 1; }
 for W in "$@"; do
-  rm -f gbrs_amd/csrc/build/em.o gbrs_amd/csrc/build/em_layout.o
-  GBRS_HIPCC_EXTRA="-DGBRS_TILE_WORDS=$W $TILE_EXTRA" python -c "import __graft_entry__ as g; g.build()" > $OUT/build.log 2>&1 || { echo "BUILD FAILED $W"; continue; }
-  timeout -k 10 200 python bench.py --steps 300 --warmup 30 --no-e2e --no-cpu-baseline --no-hmm --no-merged-line > $OUT/w$W.log 2>&1
+  GBRS_TUNING_TILE_WORDS=$W timeout -k 10 200 python bench.py --steps 300 --warmup 30 --no-e2e --no-cpu-baseline --no-hmm --no-merged-line > $OUT/w$W.log 2>&1
   python - $W $OUT/w$W.log <<'PY'
 import json, sys
 try:
@@ -14,5 +14,3 @@ except Exception as e:
     print(sys.argv[1], "FAILED", e)
 PY
 done
-rm -f gbrs_amd/csrc/build/em.o gbrs_amd/csrc/build/em_layout.o
-GBRS_HIPCC_EXTRA="" python -c "import __graft_entry__ as g; g.build()" > /dev/null 2>&1
