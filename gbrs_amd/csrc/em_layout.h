@@ -33,11 +33,14 @@ constexpr int TILE_WAVES = TILE_THREADS / 64;
 // order 5,800 words 0.1101 ms, 8,128: 0.1020, 10,000-12,000: 0.0994-0.0999, 16,320 (5.1 rounds): 0.1015; with the
 // tiles launched largest first 11,008: 0.0949, 13,000: 0.0937, 14,500: 0.0933, 16,320: 0.0927; the merged-rows form
 // of the same sample (10.7 M words) is slower with tiles above 8,128 words (1.5 rounds instead of 1.7).
-// build_tile_layout takes the largest size between TILE_WORDS and TILE_WORDS_MAX that leaves TILE_ROUNDS_MIN rounds.
+// With the largest tiles first even the merged-rows form prefers the largest tiles (8,128: 0.0465-0.0469 ms per iteration,
+// 11,008: 0.0464, 16,320: 0.0449 at 1.2 rounds; 6,016: 0.0476, 4,096: 0.0501, 2,816: 0.0528), so what is left of the
+// rule is that a launch should not have fewer tiles than the chip has places for them: build_tile_layout takes the
+// largest size between TILE_WORDS and TILE_WORDS_MAX that leaves TILE_ROUNDS_MIN round(s).
 #ifndef GBRS_TILE_WORDS
-#define GBRS_TILE_WORDS 8128
+#define GBRS_TILE_WORDS 2048
 #endif
-constexpr int TILE_WORDS = GBRS_TILE_WORDS, TILE_WORDS_MAX = GBRS_TILE_CAP - 64, TILE_ROUNDS_MIN = 4;
+constexpr int TILE_WORDS = GBRS_TILE_WORDS, TILE_WORDS_MAX = GBRS_TILE_CAP - 64, TILE_ROUNDS_MIN = 1;
 static_assert(TILE_WORDS <= TILE_WORDS_MAX, "a tile's padded words must fit the dictionary sort");
 // rows with more distinct loci than this go to the long-row path
 __host__ __device__ constexpr int pos_bits(int H) { return H <= 8 ? 5 : 4; }

@@ -99,7 +99,7 @@ def test_em_c1_shape_vs_oracle():
 
 @pytest.mark.parametrize("tile_words", [64, 1000, 8128, 11008, 16320])
 def test_em_tile_sizes_vs_oracle(tile_words, monkeypatch):
-    """The tile size is a layout choice (8,128 or 11,008 words by sample size, em_layout.h): every size, from one batch
+    """The tile size is a layout choice (2,048 to 16,320 words by sample size, em_layout.h): every size, from one batch
     per tile to the capacity of the dictionary sort, gives the oracle's iteration count and values."""
     from gbrs_amd import synth
     from gbrs_amd.alignment import AlignmentPropertyMatrix
