@@ -563,7 +563,10 @@ int em_estep(gbrs_em *em, bool materialize = false) {
 // few slots sums them in place, and the loci with many slots get one workgroup each (the leading
 // workgroups), which reduces the slots in fixed order and applies the M-step to that locus itself.
 // No intermediate A vector is written for the gathered loci and there is one launch less per step.
-constexpr int MSTEP_EPT = 4;       // elements per thread of the elementwise workgroups
+#ifndef GBRS_MSTEP_EPT
+#define GBRS_MSTEP_EPT 4
+#endif
+constexpr int MSTEP_EPT = GBRS_MSTEP_EPT;       // elements per thread of the elementwise workgroups (measured 1, 2, 4, 8)
 constexpr int GATHER_CHAINS = 4;   // independent loads in flight per lane of a many-slot locus
 __global__ void __launch_bounds__(RED_THREADS)
 mstep_gather_kernel(uint32_t L, uint32_t H, uint32_t HP, uint32_t heavy_blocks, uint32_t n_heavy,
