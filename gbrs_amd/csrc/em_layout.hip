@@ -975,7 +975,7 @@ int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L, uint32_t H, uint6
     hipLaunchKernelGGL(row_len_kernel, dim3(grid_for(M)), dim3(256), 0, s, M, hrow.p, rowstart.p, ploc.p, npm.p, dnew.p);
     GBRS_TRY(exclusive_scan(sc, npm.p, wordoff.p, M, s));
     GBRS_TRY(inclusive_scan(sc, dnew.p, dincl.p, M, s));
-    // tile size: as large as still leaves TILE_ROUNDS_MIN rounds of the chip's resident E-step workgroups (3 per CU),
+    // tile size: as large as still leaves TILE_ROUNDS_MIN rounds of the chip's resident E-step workgroups (3 or 2 per CU),
     // between TILE_WORDS and TILE_WORDS_MAX (em_layout.h); GBRS_TUNING_TILE_WORDS overrides
     uint32_t tile_words = TILE_WORDS;
     {
@@ -985,7 +985,8 @@ int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L, uint32_t H, uint6
         GBRS_HIP_CHECK(hipGetDevice(&dev));
         GBRS_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
         // (handles that run side by side - the locus ranges of one sample, GBRS_EM_SIDE_BY_SIDE - fill the rounds together)
-        const uint64_t fit = (uint64_t)total_words * side_by_side / ((uint64_t)TILE_ROUNDS_MIN * 3u * (uint64_t)std::max(n_cu, 1));
+        const unsigned per_cu = (out.weighted || H > 8) ? 2u : 3u;      // resident E-step workgroups per CU (tile_estep_kernel's launch bounds)
+        const uint64_t fit = (uint64_t)total_words * side_by_side / ((uint64_t)TILE_ROUNDS_MIN * per_cu * (uint64_t)std::max(n_cu, 1));
         tile_words = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(fit, TILE_WORDS), TILE_WORDS_MAX) & ~63u;
         if (const char *env = std::getenv("GBRS_TUNING_TILE_WORDS"); env && std::atoi(env) >= 64)
             tile_words = (uint32_t)std::min(std::atoi(env), GBRS_TILE_CAP - 64);
