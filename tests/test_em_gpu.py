@@ -97,7 +97,7 @@ def test_em_c1_shape_vs_oracle():
         em.close()
 
 
-@pytest.mark.parametrize("tile_words", [64, 1000, 8128, 11008, 16320])
+@pytest.mark.parametrize("tile_words", [64, 1000, 8128, 11008, 16320, -1000])
 def test_em_tile_sizes_vs_oracle(tile_words, monkeypatch):
     """The tile size is a layout choice (2,048 to 16,320 words by sample size, em_layout.h): every size, from one batch
     per tile to the capacity of the dictionary sort, gives the oracle's iteration count and values."""
@@ -113,7 +113,9 @@ def test_em_tile_sizes_vs_oracle(tile_words, monkeypatch):
     apm = AlignmentPropertyMatrix(shape=(inc.num_loci, inc.num_haps, inc.num_rows), indptr=inc.indptr,
                                   indices=inc.indices, haplotype_names=inc.hap_names,
                                   locus_names=inc.locus_names)
-    monkeypatch.setenv("GBRS_TUNING_TILE_WORDS", str(tile_words))
+    monkeypatch.setenv("GBRS_TUNING_TILE_WORDS", str(abs(tile_words)))
+    if tile_words < 0:                                  # the tiles in locus order instead of largest first
+        monkeypatch.setenv("GBRS_TUNING_TILE_ORDER", "0")
     for kw in (LAYOUTS["tiles"], LAYOUTS["tiles_merged"], LAYOUTS["tiles_deterministic"]):
         em = EMfactory(apm, **kw)
         em.target_lengths = eff
