@@ -15,7 +15,7 @@ LIB_PATH = os.path.join(_HERE, "libgbrs_hip.so")
 # names every build must export (checked by tests/test_abi.py against include/gbrs_hip.h)
 EXPORTS = [
     "gbrs_last_error", "gbrs_abi_version", "gbrs_device_count", "gbrs_warm_up",
-    "gbrs_em_create", "gbrs_em_create_device", "gbrs_em_set_initial_values", "gbrs_em_prepare", "gbrs_em_step", "gbrs_em_run",
+    "gbrs_em_create", "gbrs_em_create_device", "gbrs_em_create_masked", "gbrs_em_create_masked_device", "gbrs_em_set_initial_values", "gbrs_em_prepare", "gbrs_em_step", "gbrs_em_run",
     "gbrs_em_get", "gbrs_em_set_theta", "gbrs_em_group_sums", "gbrs_em_estep_partial",
     "gbrs_em_finish_step", "gbrs_em_prepare_partial", "gbrs_em_finish_prepare", "gbrs_em_stream",
     "gbrs_em_set_stream",
@@ -44,6 +44,7 @@ GBRS_EM_NO_STREAMS = 16
 GBRS_EM_DETERMINISTIC = 32
 GBRS_EM_KEEP_CSC = 64
 GBRS_EM_SIDE_BY_SIDE = 128
+GBRS_EM_ONE_SHOT = 256
 
 
 class EmInfo(C.Structure):
@@ -55,6 +56,7 @@ class EmInfo(C.Structure):
         ("layout", C.c_uint32), ("reserved", C.c_uint32),
         ("num_tiles", C.c_uint64), ("num_slots", C.c_uint64), ("num_long_rows", C.c_uint64),
         ("num_heavy_loci", C.c_uint64), ("num_light_loci", C.c_uint64), ("estep_bytes", C.c_uint64),
+        ("retained_build_bytes", C.c_uint64),
     ]
 
 
@@ -99,6 +101,8 @@ def load():
     sigs = {
         "gbrs_em_create": [u64, u32, u32, pp, pp, vp, vp, i32, u32, pp],
         "gbrs_em_create_device": [u64, u32, u32, pp, pp, vp, vp, i32, u32, pp],
+        "gbrs_em_create_masked": [u64, u32, u32, pp, pp, vp, vp, vp, i32, u32, pp],
+        "gbrs_em_create_masked_device": [u64, u32, u32, pp, pp, vp, vp, vp, i32, u32, pp],
         "gbrs_em_set_initial_values": [vp, pp],
         "gbrs_em_prepare": [vp, dbl],
         "gbrs_em_step": [vp, i32, C.POINTER(dbl)],
@@ -135,7 +139,7 @@ def load():
         fn.argtypes = args
     lib.gbrs_em_stream.restype = vp
     lib.gbrs_em_stream.argtypes = [vp]
-    if lib.gbrs_abi_version() != 2:
+    if lib.gbrs_abi_version() != 3:
         raise ImportError("libgbrs_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -34,6 +34,7 @@ class AlignmentPropertyMatrix:
         self.num_groups = 0
         self.count = None
         self.values = None          # per-haplotype float64 arrays aligned with indices, or None = all ones
+        self.haplotype_mask = None  # uint32[L], bit h = (h, l) kept: a `-G` mask the device applies (set_haplotype_mask)
         groups_thread = None
         if h5file is not None:
             from . import emase_h5
@@ -46,7 +47,6 @@ class AlignmentPropertyMatrix:
                     try:
                         if self.lname is None:
                             raise RuntimeError('Locus IDs are not available.')
-                        self.lid = dict(zip(self.lname, np.arange(len(self.lname))))
                         self.load_groups(grpfile)
                     except BaseException as ex:      # noqa: BLE001 - re-raised on the calling thread below
                         box['error'] = ex
@@ -54,6 +54,8 @@ class AlignmentPropertyMatrix:
                 def start():
                     nonlocal groups_thread
                     self.num_loci, self.num_haplotypes, self.num_reads = self.shape
+                    if self.lname is not None:       # before anything that runs beside the decode looks a name up
+                        self.lid = dict(zip(self.lname, np.arange(len(self.lname))))
                     if on_names is not None:
                         on_names(self)
                     if grpfile is not None:
@@ -72,6 +74,8 @@ class AlignmentPropertyMatrix:
             self._load_npz(npzfile)
             if on_names is not None:
                 self.num_loci, self.num_haplotypes, self.num_reads = self.shape
+                if self.lname is not None:
+                    self.lid = dict(zip(self.lname, np.arange(len(self.lname))))
                 on_names(self)
         else:
             if shape is None or len(shape) != 3 or (np.array(shape) < 1).any():
@@ -148,9 +152,27 @@ class AlignmentPropertyMatrix:
         return self._group_csr[1]
 
     # ---- structure edits -------------------------------------------------------------------
+    def set_haplotype_mask(self, allowed):
+        """The `-G` restriction of `gbrs quantify` (gbrs/emase_utils.py:271-273: `multiply(gtmask, axis=2)` +
+        `eliminate_zeros()`) as a per-locus bit mask, uint32[L] with bit h set where (haplotype h, locus l) stays.
+        The host arrays are left alone: gbrs_em_create_masked drops the columns on the device.  Anything that
+        needs the edited structure on the host (save, nnz) calls apply_haplotype_mask() first."""
+        allowed = np.ascontiguousarray(allowed, dtype=np.uint32)
+        if allowed.shape != (self.num_loci,):
+            raise RuntimeError('The haplotype mask does not match to the matrix shape.')
+        self.haplotype_mask = allowed if self.haplotype_mask is None else (self.haplotype_mask & allowed)
+
+    def apply_haplotype_mask(self):
+        """Carry a pending device-side mask out on the host arrays (the reference's eager behaviour)."""
+        if self.haplotype_mask is None:
+            return
+        allowed, self.haplotype_mask = self.haplotype_mask, None
+        H = self.num_haplotypes
+        self.mask_haplotype_loci(((allowed[None, :] >> np.arange(H, dtype=np.uint32)[:, None]) & 1).astype(np.float64))
+
     def mask_haplotype_loci(self, gtmask):
-        """Drop every entry (h, l) with gtmask[h, l] == 0: `multiply(gtmask, axis=2)` followed by
-        `eliminate_zeros()` per haplotype (gbrs/emase_utils.py:271-273)."""
+        """Drop every entry (h, l) with gtmask[h, l] == 0 from the host arrays: `multiply(gtmask, axis=2)` followed
+        by `eliminate_zeros()` per haplotype (gbrs/emase_utils.py:271-273)."""
         gtmask = np.asarray(gtmask)
         L, H, R = self.shape
         for h in range(H):
@@ -164,6 +186,7 @@ class AlignmentPropertyMatrix:
 
     @property
     def nnz(self):
+        self.apply_haplotype_mask()
         return int(sum(len(i) for i in self.indices))
 
     # ---- npz mirror ------------------------------------------------------------------------
@@ -191,6 +214,7 @@ class AlignmentPropertyMatrix:
             z.close()
 
     def save_npz(self, path):
+        self.apply_haplotype_mask()
         out = dict(shape=np.asarray(self.shape, dtype=np.int64))
         for h in range(self.num_haplotypes):
             out[f'indptr{h}'] = self.indptr[h]
@@ -210,6 +234,7 @@ class AlignmentPropertyMatrix:
         if str(h5file).endswith('.npz'):
             return self.save_npz(h5file)
         from . import emase_h5
+        self.apply_haplotype_mask()
         emase_h5.save(self, h5file, **kw)
 
 

@@ -115,7 +115,8 @@ def main(argv=None) -> int:
                      max_iters=args.max_iters, tolerance=args.tolerance,
                      report_alignment_counts=args.report_alignment_counts,
                      report_posterior=args.report_posterior, device=args.device,
-                     merge_identical_rows=args.merge_identical_rows, stage_times=stages)
+                     merge_identical_rows=args.merge_identical_rows, stage_times=stages,
+                     one_shot=True)         # the command builds one handle and exits: GBRS_EM_ONE_SHOT
         elif args.command == 'compress':
             from .compress import compress
             files = [f for x in args.emase_files for f in x.split(',')]

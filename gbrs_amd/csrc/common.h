@@ -42,12 +42,16 @@ int select_device(int device);
 // several multi-gigabyte temporaries keeps them until it is done instead of handing them back one by one (up to
 // 96 GB of them; beyond that blocks are freed as they go).
 void deferred_free(void *p, size_t bytes);
+// hipFree everything parked on this thread right now (a hipMalloc just failed); returns the bytes given back
+size_t deferred_flush();
 struct DeferFrees {
     // sink: where the collected blocks go when the scope ends (their new owner frees them later, e.g. with the
-    // handle); nullptr = hipFree them there and then
-    explicit DeferFrees(std::vector<void *> *sink = nullptr);
+    // handle: GBRS_EM_ONE_SHOT); nullptr = one batched hipFree pass there and then.  sink_bytes (nullable) is
+    // increased by the bytes handed over.
+    explicit DeferFrees(std::vector<void *> *sink = nullptr, size_t *sink_bytes = nullptr);
     ~DeferFrees();
     std::vector<void *> *sink;
+    size_t *sink_bytes;
     DeferFrees(const DeferFrees &) = delete;
     DeferFrees &operator=(const DeferFrees &) = delete;
     bool outer;
@@ -71,6 +75,10 @@ struct DevBuf {
         n = count;
         if (count == 0) return GBRS_OK;
         hipError_t e = hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T));
+        if (e != hipSuccess && deferred_flush() > 0) {      // blocks parked by a DeferFrees scope: give them back, retry
+            (void)hipGetLastError();
+            e = hipMalloc(reinterpret_cast<void **>(&p), count * sizeof(T));
+        }
         if (e != hipSuccess) {
             p = nullptr;
             return fail(GBRS_ERR_HIP, "hipMalloc(%zu bytes) failed: %s", count * sizeof(T),

@@ -28,7 +28,17 @@ void deferred_free(void *p, size_t bytes) {
         (void)hipFree(p);
     }
 }
-DeferFrees::DeferFrees(std::vector<void *> *sink_) : sink(sink_), outer(g_deferred == nullptr) {
+size_t deferred_flush() {
+    if (!g_deferred || g_deferred->empty()) return 0;
+    (void)hipDeviceSynchronize();                   // nothing in flight may still read a parked block
+    for (void *p : *g_deferred) (void)hipFree(p);
+    g_deferred->clear();
+    const size_t b = g_deferred_bytes;
+    g_deferred_bytes = 0;
+    return b;
+}
+DeferFrees::DeferFrees(std::vector<void *> *sink_, size_t *sink_bytes_)
+    : sink(sink_), sink_bytes(sink_bytes_), outer(g_deferred == nullptr) {
     static const bool off = [] { const char *e = std::getenv("GBRS_TUNING_EAGER_FREE"); return e && std::atoi(e) != 0; }();
     if (outer && !off) g_deferred = new std::vector<void *>();
     else outer = false;
@@ -37,10 +47,13 @@ DeferFrees::~DeferFrees() {
     if (!outer) return;
     std::vector<void *> *v = g_deferred;
     g_deferred = nullptr;
-    g_deferred_bytes = 0;
-    if (sink) sink->insert(sink->end(), v->begin(), v->end());
-    else
+    if (sink) {
+        sink->insert(sink->end(), v->begin(), v->end());
+        if (sink_bytes) *sink_bytes += g_deferred_bytes;
+    } else {
         for (void *p : *v) (void)hipFree(p);
+    }
+    g_deferred_bytes = 0;
     delete v;
 }
 

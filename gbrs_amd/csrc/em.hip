@@ -374,6 +374,21 @@ csc_acc_values_kernel(uint64_t n, uint32_t ncols, uint32_t L, uint32_t H, const 
     atomicAdd(&acc[(size_t)l * H + h], (count ? count[r] : 1.0) * vals[k] / d);
 }
 
+// `-G` haplotype mask (gbrs/emase_utils.py:240-273: multiply(gtmask, axis=2) + eliminate_zeros): the mask is
+// per (haplotype, locus), i.e. it drops whole CSC columns, so the masked tensor is the kept columns moved up
+// against each other.  dst_ptr are the column offsets after the mask (dropped columns have width 0), src_ptr the
+// offsets in the arrays as uploaded; one thread per surviving entry.
+template <typename T>
+__global__ void __launch_bounds__(256)
+compact_columns_kernel(uint64_t n, uint32_t ncols, const uint64_t *__restrict__ dst_ptr,
+                       const uint64_t *__restrict__ src_ptr, const T *__restrict__ src, T *__restrict__ dst) {
+    const uint64_t k = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k - (threadIdx.x & 63) >= n) return;
+    const bool live = k < n;
+    const uint32_t c = entry_column(dst_ptr, ncols, live ? k : n - 1, n);
+    if (live) dst[k] = src[src_ptr[c] + (k - dst_ptr[c])];
+}
+
 // largest row id of the uploaded arrays (inputs that arrive as device pointers cannot be checked on
 // the host, and an out-of-range id would make the scatter kernels fault)
 __global__ void __launch_bounds__(256)
@@ -423,6 +438,8 @@ struct gbrs_em {
     // layout 0
     DevBuf<uint32_t> ent_row;
     DevBuf<uint64_t> col_ptr;     // H*L + 1
+    DevBuf<uint64_t> col_ptr_src; // H*L + 1: column offsets of the caller's arrays when a haplotype mask dropped columns
+    bool masked = false;          // (kept with GBRS_EM_KEEP_CSC, for gbrs_em_set_initial_values)
     DevBuf<double> den;           // R
 
     DevBuf<double> count, eff_len;                 // R ; L*H locus-major
@@ -873,13 +890,18 @@ int em_ensure_hist(gbrs_em *em, int cap) {
 
 // Concatenate the per-haplotype CSC arrays on the device: column id c = h*L + l, col_ptr[c] is the
 // offset of the column's first entry in ent_row.  Validates monotone indptr and (host inputs) row ids.
+// allowed (host, nullable): uint32[L], bit h set = the entries of (haplotype h, locus l) stay; the other columns
+// are dropped on the device (compact_columns_kernel).  src_ptr_dev (nullable) then receives the column offsets of
+// the arrays as given, for callers that have to move a second per-entry array the same way.
 int upload_csc(uint64_t R, uint32_t L, uint32_t H, const uint32_t *const *indptr,
                const uint32_t *const *indices, bool on_device, DevBuf<uint32_t> &ent_row,
-               DevBuf<uint64_t> &col_ptr_dev, uint64_t &n_out) {
+               DevBuf<uint64_t> &col_ptr_dev, uint64_t &n_out, const uint32_t *allowed = nullptr,
+               DevBuf<uint64_t> *src_ptr_dev = nullptr, hipStream_t stream = nullptr) {
     const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-    std::vector<uint64_t> col_ptr((size_t)H * L + 1);
+    std::vector<uint64_t> col_ptr((size_t)H * L + 1), src_ptr;
+    if (allowed) src_ptr.resize((size_t)H * L + 1);
     std::vector<uint32_t> tmp(L + 1);
-    uint64_t n = 0;
+    uint64_t n = 0, n_src = 0;
     std::vector<uint64_t> hap_off(H + 1);
     for (uint32_t h = 0; h < H; ++h) {
         if (!indptr[h]) return fail(GBRS_ERR_INVALID, "indptr[%u] is NULL", h);
@@ -889,23 +911,46 @@ int upload_csc(uint64_t R, uint32_t L, uint32_t H, const uint32_t *const *indptr
             std::memcpy(tmp.data(), indptr[h], (L + 1) * sizeof(uint32_t));
         }
         if (tmp[0] != 0) return fail(GBRS_ERR_INVALID, "indptr[%u][0] != 0", h);
-        hap_off[h] = n;
+        hap_off[h] = n_src;
         for (uint32_t l = 0; l < L; ++l) {
             if (tmp[l + 1] < tmp[l]) return fail(GBRS_ERR_INVALID, "indptr[%u] is not non-decreasing at %u", h, l);
-            col_ptr[(size_t)h * L + l] = n + tmp[l];
+            col_ptr[(size_t)h * L + l] = n;
+            if (allowed) {
+                src_ptr[(size_t)h * L + l] = n_src + tmp[l];
+                if ((allowed[l] >> h) & 1u) n += tmp[l + 1] - tmp[l];
+            } else {
+                n += tmp[l + 1] - tmp[l];
+            }
         }
-        n += tmp[L];
+        n_src += tmp[L];
     }
-    hap_off[H] = n;
+    hap_off[H] = n_src;
     col_ptr[(size_t)H * L] = n;
     GBRS_TRY(col_ptr_dev.alloc(col_ptr.size()));
     GBRS_HIP_CHECK(hipMemcpy(col_ptr_dev.p, col_ptr.data(), col_ptr_dev.bytes(), hipMemcpyHostToDevice));
     GBRS_TRY(ent_row.alloc(std::max<uint64_t>(n, 1)));
+    DevBuf<uint32_t> staged;                      // masked: the arrays as given, before the columns move up
+    DevBuf<uint64_t> src_local;
+    if (allowed) {
+        src_ptr[(size_t)H * L] = n_src;
+        GBRS_TRY(staged.alloc(std::max<uint64_t>(n_src, 1)));
+        DevBuf<uint64_t> &sp = src_ptr_dev ? *src_ptr_dev : src_local;
+        GBRS_TRY(sp.alloc(src_ptr.size()));
+        GBRS_HIP_CHECK(hipMemcpy(sp.p, src_ptr.data(), sp.bytes(), hipMemcpyHostToDevice));
+    }
+    uint32_t *dst = allowed ? staged.p : ent_row.p;
     for (uint32_t h = 0; h < H; ++h) {
         const uint64_t cnt = hap_off[h + 1] - hap_off[h];
         if (cnt == 0) continue;
         if (!indices[h]) return fail(GBRS_ERR_INVALID, "indices[%u] is NULL", h);
-        GBRS_HIP_CHECK(hipMemcpy(ent_row.p + hap_off[h], indices[h], cnt * sizeof(uint32_t), kind));
+        GBRS_HIP_CHECK(hipMemcpy(dst + hap_off[h], indices[h], cnt * sizeof(uint32_t), kind));
+    }
+    if (allowed && n) {
+        const DevBuf<uint64_t> &sp = src_ptr_dev ? *src_ptr_dev : src_local;
+        hipLaunchKernelGGL(compact_columns_kernel<uint32_t>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, n,
+                           H * L, col_ptr_dev.p, sp.p, staged.p, ent_row.p);
+        GBRS_HIP_CHECK(hipStreamSynchronize(stream));
+        GBRS_HIP_CHECK(hipGetLastError());
     }
     n_out = n;
     return GBRS_OK;
@@ -928,7 +973,7 @@ int check_row_ids(uint64_t n, const uint32_t *ent_row, uint64_t R, hipStream_t s
 
 int em_create_impl(uint64_t R, uint32_t L, uint32_t H, const uint32_t *const *indptr,
                    const uint32_t *const *indices, const double *count, const double *eff_len,
-                   int device, uint32_t flags, bool on_device, gbrs_em_t **out) {
+                   const uint32_t *allowed, int device, uint32_t flags, bool on_device, gbrs_em_t **out) {
     if (!out) return fail(GBRS_ERR_INVALID, "out is NULL");
     *out = nullptr;
     if (H < 1 || H > 32 || L < 1 || R < 1 || R > 0xFFFFFFFFull)
@@ -948,7 +993,9 @@ int em_create_impl(uint64_t R, uint32_t L, uint32_t H, const uint32_t *const *in
     const hipMemcpyKind kind = on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     uint64_t n = 0;
     StageTimer stg("create");
-    GBRS_TRY(upload_csc(R, L, H, indptr, indices, on_device, em->ent_row, em->col_ptr, n));
+    em->masked = allowed != nullptr;
+    GBRS_TRY(upload_csc(R, L, H, indptr, indices, on_device, em->ent_row, em->col_ptr, n, allowed,
+                        (allowed && (flags & GBRS_EM_KEEP_CSC)) ? &em->col_ptr_src : nullptr, em->stream));
     stg.mark("upload csc");
     em->N = n;
     const size_t LH = (size_t)L * H;
@@ -997,6 +1044,7 @@ int em_create_impl(uint64_t R, uint32_t L, uint32_t H, const uint32_t *const *in
             const bool distinct = count != nullptr || (flags & GBRS_EM_MERGE_IDENTICAL_ROWS);
             row_order = (distinct && !(flags & GBRS_EM_NO_INTERLEAVE)) ? 1 : 0;
         }
+        em->tl.retain_temporaries = (flags & GBRS_EM_ONE_SHOT) != 0;
         GBRS_TRY(build_tile_layout(em->tl, R, L, H, n, em->ent_row.p, em->col_ptr.p,
                                    count ? em->count.p : nullptr, (flags & GBRS_EM_MERGE_IDENTICAL_ROWS) != 0,
                                    row_order, (flags & GBRS_EM_DETERMINISTIC) != 0,
@@ -1006,10 +1054,15 @@ int em_create_impl(uint64_t R, uint32_t L, uint32_t H, const uint32_t *const *in
         // the CSC copy and the per-row denominators are only needed by layout 0 (and, until
         // gbrs_em_set_initial_values has run, when the caller announced stored values)
         em->keep_csc = (flags & GBRS_EM_KEEP_CSC) != 0;
-        if (!em->keep_csc) {                  // (kept on the device until the handle goes: common.h, DeferFrees)
-            DeferFrees with_the_layout(&em->tl.retired);
-            em->ent_row.release();
-            em->den.release();
+        if (!em->keep_csc) {
+            if (em->tl.retain_temporaries) {  // one-shot process: left to the handle's destructor (common.h, DeferFrees)
+                DeferFrees with_the_layout(&em->tl.retired, &em->tl.retired_bytes);
+                em->ent_row.release();
+                em->den.release();
+            } else {
+                em->ent_row.release();
+                em->den.release();
+            }
         }
         stg.mark("release csc copy");
     }
@@ -1092,13 +1145,31 @@ extern "C" {
 int gbrs_em_create(uint64_t R, uint32_t L, uint32_t H, const uint32_t *const *indptr,
                    const uint32_t *const *indices, const double *count, const double *eff_len,
                    int device, uint32_t flags, gbrs_em_t **out) {
-    return em_create_impl(R, L, H, indptr, indices, count, eff_len, device, flags, false, out);
+    return em_create_impl(R, L, H, indptr, indices, count, eff_len, nullptr, device, flags, false, out);
 }
 
 int gbrs_em_create_device(uint64_t R, uint32_t L, uint32_t H, const uint32_t *const *indptr,
                           const uint32_t *const *indices, const double *count, const double *eff_len,
                           int device, uint32_t flags, gbrs_em_t **out) {
-    return em_create_impl(R, L, H, indptr, indices, count, eff_len, device, flags, true, out);
+    return em_create_impl(R, L, H, indptr, indices, count, eff_len, nullptr, device, flags, true, out);
+}
+
+int gbrs_em_create_masked(uint64_t R, uint32_t L, uint32_t H, const uint32_t *const *indptr,
+                          const uint32_t *const *indices, const double *count, const double *eff_len,
+                          const uint32_t *allowed, int device, uint32_t flags, gbrs_em_t **out) {
+    if (allowed && H < 32)
+        for (uint32_t l = 0; l < L; ++l)
+            if (allowed[l] >> H) return fail(GBRS_ERR_INVALID, "allowed[%u] names a haplotype >= num_haps", l);
+    return em_create_impl(R, L, H, indptr, indices, count, eff_len, allowed, device, flags, false, out);
+}
+
+int gbrs_em_create_masked_device(uint64_t R, uint32_t L, uint32_t H, const uint32_t *const *indptr,
+                                 const uint32_t *const *indices, const double *count, const double *eff_len,
+                                 const uint32_t *allowed, int device, uint32_t flags, gbrs_em_t **out) {
+    if (allowed && H < 32)
+        for (uint32_t l = 0; l < L; ++l)
+            if (allowed[l] >> H) return fail(GBRS_ERR_INVALID, "allowed[%u] names a haplotype >= num_haps", l);
+    return em_create_impl(R, L, H, indptr, indices, count, eff_len, allowed, device, flags, true, out);
 }
 
 namespace {
@@ -1130,13 +1201,25 @@ int gbrs_em_set_initial_values(gbrs_em_t *em, const double *const *values) {
         DevBuf<int> bad;
         GBRS_TRY(vals.alloc(n));
         GBRS_TRY(bad.alloc(1));
+        // values[h] lines up with indices[h] as given to create: under a haplotype mask they are staged whole and
+        // then moved the way the row ids were (compact_columns_kernel)
+        const DevBuf<uint64_t> &given = em->masked ? em->col_ptr_src : em->col_ptr;
+        if (!given.p) return fail(GBRS_ERR_STATE, "the handle no longer knows the layout of the caller's arrays");
         std::vector<uint64_t> cp((size_t)em->H * em->L + 1);
-        GBRS_HIP_CHECK(hipMemcpy(cp.data(), em->col_ptr.p, cp.size() * 8, hipMemcpyDeviceToHost));
+        GBRS_HIP_CHECK(hipMemcpy(cp.data(), given.p, cp.size() * 8, hipMemcpyDeviceToHost));
+        DevBuf<double> staged;
+        if (em->masked) GBRS_TRY(staged.alloc(std::max<uint64_t>(cp.back(), 1)));
+        double *dst = em->masked ? staged.p : vals.p;
         for (uint32_t h = 0; h < em->H; ++h) {
             const uint64_t b = cp[(size_t)h * em->L], cnt = cp[(size_t)(h + 1) * em->L] - b;
             if (!cnt) continue;
             if (!values[h]) return fail(GBRS_ERR_INVALID, "values[%u] is NULL", h);
-            GBRS_HIP_CHECK(hipMemcpy(vals.p + b, values[h], cnt * sizeof(double), hipMemcpyHostToDevice));
+            GBRS_HIP_CHECK(hipMemcpy(dst + b, values[h], cnt * sizeof(double), hipMemcpyHostToDevice));
+        }
+        if (em->masked) {
+            hipLaunchKernelGGL(compact_columns_kernel<double>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, em->stream,
+                               n, em->H * em->L, em->col_ptr.p, em->col_ptr_src.p, staged.p, vals.p);
+            GBRS_HIP_CHECK(hipStreamSynchronize(em->stream));
         }
         GBRS_HIP_CHECK(hipMemsetAsync(bad.p, 0, sizeof(int), em->stream));
         GBRS_HIP_CHECK(hipMemsetAsync(em->den.p, 0, em->den.bytes(), em->stream));
@@ -1159,6 +1242,7 @@ int gbrs_em_set_initial_values(gbrs_em_t *em, const double *const *values) {
     if (em->layout == 1 && em->keep_csc) {     // the tiled layout needs neither array from here on
         em->ent_row.release();
         em->den.release();
+        em->col_ptr_src.release();
         em->keep_csc = false;
     }
     return GBRS_OK;
@@ -1402,6 +1486,7 @@ int gbrs_em_info(gbrs_em_t *em, gbrs_em_info_t *info) {
     info->num_loci = em->L;
     info->num_haps = em->H;
     info->layout = em->layout;
+    info->retained_build_bytes = em->tl.retired_bytes;
     return GBRS_OK;
 }
 

@@ -99,9 +99,12 @@ struct TileLayout {
     DevBuf<uint32_t> long_loc, long_mask;
     DevBuf<double> long_weight;      // n_long
     DevBuf<double> acc_extra;        // L*H, global-atomic target of the long-row kernel
-    // build temporaries, given back to the device with the layout (common.h, DeferFrees): a process that handles one
-    // sample never pays for returning them, one that handles many pays at gbrs_em_destroy
+    // GBRS_EM_ONE_SHOT: the build temporaries stay allocated until the layout goes (common.h, DeferFrees): a
+    // process that handles one sample and exits never pays for returning them.  Without the flag they are freed in
+    // one pass when the build ends.
+    bool retain_temporaries = false;
     std::vector<void *> retired;
+    size_t retired_bytes = 0;
     TileLayout() = default;
     TileLayout(const TileLayout &) = delete;
     TileLayout &operator=(const TileLayout &) = delete;

@@ -823,7 +823,9 @@ int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L, uint32_t H, uint6
     if (H > 16) return fail(GBRS_ERR_INVALID, "the tiled layout packs the haplotype mask in 16 bits (H <= 16)");
     if (N >= 0xFFFFFFFFull || L >= (1u << 27))
         return fail(GBRS_ERR_INVALID, "the tiled layout needs N < 2^32 entries and L < 2^27 loci per handle");
-    DeferFrees keep_temporaries(&out.retired);       // (common.h) the temporaries leave with the layout
+    // (common.h) the temporaries are parked while the build runs - a hipMalloc that follows a large hipFree stalls on
+    // some hosts - and go back in one pass when it ends; a one-shot process leaves them to the layout's destructor
+    DeferFrees park_temporaries(out.retain_temporaries ? &out.retired : nullptr, &out.retired_bytes);
     StageTimer stg("layout");
     Scratch sc;
     DevBuf<BuildFlags> d_flags;

@@ -20,7 +20,8 @@ class EMfactory:
     """A class that coordinates Expectation-Maximization (MI355X HIP path)."""
 
     def __init__(self, alignments, device: int = 0, merge_identical_rows: bool = False,
-                 csc_layout: bool = False, extra_flags: int = 0, deterministic: bool = False):
+                 csc_layout: bool = False, extra_flags: int = 0, deterministic: bool = False,
+                 one_shot: bool = False):
         self.probability = alignments
         self.grp_conv_mat = None          # kept for attribute parity; groups live in probability
         self.t2t_mat = None               # Models 1-3 only (EMfactory.py:48-59): never built
@@ -28,7 +29,8 @@ class EMfactory:
         self.device = device
         self.flags = (_lib.GBRS_EM_MERGE_IDENTICAL_ROWS if merge_identical_rows else 0) | \
                      (_lib.GBRS_EM_LAYOUT_CSC if csc_layout else 0) | \
-                     (_lib.GBRS_EM_DETERMINISTIC if deterministic else 0) | int(extra_flags)   # tuning switches of gbrs_hip.h
+                     (_lib.GBRS_EM_DETERMINISTIC if deterministic else 0) | \
+                     (_lib.GBRS_EM_ONE_SHOT if one_shot else 0) | int(extra_flags)   # tuning switches of gbrs_hip.h
         self._h = None
         self._theta = None                # host copy of allelic_expression (H x L)
         self._theta_dirty = False         # host copy edited, device not yet updated
@@ -49,8 +51,14 @@ class EMfactory:
         cnt = None if apm.count is None else np.ascontiguousarray(apm.count, dtype=np.float64)
         vals = getattr(apm, 'values', None)
         flags = self.flags | (_lib.GBRS_EM_KEEP_CSC if vals is not None else 0)
-        _lib.check(lib.gbrs_em_create(R, L, H, tab_p, tab_i, _lib.ptr(cnt), _lib.ptr(eff),
-                                      self.device, flags, C.byref(h)))
+        allowed = getattr(apm, 'haplotype_mask', None)      # `-G`: the device drops the masked columns
+        if allowed is not None:
+            allowed = np.ascontiguousarray(allowed, dtype=np.uint32)
+            _lib.check(lib.gbrs_em_create_masked(R, L, H, tab_p, tab_i, _lib.ptr(cnt), _lib.ptr(eff),
+                                                 _lib.ptr(allowed), self.device, flags, C.byref(h)))
+        else:
+            _lib.check(lib.gbrs_em_create(R, L, H, tab_p, tab_i, _lib.ptr(cnt), _lib.ptr(eff),
+                                          self.device, flags, C.byref(h)))
         self._h = h
         if vals is not None:
             # the file stores alignment values: they fix the starting point (EMfactory.py:95-98)
@@ -311,7 +319,8 @@ def write_locus_table(filename, hap_names, row_names, values, reorder='as-is', n
     name_blob, name_off = _blob_cached(names)
     note_blob = note_off = None
     if notes is not None:
-        note_blob, note_off = _blob([str(notes[n]) for n in names])
+        aligned = notes.aligned_blob(row_names) if hasattr(notes, 'aligned_blob') else None
+        note_blob, note_off = aligned if aligned is not None else _blob([str(notes[n]) for n in names])
     head = '\t'.join(['locus', *hap_names, 'total'] + (['notes'] if notes is not None else [])) + '\n'
 
     def emit():       # every array the call reads is held by this closure

@@ -8,6 +8,13 @@ import numpy as np
 from . import _lib
 
 
+def _allowed_array(allowed, L):
+    al = np.ascontiguousarray(allowed, dtype=np.uint32)
+    if al.shape != (L,):
+        raise RuntimeError('allowed must hold one haplotype bit mask per locus')
+    return al
+
+
 class EmEngine:
     def __init__(self, handle, shape, keepalive=None):
         self._h = handle
@@ -16,7 +23,7 @@ class EmEngine:
 
     # ---- construction ----------------------------------------------------------------------
     @classmethod
-    def from_host(cls, R, L, H, indptr, indices, count=None, eff_len=None, device=0, flags=0):
+    def from_host(cls, R, L, H, indptr, indices, count=None, eff_len=None, device=0, flags=0, allowed=None):
         lib = _lib.load()
         ip = [np.ascontiguousarray(p, dtype=np.uint32) for p in indptr]
         ix = [np.ascontiguousarray(i, dtype=np.uint32) for i in indices]
@@ -30,19 +37,31 @@ class EmEngine:
         if eff is not None and eff.shape != (H, L):
             raise RuntimeError('eff_len must be (H x L)')
         h = C.c_void_p()
-        _lib.check(lib.gbrs_em_create(R, L, H, _lib.ptr_table(ip), _lib.ptr_table(ix), _lib.ptr(cnt),
-                                      _lib.ptr(eff), device, flags, C.byref(h)))
+        if allowed is not None:         # `-G`: uint32[L] haplotype bits per locus, applied on the device
+            al = _allowed_array(allowed, L)
+            _lib.check(lib.gbrs_em_create_masked(R, L, H, _lib.ptr_table(ip), _lib.ptr_table(ix), _lib.ptr(cnt),
+                                                 _lib.ptr(eff), _lib.ptr(al), device, flags, C.byref(h)))
+        else:
+            _lib.check(lib.gbrs_em_create(R, L, H, _lib.ptr_table(ip), _lib.ptr_table(ix), _lib.ptr(cnt),
+                                          _lib.ptr(eff), device, flags, C.byref(h)))
         return cls(h, (L, H, R))
 
     @classmethod
     def from_device(cls, R, L, H, indptr_ptrs, indices_ptrs, count_ptr=None, eff_len_ptr=None,
-                    device=0, flags=0):
-        """All arguments are raw device addresses (ints); the arrays are only read during the call."""
+                    device=0, flags=0, allowed=None):
+        """All array arguments are raw device addresses (ints); the arrays are only read during the call.
+        `allowed` (the `-G` mask) is a host uint32[L] array."""
         lib = _lib.load()
         h = C.c_void_p()
-        _lib.check(lib.gbrs_em_create_device(R, L, H, _lib.raw_table(indptr_ptrs),
-                                             _lib.raw_table(indices_ptrs), count_ptr, eff_len_ptr,
-                                             device, flags, C.byref(h)))
+        if allowed is not None:
+            al = _allowed_array(allowed, L)
+            _lib.check(lib.gbrs_em_create_masked_device(R, L, H, _lib.raw_table(indptr_ptrs),
+                                                        _lib.raw_table(indices_ptrs), count_ptr, eff_len_ptr,
+                                                        _lib.ptr(al), device, flags, C.byref(h)))
+        else:
+            _lib.check(lib.gbrs_em_create_device(R, L, H, _lib.raw_table(indptr_ptrs),
+                                                 _lib.raw_table(indices_ptrs), count_ptr, eff_len_ptr,
+                                                 device, flags, C.byref(h)))
         return cls(h, (L, H, R))
 
     def set_initial_values(self, values):

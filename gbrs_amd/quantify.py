@@ -32,40 +32,121 @@ def _default_support_file(given, default_name, what_is_lost):
     return path
 
 
-def read_genotype_calls(genotype_file):
-    """{gene id: diplotype string} from a `genotypes.tsv` (`#Gene_ID<TAB>Diplotype` header, then one
-    line per gene).  Only the comment lines that open the file are skipped (gbrs/emase_utils.py:248)."""
-    calls = {}
-    in_header = True
+def read_genotype_table(genotype_file):
+    """(gene ids, diplotype strings) of a `genotypes.tsv` in file order, one pair per line (a gene listed twice
+    appears twice): `#Gene_ID<TAB>Diplotype` header, then `<gene><TAB><call>[<TAB>...]` lines.  Only the comment
+    lines that open the file are skipped (gbrs/emase_utils.py:262: dropwhile(is_comment))."""
     with open(genotype_file) as fh:
-        for line in fh:
-            if in_header and line.startswith('#'):
-                continue
-            in_header = False
-            fields = line.rstrip().split('\t')
-            calls[fields[0]] = fields[1]
-    return calls
+        text = fh.read()
+    pos = 0
+    while text.startswith('#', pos):
+        nl = text.find('\n', pos)
+        pos = len(text) if nl < 0 else nl + 1
+    body = text[pos:]
+    if not body:
+        return [], []
+    n_lines = body.count('\n') + (0 if body.endswith('\n') else 1)
+    # the plain form - exactly two tab-separated fields per line, no other white space - splits in one pass
+    if body.count('\t') == n_lines and not (' ' in body or '\r' in body or '\n\n' in body or body.startswith('\n')):
+        tokens = body.replace('\n', '\t').split('\t')
+        if not body.endswith('\n'):
+            tokens.append('')
+        if len(tokens) == 2 * n_lines + 1 and tokens[-1] == '':
+            return tokens[0:-1:2], tokens[1:-1:2]
+    genes, calls = [], []
+    for line in body.splitlines():
+        g, gt = line.rstrip().split('\t')[:2]           # ValueError on a one-field line, as in the reference
+        genes.append(g)
+        calls.append(gt)
+    return genes, calls
+
+
+def read_genotype_calls(genotype_file):
+    """{gene id: diplotype string}; for a gene listed twice the later line (what gtcall_g keeps,
+    gbrs/emase_utils.py:265)."""
+    return dict(zip(*read_genotype_table(genotype_file)))
+
+
+class CallNotes:
+    """The `notes` argument of the report writers for one naming level: name -> diplotype call, None where the
+    gene has no call (printed as `None`, as dict.fromkeys leaves it in the reference: gbrs/emase_utils.py:251-253).
+    Behaves like the reference's dict for look-ups; a writer that lists exactly the names it was built over gets
+    the whole notes column in one piece (aligned_blob)."""
+
+    def __init__(self, names, text, has_call):
+        self.names = names                 # the list / array the table rows are named by
+        self.text = text                   # 'U' array aligned with names: the call, 'None' without one
+        self.has_call = has_call           # bool array aligned with names
+        self._index = None
+
+    def __getitem__(self, name):
+        if self._index is None:
+            self._index = {str(n): k for k, n in enumerate(self.names)}
+        k = self._index[str(name)]
+        return str(self.text[k]) if self.has_call[k] else None
+
+    def __len__(self):
+        return len(self.text)
+
+    def aligned_blob(self, row_names):
+        """(bytes of str(call) for every row laid end to end, int64 offsets), or None when row_names is not the
+        name list this column was built over (or a call is not plain ASCII)."""
+        if row_names is not self.names:
+            return None
+        n, width = len(self.text), self.text.dtype.itemsize // 4
+        code = np.frombuffer(self.text.tobytes(), dtype=np.uint32).reshape(n, width)
+        if (code > 127).any():
+            return None
+        used = code != 0
+        off = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(used.sum(axis=1), out=off[1:])
+        return code[used].astype(np.uint8).tobytes(), off
 
 
 def diplotype_mask(aln_mat, calls):
-    """(mask, gene notes, isoform notes) for a set of genotype calls.
+    """(allowed, gene notes, isoform notes) for genotype calls given as (gene ids, diplotype strings) in file
+    order, or as a {gene: call} dict.
 
-    mask is (H x L) with 1 where the haplotype is one of the two letters called for the locus's gene
-    (gbrs/emase_utils.py:245-269); the notes map every gene / isoform name to its call, None when
-    the gene has none (those print as `None` in the reports' notes column, as in the reference)."""
+    allowed is uint32[L] with bit h set where haplotype h is one of the letters called for a gene the locus
+    belongs to - the (H x L) 0/1 `gtmask` of gbrs/emase_utils.py:249-268 packed per locus; a gene listed twice
+    contributes both lines, a locus in no called gene keeps nothing.  The notes are CallNotes over aln_mat.gname /
+    aln_mat.lname: the call of the gene's (isoform's) last line, None without one."""
+    from operator import itemgetter
+    genes, texts = (list(calls.keys()), list(calls.values())) if isinstance(calls, dict) else calls
+    L, G = aln_mat.num_loci, len(aln_mat.gname)
+    n = len(genes)
+    text = np.asarray(texts, dtype='U') if n else np.zeros(0, dtype='U1')
+    width = text.dtype.itemsize // 4
+    note_type = f'U{max(width, 4)}'
+    gene_text, iso_text = np.full(G, 'None', dtype=note_type), np.full(L, 'None', dtype=note_type)
+    gene_has, iso_has = np.zeros(G, dtype=bool), np.zeros(L, dtype=bool)
+    allowed = np.zeros(L, dtype=np.uint32)
+    gnotes, tnotes = CallNotes(aln_mat.gname, gene_text, gene_has), CallNotes(aln_mat.lname, iso_text, iso_has)
+    if n == 0:
+        return allowed, gnotes, tnotes
+    gene_index = {name: k for k, name in enumerate(aln_mat.gname.tolist())}
+    found = itemgetter(*genes)(gene_index)                       # KeyError on a gene the group file does not list
+    gidx = np.asarray(found if n > 1 else (found,), dtype=np.int64)
+    # letters -> haplotype bits, through the distinct characters of the calls
+    code = np.frombuffer(text.tobytes(), dtype=np.uint32).reshape(n, width)
     hap_index = {name: k for k, name in enumerate(aln_mat.hname)}
-    gene_index = {name: k for k, name in enumerate(aln_mat.gname)}
-    mask = np.zeros((aln_mat.num_haplotypes, aln_mat.num_loci))
-    gene_notes = {str(g): None for g in aln_mat.gname}
-    isoform_notes = {t: None for t in aln_mat.lname}
-    for gene, call in calls.items():
-        members = np.asarray(aln_mat.groups[gene_index[gene]], dtype=np.int64)
-        letters = [hap_index[ch] for ch in call]
-        mask[np.ix_(letters, members)] = 1.0
-        gene_notes[gene] = call
-        for t in members:
-            isoform_notes[aln_mat.lname[t]] = call
-    return mask, gene_notes, isoform_notes
+    uniq, inv = np.unique(code, return_inverse=True)
+    bit_of = np.array([np.uint32(1) << np.uint32(hap_index[chr(cp)]) if cp else np.uint32(0)     # KeyError on an
+                       for cp in uniq.tolist()], dtype=np.uint32)                                # unknown letter
+    bits = np.bitwise_or.reduce(bit_of[inv].reshape(n, width), axis=1)
+    # every line marks the loci of its gene
+    ptr, mem = aln_mat.group_csr()
+    start, size = ptr[gidx], ptr[gidx + 1] - ptr[gidx]
+    line_of = np.repeat(np.arange(n, dtype=np.int64), size)
+    first = np.zeros(n, dtype=np.int64)
+    np.cumsum(size[:-1], out=first[1:])
+    loci = mem[start[line_of] + (np.arange(len(line_of), dtype=np.int64) - first[line_of])]
+    np.bitwise_or.at(allowed, loci, bits[line_of])
+    gene_text[gidx] = text                                       # a repeated index keeps the last line's call
+    gene_has[gidx] = True
+    iso_text[loci] = text[line_of]
+    iso_has[loci] = True
+    return allowed, gnotes, tnotes
 
 
 def _write_expression_reports(em, outbase, with_groups, isoform_notes, gene_notes, report_posterior):
@@ -100,7 +181,8 @@ def quantify(alignment_file: str, group_file: str = None, length_file: str = Non
              genotype_file: str = None, outbase: str = 'gbrs.quantified', multiread_model: int = 4,
              pseudocount: float = 0.0, max_iters: int = 999, tolerance: float = 0.0001,
              report_alignment_counts: bool = False, report_posterior: bool = False,
-             device: int = 0, merge_identical_rows: bool = False, stage_times: dict = None) -> None:
+             device: int = 0, merge_identical_rows: bool = False, stage_times: dict = None,
+             one_shot: bool = False) -> None:
     """Quantify allele-specific expression from an EMASE alignment file.  `stage_times` (optional
     dict) receives the wall-clock seconds of the stages: load, mask, em_setup, em_run, reports,
     alignment_counts."""
@@ -144,14 +226,14 @@ def quantify(alignment_file: str, group_file: str = None, length_file: str = Non
     else:
         outbase = f'{outbase}.diploid'
         logger.info(f'Loading and processing genotype calls from: {genotype_file}')
-        mask, gene_notes, isoform_notes = diplotype_mask(aln_mat, read_genotype_calls(genotype_file))
-        aln_mat.mask_haplotype_loci(mask)
+        allowed, gene_notes, isoform_notes = diplotype_mask(aln_mat, read_genotype_table(genotype_file))
+        aln_mat.set_haplotype_mask(allowed)        # applied on the device when the EM handle is built
     logger.debug(f'Outbase now: {outbase}')
     marks['mask'] = clock() - t0
 
     logger.info('Running EMASE')
     t0 = clock()
-    em = EMfactory(aln_mat, device=device, merge_identical_rows=merge_identical_rows)
+    em = EMfactory(aln_mat, device=device, merge_identical_rows=merge_identical_rows, one_shot=one_shot)
     if lengths_pending:
         em.set_target_lengths(lengths_pending[0].result())
         em.prepare(pseudocount=pseudocount)
@@ -172,9 +254,11 @@ def quantify(alignment_file: str, group_file: str = None, length_file: str = Non
     if report_alignment_counts:
         t0 = clock()
         from .counts import report_alignment_counts as write_counts
-        # the EM above may have masked the tensor (-G); the reference reloads the file for this report
-        # (gbrs/emase_utils.py:318-331), so the counts are always those of the unmasked alignments
-        fresh = load_alignment(alignment_file, grpfile=group_file) if genotype_file is not None else aln_mat
+        # the reference reloads the file for this report (gbrs/emase_utils.py:318-331), so the counts are always those
+        # of the unmasked alignments; a `-G` mask here is a note for the device and leaves the host arrays as loaded -
+        # unless something (--report-posterior) has carried it out on them since
+        fresh = aln_mat if genotype_file is None or aln_mat.haplotype_mask is not None else \
+            load_alignment(alignment_file, grpfile=group_file)
         for level, grp_wise in (('isoform', False), ('gene', True)):
             if grp_wise and group_file is None:
                 continue

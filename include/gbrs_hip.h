@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GBRS_ABI_VERSION 2
+#define GBRS_ABI_VERSION 3
 
 enum gbrs_status {
     GBRS_OK = 0,
@@ -91,6 +91,12 @@ typedef struct gbrs_em gbrs_em_t;
 /* This handle is one of two locus ranges of one sample that run side by side on the device (the two engines of
  * a rank in gbrs_amd/dist.py PipelinedShardedEM): the layout sizes its tiles for the two together. */
 #define GBRS_EM_SIDE_BY_SIDE 128u
+/* The process builds this one handle and exits (the `gbrs quantify` command): the multi-gigabyte temporaries of the
+ * layout build and the uploaded CSC copy stay allocated until gbrs_em_destroy instead of being freed when create
+ * returns (on some hosts a hipMalloc that follows a large hipFree stalls for 0.1-0.2 s; the whole create is ~45 ms
+ * shorter).  gbrs_em_info.retained_build_bytes reports what is held.  Without the flag create frees them in one pass
+ * before it returns, so several live handles cost their layouts only. */
+#define GBRS_EM_ONE_SHOT 256u
 
 /*
  * Replaces: AlignmentPropertyMatrix(h5file=...) as consumed by EMfactory.__init__
@@ -116,6 +122,25 @@ int gbrs_em_create_device(uint64_t num_rows, uint32_t num_loci, uint32_t num_hap
                           const uint32_t *const *indptr, const uint32_t *const *indices,
                           const double *count, const double *eff_len,
                           int device, uint32_t flags, gbrs_em_t **out);
+
+/*
+ * The same with the `-G` genotype mask of `gbrs quantify` applied on the device.  Replaces
+ * gbrs/emase_utils.py:240-273: `aln_mat.multiply(gtmask, axis=2)` followed by `eliminate_zeros()` per haplotype,
+ * i.e. every stored entry (h, l, r) whose haplotype h is not one of the two called for the gene of locus l leaves
+ * the structure before EMfactory sees it (rows left without entries drop out, as they do there).
+ *   allowed  HOST uint32[L] in both variants, bit h set = entries of (haplotype h, locus l) stay; NULL = no mask.
+ * The mask selects whole CSC columns, so the library uploads the arrays as they are and moves the surviving
+ * columns together on the device; no host pass over the entries.  gbrs_em_info.num_entries is the masked count;
+ * values given to gbrs_em_set_initial_values still line up with the indices arrays as passed here.
+ */
+int gbrs_em_create_masked(uint64_t num_rows, uint32_t num_loci, uint32_t num_haps,
+                          const uint32_t *const *indptr, const uint32_t *const *indices,
+                          const double *count, const double *eff_len, const uint32_t *allowed,
+                          int device, uint32_t flags, gbrs_em_t **out);
+int gbrs_em_create_masked_device(uint64_t num_rows, uint32_t num_loci, uint32_t num_haps,
+                                 const uint32_t *const *indptr, const uint32_t *const *indices,
+                                 const double *count, const double *eff_len, const uint32_t *allowed,
+                                 int device, uint32_t flags, gbrs_em_t **out);
 
 /* Stored alignment values (an EMASE file saved with incidence_only = False, or a legacy COO file:
  * emase/Sparse3DMatrix.py:84-88, :93-99): values[h] double[nnz_h], aligned with indices[h] as given to
@@ -196,6 +221,8 @@ typedef struct gbrs_em_info {
     uint64_t num_light_loci;    /* layout 1: loci with 2..16 slots (summed in place)        */
     uint64_t estep_bytes;       /* bytes the E-step kernel itself moves per launch: word stream, tile
                                    headers, dictionary, theta gather, slot stores [, row weights]  */
+    uint64_t retained_build_bytes; /* device bytes of build temporaries the handle still holds
+                                   (GBRS_EM_ONE_SHOT; 0 otherwise)                                */
 } gbrs_em_info_t;
 int gbrs_em_info(gbrs_em_t *em, gbrs_em_info_t *info);
 

@@ -149,7 +149,7 @@ class EMOracle:
             kept_per_col = np.where(keep_col, width, 0)
             self.indices[h] = self.indices[h][per_entry]
             self.indptr[h] = np.concatenate(([0], np.cumsum(kept_per_col))).astype(np.int64)
-            self.values[h] = np.ones(len(self.indices[h]), dtype=np.float64)
+            self.values[h] = self.values[h][per_entry]      # kept entries are multiplied by 1.0: stored values survive
 
 
 def tpm_report_values(theta):

@@ -481,6 +481,11 @@ def main():
             hmm_case("h4_do_full", 4, [50, 21], 38, False, style="do")
         if only == "hmm_do":
             return
+        if only in (None, "em_mask_values"):
+            # stored values under a `-G` mask: multiply(gtmask, axis=2) keeps the surviving entries' values
+            em_case("h8_mask_values", 1600, 8, 70, 24,   True,  True,  0.0, True,  1e-4, 999, with_values=True)
+        if only == "em_mask_values":
+            return
         #        name            R     H  L    seed  count  len    pc   mask   tol   max
         em_case("h2_plain",      1500, 2, 60,  11,   False, False, 0.0, False, 1e-4, 999)
         em_case("h2_len",        1500, 2, 60,  12,   False, True,  0.0, False, 1e-4, 999)

@@ -125,6 +125,71 @@ def test_c2_full_size_properties(c2_sample):
     em.close()
 
 
+def test_c2_full_size_genotype_mask_on_device(c2_sample):
+    """`gbrs quantify -G` at BASELINE configs[1] size (gbrs/emase_utils.py:240-273): every gene keeps the two
+    haplotypes of a called diplotype, gbrs_em_create_masked_device drops the other columns on the device.  Checked
+    against the same restriction carried out with torch on the arrays and fed to the plain CSC kernels (a different
+    masking code, layout and summation order), and through conservation of the surviving reads' mass."""
+    import torch
+    from gbrs_amd import _lib
+    prob = c2_sample
+    R, L, H = prob["R"], prob["L"], prob["H"]
+    rng = np.random.default_rng(5)
+    starts = prob["gene_starts"]
+    sizes = np.diff(np.concatenate((starts, [L])))
+    pair = rng.integers(0, H, size=(len(starts), 2))
+    gene_bits = ((1 << pair[:, 0]) | (1 << pair[:, 1])).astype(np.uint32)
+    allowed = np.repeat(gene_bits, sizes)
+    assert allowed.shape == (L,)
+    # the reference's order of operations, with torch: entries of dropped columns leave the arrays
+    alive = torch.zeros(R, dtype=torch.bool, device="cuda:0")
+    m_indptr, m_indices, n_kept = [], [], 0
+    for h in range(H):
+        keep_col = torch.from_numpy(((allowed >> h) & 1).astype(bool)).to("cuda:0")
+        width = (prob["indptr"][h][1:] - prob["indptr"][h][:-1]).to(torch.int64)
+        keep = torch.repeat_interleave(keep_col, width)
+        idx = prob["indices"][h][keep].contiguous()
+        alive[idx.to(torch.int64)] = True
+        m_indices.append(idx)
+        ptr = torch.zeros(L + 1, dtype=torch.int64, device="cuda:0")
+        ptr[1:] = torch.cumsum(torch.where(keep_col, width, torch.zeros_like(width)), 0)
+        m_indptr.append(ptr.to(torch.int32))
+        n_kept += int(idx.numel())
+        del keep, width
+    survivors = int(alive.sum().item())
+    assert 0 < survivors < R and n_kept < prob["N"] // 2
+    from gbrs_amd.engine import EmEngine
+    host_masked = EmEngine.from_device(R, L, H, [t.data_ptr() for t in m_indptr], [t.data_ptr() for t in m_indices],
+                                       None, prob["eff_len"].data_ptr(), device=0, flags=_lib.GBRS_EM_LAYOUT_CSC)
+    host_masked.prepare(0.0)
+    ref0 = host_masked.theta()
+    host_masked.step(3)
+    ref3, refc = host_masked.theta(), host_masked.expected_counts()
+    host_masked.close()
+    del m_indptr, m_indices, alive
+    torch.cuda.empty_cache()
+
+    eng = EmEngine.from_device(R, L, H, [t.data_ptr() for t in prob["indptr"]], [t.data_ptr() for t in prob["indices"]],
+                               None, prob["eff_len"].data_ptr(), device=0, allowed=allowed)
+    inf = eng.info()
+    assert inf.layout == 1 and inf.num_entries == n_kept and inf.num_device_rows == survivors
+    assert inf.retained_build_bytes == 0
+    eng.prepare(0.0)
+    th0 = eng.theta()
+    close(th0, ref0)
+    hap_kept = ((allowed[None, :] >> np.arange(H, dtype=np.uint32)[:, None]) & 1).astype(bool)
+    assert not th0[~hap_kept].any()                         # a masked (haplotype, locus) never gets abundance
+    eng.step(3)
+    close(eng.theta(), ref3)
+    close(eng.expected_counts(), refc)
+    assert abs(eng.expected_counts().sum() - survivors) <= 1e-9 * survivors
+    eng.prepare(0.0)
+    n_it, hist = eng.run(model=4, tol=1e-4, max_iters=999)
+    assert 1 < n_it < 999 and hist[-1] <= 100.0
+    assert abs(eng.expected_counts().sum() - survivors) <= 1e-9 * survivors
+    eng.close()
+
+
 def test_c2_full_size_deterministic_mode(c2_sample):
     """40M reads: two deterministic-mode runs are bit-identical, agree with the default path to 1e-9 and stop
     at the same iteration."""

@@ -20,7 +20,16 @@ LAYOUTS = {"tiles": dict(), "tiles_merged": dict(merge_identical_rows=True), "cs
            "tiles_deterministic_merged": dict(deterministic=True, merge_identical_rows=True)}
 
 
-def make_factory(g, layout="tiles"):
+def pack_mask(gtmask):
+    """(H x L) 0/1 mask -> uint32[L] with bit h set where gtmask[h, l] != 0 (the `allowed` argument of
+    gbrs_em_create_masked)."""
+    H = gtmask.shape[0]
+    return ((gtmask != 0).astype(np.uint32) << np.arange(H, dtype=np.uint32)[:, None]).sum(axis=0).astype(np.uint32)
+
+
+def make_factory(g, layout="tiles", mask_on="device"):
+    """mask_on: where a golden's `-G` mask is carried out - "device" (gbrs_em_create_masked, what `gbrs quantify -G`
+    does) or "host" (the container edits its arrays first, the reference's order of operations)."""
     from gbrs_amd.alignment import AlignmentPropertyMatrix
     from gbrs_amd.em import EMfactory
     R, L, H, indptr, indices, count, eff_len, groups, gtmask = em_case_inputs(g)
@@ -31,7 +40,10 @@ def make_factory(g, layout="tiles"):
     apm.gname = np.array([f"G{i:07d}" for i in range(len(groups))])
     apm.num_groups = len(groups)
     if gtmask is not None:
-        apm.mask_haplotype_loci(gtmask)
+        if mask_on == "device":
+            apm.set_haplotype_mask(pack_mask(gtmask))
+        else:
+            apm.mask_haplotype_loci(gtmask)
     em = EMfactory(apm, **LAYOUTS[layout])
     em.target_lengths = eff_len
     return em
@@ -70,6 +82,93 @@ def test_em_matches_reference_golden(path, layout):
     close(em.get_allelic_expression(at_group_level=True), g["gene_theta"])
     close(em._group_sums(1), g["gene_counts"])
     em.close()
+
+
+@pytest.mark.parametrize("layout", ["tiles", "csc", "tiles_deterministic_merged"])
+@pytest.mark.parametrize("case", ["h8_mask", "h8_mask_count"])
+def test_genotype_mask_on_host_and_on_device_agree(case, layout):
+    """gbrs_em_create_masked drops the masked columns on the device; the container can also carry the mask out on
+    its arrays before create (gbrs/emase_utils.py:271-273).  Same structure either way: same entry count, same
+    reference numbers; bit-identical in the deterministic layout."""
+    g = load_golden([p for p in golden_files("em") if p.endswith(f"em_{case}.npz")][0])
+    res = []
+    for where in ("device", "host"):
+        em = make_factory(g, layout, mask_on=where)
+        em.prepare(pseudocount=float(g["pseudocount"]))
+        n_entries = em.info().num_entries
+        em.run(model=4, tol=float(g["tol"]), max_iters=int(g["max_iters"]), verbose=False)
+        assert em.num_iters == int(g["num_iters"])
+        close(em.allelic_expression, g["theta_final"])
+        res.append((n_entries, em.allelic_expression.copy(), em.expected_read_counts()))
+        em.close()
+    assert res[0][0] == res[1][0] == int((np.concatenate([g[f"indptr{h}"][1:] - g[f"indptr{h}"][:-1]
+                                                           for h in range(int(g["num_haps"]))])
+                                          * (g["gtmask"].ravel() != 0)).sum())
+    if layout == "tiles_deterministic_merged":
+        assert np.array_equal(res[0][1], res[1][1]) and np.array_equal(res[0][2], res[1][2])
+    else:
+        close(res[0][1], res[1][1])
+
+
+def test_genotype_mask_with_stored_values():
+    """A file that stores alignment values (incidence_only=False) under a `-G` mask: the values handed to
+    gbrs_em_set_initial_values line up with the unmasked index arrays and move with the surviving columns."""
+    from gbrs_amd.alignment import AlignmentPropertyMatrix
+    from gbrs_amd.em import EMfactory
+    from oracle.em_oracle import EMOracle
+    path = [p for p in golden_files("em") if "values" in p][0]
+    g = load_golden(path)
+    R, L, H, indptr, indices, count, eff_len, groups, _ = em_case_inputs(g)
+    rng = np.random.default_rng(11)
+    gtmask = (rng.random((H, L)) < 0.6).astype(np.float64)
+    out = []
+    for where in ("device", "host"):
+        apm = AlignmentPropertyMatrix(shape=(L, H, R), indptr=indptr, indices=indices, count=count,
+                                      haplotype_names=[chr(65 + h) for h in range(H)],
+                                      locus_names=[f"T{l:07d}" for l in range(L)], values=em_case_values(g))
+        if where == "device":
+            apm.set_haplotype_mask(pack_mask(gtmask))
+        else:
+            apm.mask_haplotype_loci(gtmask)
+        em = EMfactory(apm)
+        em.target_lengths = eff_len
+        em.prepare(pseudocount=0.0)
+        th0 = em.allelic_expression.copy()
+        em.run(model=4, tol=0.0, max_iters=3, verbose=False)
+        out.append((th0, em.allelic_expression.copy()))
+        em.close()
+    close(out[0][0], out[1][0])
+    close(out[0][1], out[1][1])
+    o = EMOracle(R, L, H, indptr, indices, count, values=em_case_values(g))
+    o.apply_genotype_mask(gtmask)
+    o.prepare(0.0, eff_len)
+    close(out[0][0], o.theta)
+    o.run(tol=0.0, max_iters=3)
+    close(out[0][1], o.theta)
+
+
+def test_masked_create_argument_checks(hip_lib):
+    import ctypes as C
+    from gbrs_amd import _lib
+    from gbrs_amd.engine import EmEngine
+    ip = [np.array([0, 1, 2], dtype=np.uint32)] * 2
+    ix = [np.array([0, 1], dtype=np.uint32)] * 2
+    with pytest.raises(_lib.GbrsHipError, match="names a haplotype"):
+        EmEngine.from_host(2, 2, 2, ip, ix, allowed=np.array([1, 4], dtype=np.uint32))
+    # everything masked away: a handle with no entries; prepare gives zeros
+    e = EmEngine.from_host(2, 2, 2, ip, ix, allowed=np.zeros(2, dtype=np.uint32))
+    assert e.info().num_entries == 0
+    e.prepare(0.0)
+    assert not e.theta().any()
+    e.close()
+    # NULL mask = gbrs_em_create
+    h = C.c_void_p()
+    _lib.check(hip_lib.gbrs_em_create_masked(2, 2, 2, _lib.ptr_table(ip), _lib.ptr_table(ix), None, None, None, 0, 0,
+                                             C.byref(h)))
+    inf = _lib.EmInfo()
+    _lib.check(hip_lib.gbrs_em_info(h, C.byref(inf)))
+    assert inf.num_entries == 4 and inf.retained_build_bytes == 0
+    hip_lib.gbrs_em_destroy(h)
 
 
 def test_em_c1_shape_vs_oracle():

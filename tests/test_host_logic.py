@@ -117,8 +117,14 @@ def test_cli_surface_and_error_swallowing(tmp_path, capsys):
     assert cli.main(["quantify", "-i", str(f)]) == 0
 
 
+def pack_mask(gtmask):
+    """(H x L) 0/1 mask -> uint32[L] with bit h set where gtmask[h, l] != 0."""
+    H = gtmask.shape[0]
+    return ((gtmask != 0).astype(np.uint32) << np.arange(H, dtype=np.uint32)[:, None]).sum(axis=0).astype(np.uint32)
+
+
 def test_genotype_mask_parsing(tmp_path):
-    from gbrs_amd.quantify import diplotype_mask, read_genotype_calls
+    from gbrs_amd.quantify import diplotype_mask, read_genotype_calls, read_genotype_table
     g = golden("h8_mask")
     apm, groups, gtmask, _ = make_apm(g)
     apm.groups = groups
@@ -132,14 +138,63 @@ def test_genotype_mask_parsing(tmp_path):
             code = "".join(apm.hname[h] for h in (hs if len(hs) == 2 else [hs[0], hs[0]]))
             fh.write(f"G{i:07d}\t{code}\n")
     calls = read_genotype_calls(str(gt))
-    m, cg, ct = diplotype_mask(apm, calls)
-    np.testing.assert_array_equal(m, gtmask)
+    table = read_genotype_table(str(gt))
+    assert dict(zip(*table)) == calls and len(table[0]) == len(groups)
+    m, cg, ct = diplotype_mask(apm, table)
+    np.testing.assert_array_equal(m, pack_mask(gtmask))
+    assert m.dtype == np.uint32
     assert cg["G0000000"] is not None and ct[apm.lname[groups[0][0]]] == cg["G0000000"]
     assert len(cg) == len(groups) and len(ct) == apm.num_loci
+    # the pending device mask, carried out on the host, is the reference's multiply + eliminate_zeros
+    from oracle.em_oracle import EMOracle
+    R, L, H, indptr, indices, count, eff_len, _, _ = em_case_inputs(g)
+    o = EMOracle(R, L, H, indptr, indices, count)
+    o.apply_genotype_mask(gtmask)
+    apm.set_haplotype_mask(m)
+    assert apm.nnz == sum(len(i) for i in o.indices) and apm.haplotype_mask is None
+    for h in range(H):
+        np.testing.assert_array_equal(apm.indptr[h], o.indptr[h])
+        np.testing.assert_array_equal(apm.indices[h], o.indices[h])
     # a gene missing from the file keeps the note None, as the reference's dict.fromkeys tables do
     m2, cg2, ct2 = diplotype_mask(apm, {k: v for k, v in calls.items() if k != "G0000001"})
     assert cg2["G0000001"] is None and ct2[apm.lname[groups[1][0]]] is None
-    assert not m2[:, groups[1]].any()
+    assert not m2[groups[1]].any()
+    # the notes column in one piece is what the per-name look-ups give
+    blob, off = ct2.aligned_blob(apm.lname)
+    assert [blob[off[k]:off[k + 1]].decode() for k in range(apm.num_loci)] == [str(ct2[t]) for t in apm.lname]
+    assert ct2.aligned_blob(list(apm.lname)) is None          # another list object: the writer falls back to look-ups
+
+
+def test_genotype_table_forms(tmp_path):
+    """Lines the one-pass split declines (extra columns, trailing blanks, no final newline) go through the
+    reference's per-line rule; a gene listed twice contributes both lines to the mask (gbrs/emase_utils.py:262-268:
+    the mask accumulates, the notes keep the later call)."""
+    from gbrs_amd.quantify import diplotype_mask, read_genotype_table
+    g = golden("h8_mask")
+    apm, groups, gtmask, _ = make_apm(g)
+    apm.groups = groups
+    apm.gname = np.array([f"G{i:07d}" for i in range(len(groups))])
+    apm.num_groups = len(groups)
+    plain = tmp_path / "plain.tsv"
+    plain.write_text("#Gene_ID\tDiplotype\n#second comment\nG0000000\tAB\nG0000001\tCC\nG0000000\tGH")
+    assert read_genotype_table(str(plain)) == (["G0000000", "G0000001", "G0000000"], ["AB", "CC", "GH"])
+    odd = tmp_path / "odd.tsv"
+    odd.write_text("#Gene_ID\tDiplotype\nG0000000\tAB\textra\nG0000001\tCC  \n#G0000002\tDD\nG0000000\tGH\n")
+    genes, calls = read_genotype_table(str(odd))
+    assert genes == ["G0000000", "G0000001", "#G0000002", "G0000000"] and calls == ["AB", "CC", "DD", "GH"]
+    allowed, cg, ct = diplotype_mask(apm, read_genotype_table(str(plain)))
+    assert set(allowed[groups[0]].tolist()) == {0b11000011} and set(allowed[groups[1]].tolist()) == {0b100}
+    rest = np.setdiff1d(np.arange(apm.num_loci), np.concatenate([groups[0], groups[1]]))
+    assert not allowed[rest].any()
+    assert cg["G0000000"] == "GH" and ct[apm.lname[groups[0][0]]] == "GH" and cg["G0000002"] is None
+    with pytest.raises(KeyError):
+        diplotype_mask(apm, (["G0000000"], ["AZ"]))            # unknown haplotype letter
+    with pytest.raises(KeyError):
+        diplotype_mask(apm, (["nope"], ["AB"]))                # gene the group file does not list
+    bad = tmp_path / "bad.tsv"
+    bad.write_text("G0000000\n")
+    with pytest.raises(ValueError):
+        read_genotype_table(str(bad))
 
 
 def test_read_gene_tpm_native_and_fallback_agree(tmp_path):
