@@ -49,8 +49,15 @@ def parse():
     ap.add_argument("--no-merged-line", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="skip the post-run tiles-vs-CSC theta comparison")
     ap.add_argument("--from-host", action="store_true", help="also time gbrs_em_create from host (numpy) arrays: PCIe copy + layout build")
-    ap.add_argument("--cpu-rows", type=int, default=2_000_000)
+    ap.add_argument("--cpu-rows", type=int, default=2_000_000, help="rows of the one-core baseline when it cannot run at full size")
     ap.add_argument("--cpu-iters", type=int, default=60, help="oracle iterations timed for cpu_baseline (stops at 25 s)")
+    ap.add_argument("--cpu-full", default="auto", choices=["auto", "yes", "no"],
+                    help="one-core baselines on the whole 40M-read sample (auto: when the host has >= 128 GB of memory; "
+                         "SURVEY 8d allows the row subsample only on smaller hosts)")
+    ap.add_argument("--variant", default="survey", choices=["survey", "multi_isoform"],
+                    help="read generator of the timed workload: SURVEY 8d's (the headline) or the multi-isoform one "
+                         "(gbrs_amd/synth_torch.py); the default run reports the second as `multi_isoform_variant`")
+    ap.add_argument("--no-multi-isoform-line", action="store_true")
     ap.add_argument("--hmm-samples", type=int, default=1)
     ap.add_argument("--hmm-batch", type=int, default=64, help="second HMM measurement with this many samples in one launch (0 = skip)")
     ap.add_argument("--hmm-batch-large", type=int, default=256,
@@ -75,14 +82,20 @@ class DevArray:
         self.__cuda_array_interface__ = dict(shape=(n,), typestr="<f8", data=(ptr, False), version=2)
 
 
-def em_bench(args, rank, world, torch, dist):
+def em_bench(args, rank, world, torch, dist, keep_host=False):
     from gbrs_amd import _lib, synth, synth_torch
     from gbrs_amd.engine import EmEngine
     dev = f"cuda:{torch.cuda.current_device()}"
     t0 = time.perf_counter()
     prob = synth_torch.make_em_problem_device(args.rows, args.haps, args.loci, synth.SEED_BASE_EM + 1, dev,
-                                              row_seed=synth.SEED_BASE_EM + 1 + rank)
+                                              row_seed=synth.SEED_BASE_EM + 1 + rank, variant=args.variant)
     t_gen = time.perf_counter() - t0
+    host = None
+    if keep_host:                 # the same reads for the one-core oracle (cpu_baseline at full size)
+        import numpy as np
+        host = dict(indptr=[t.cpu().numpy().view(np.uint32) for t in prob["indptr"]],
+                    indices=[t.cpu().numpy().view(np.uint32) for t in prob["indices"]],
+                    eff_len=prob["eff_len"].cpu().numpy())
     t0 = time.perf_counter()
     eng = EmEngine.from_device(
         prob["R"], prob["L"], prob["H"], [t.data_ptr() for t in prob["indptr"]],
@@ -143,7 +156,8 @@ def em_bench(args, rank, world, torch, dist):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     inf = eng.info()
-    res = dict(dt=dt, t_gen=t_gen, t_create=t_create, t_create_host=t_host, N=n_entries, info=inf)
+    res = dict(dt=dt, t_gen=t_gen, t_create=t_create, t_create_host=t_host, N=n_entries, info=inf, host=host,
+               mean_loci_per_read=prob.get("mean_loci_per_read"))
     # ---- outside the timed region: is the state the timed steps produced a valid EM state? ----------
     res["check"] = em_state_check(torch, [eng.expected_counts()], float(args.rows) * world)
     if world == 1 and not args.no_check:
@@ -364,11 +378,45 @@ def em_state_check(torch, counts_list, expect_total):
     return out
 
 
-def em_cpu_baseline(args):
-    """The numpy oracle (op-for-op restatement of the reference) on one core, bounded sample."""
+def host_memory_gb():
+    try:
+        return os.sysconf("SC_PAGE_SIZE") * os.sysconf("SC_PHYS_PAGES") / 2.0**30
+    except (ValueError, OSError):
+        return 0.0
+
+
+def cpu_full_size(args):
+    return args.cpu_full == "yes" or (args.cpu_full == "auto" and host_memory_gb() >= 128.0)
+
+
+def em_cpu_baseline(args, host=None):
+    """The numpy oracle (op-for-op restatement of the reference) on one core: on the whole workload - the reads the
+    timed region processed, copied back from HBM - when the host has the memory, else on a row subsample."""
     import numpy as np
     from gbrs_amd import synth
     from oracle.em_oracle import EMOracle
+    if host is not None:
+        R, L, H = args.rows, args.loci, args.haps
+        t0 = time.perf_counter()
+        o = EMOracle(R, L, H, host["indptr"], host["indices"], None)
+        t_build = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        o.prepare(0.0, host["eff_len"])
+        t_prep = time.perf_counter() - t0
+        nnz = int(sum(len(i) for i in host["indices"]))
+        o.em_step()
+        t0 = time.perf_counter()
+        n = 0
+        while n < 3 or (n < args.cpu_iters and time.perf_counter() - t0 < 12.0):
+            o.em_step()
+            n += 1
+        dt = (time.perf_counter() - t0) / n
+        return dict(value=1.0 / dt, unit="iters/s", cores=1, kind="port", full_size=True,
+                    prepare_s=t_prep, ms_per_iter=dt * 1e3,
+                    sample=f"numpy oracle on the whole workload: the R={R} reads (N={nnz} entries) of the timed region "
+                           f"copied back from HBM, prepare {t_prep:.1f} s, then {n} iterations after one untimed, "
+                           f"{dt * 1e3:.0f} ms/iter; nothing scaled; host has {os.cpu_count()} cores and "
+                           f"{host_memory_gb():.0f} GB, reference is single-threaded")
     R = min(args.cpu_rows, args.rows)
     inc = synth.make_em_problem(R=R, H=args.haps, L=args.loci, seed=synth.SEED_BASE_EM + 1)
     o = EMOracle(inc.num_rows, inc.num_loci, inc.num_haps, inc.indptr, inc.indices, None)
@@ -381,10 +429,11 @@ def em_cpu_baseline(args):
         n += 1
     dt = (time.perf_counter() - t0) / max(n, 1)
     scale = args.rows / R
-    return dict(value=1.0 / (dt * scale), unit="iters/s", cores=1, kind="port",
+    return dict(value=1.0 / (dt * scale), unit="iters/s", cores=1, kind="port", full_size=False,
                 sample=f"numpy oracle, {n} iterations at R={R} rows (N={inc.nnz} entries), "
                        f"{dt * 1e3:.1f} ms/iter measured, scaled x{scale:g} linearly in rows to the "
-                       f"{args.rows}-row workload; host has {os.cpu_count()} cores, reference is single-threaded")
+                       f"{args.rows}-row workload (host memory {host_memory_gb():.0f} GB < 128 GB: SURVEY 8d's subsample "
+                       f"rule); host has {os.cpu_count()} cores, reference is single-threaded")
 
 
 def hmm_bench(args, torch, ns=None, with_cpu=True):
@@ -508,6 +557,11 @@ def self_launch(args):
         print(f"[bench] expected one JSON line with n_gpus={args.gpus}, got {[r.get('n_gpus') for r in recs]}",
               file=sys.stderr, flush=True)
         raise SystemExit(3)
+    if args.backend == "nccl" and recs[0].get("rccl_ranks") != args.gpus:
+        # a run that fell back to fewer RCCL ranks than GPUs asked for is not a scaling measurement
+        print(f"[bench] --gpus {args.gpus} over RCCL but the line says rccl_ranks={recs[0].get('rccl_ranks')}",
+              file=sys.stderr, flush=True)
+        raise SystemExit(4)
     raise SystemExit(0)
 
 
@@ -521,7 +575,8 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     e2e = None
-    if world == 1 and not args.no_e2e and not args.merge and args.rows == 40_000_000 and args.haps == 8:
+    if world == 1 and not args.no_e2e and not args.merge and args.rows == 40_000_000 and args.haps == 8 \
+            and args.variant == "survey":
         # End-to-end `gbrs quantify` + `gbrs reconstruct` (file in -> reports out) as fresh child processes,
         # measured BEFORE this process opens the GPU: a second process holding a device context slows the
         # large allocations of the measured one.  Outside the timed EM region; its own object in the line.
@@ -534,7 +589,7 @@ def main():
         import e2e_bench
         try:
             e2e = e2e_bench.measure(args.rows, args.haps, args.loci, args.e2e_format, args.cpu_rows, repeats=3,
-                                    with_cpu=not args.no_cpu_baseline)
+                                    with_cpu=not args.no_cpu_baseline, cpu_full=args.cpu_full)
         except Exception as ex:                         # noqa: BLE001 - reported in the line, never hidden
             e2e = {"error": f"{type(ex).__name__}: {ex}"}
     import torch
@@ -586,8 +641,9 @@ def main():
             torch.cuda.empty_cache()
             path_note = f"two-engine setup declined on some rank (this rank: {err}); one engine per GPU"
             print(f"[bench] rank {rank}: {path_note}", file=sys.stderr, flush=True)
+    want_full_cpu = rank == 0 and world == 1 and not args.no_cpu_baseline and cpu_full_size(args)
     if em is None:
-        em = em_bench(args, rank, world, torch, dist)
+        em = em_bench(args, rank, world, torch, dist, keep_host=want_full_cpu)
     inf = em["info"]
     infos = em.get("infos", [inf])
     ms_per_step = em["dt"] / args.steps * 1e3
@@ -609,7 +665,8 @@ def main():
         "dtype": "f64", "data": "synthetic",
         "path": path, "rccl_ranks": world if ((world > 1 or args.rccl_selftest) and args.backend == "nccl") else 0,
         "backend": args.backend if world > 1 else None,
-        "config": {"workload": f"configs[1]: single DO sample, R={args.rows} reads x H={args.haps} x "
+        "config": {"workload": ("" if args.variant == "survey" else f"[{args.variant} reads, not the headline] ") +
+                               f"configs[1]: single DO sample, R={args.rows} reads x H={args.haps} x "
                                f"L={args.loci} isoforms, N={em['N']} alignment entries, quantify Model 4, "
                                f"tol=0 fixed iterations" + (", rows sharded one 40M-read shard per GPU + "
                                "RCCL all-reduce of the H*L vector per iteration" if world > 1 else "")
@@ -673,7 +730,7 @@ def main():
         pass
     if rank == 0:
         if not args.no_cpu_baseline:
-            line["cpu_baseline"] = em_cpu_baseline(args)
+            line["cpu_baseline"] = em_cpu_baseline(args, em.pop("host", None))
             line["speedup_vs_cpu"] = (value / world) / line["cpu_baseline"]["value"]
         if not args.merge and not args.no_merged_line and world == 1:
             import copy
@@ -688,6 +745,32 @@ def main():
                 "estep_kernel_ms": m["estep_ms"], "device_rows": int(m["info"].num_device_rows),
                 "device_words": int(m["info"].num_device_words), "layout_bytes": int(m["info"].bytes_per_iter),
                 "state_check": m.get("check")}
+        if not args.merge and not args.no_multi_isoform_line and world == 1 and args.variant == "survey":
+            import copy
+            a3 = copy.copy(args)
+            a3.variant = "multi_isoform"
+            v = em_bench(a3, rank, world, torch, dist)
+            vi = v["info"]
+            v_estep_s = v["estep_ms"] * 1e-3
+            v_priced = min(int(vi.algorithmic_bytes), int(vi.estep_bytes))
+            line["multi_isoform_variant"] = {
+                "note": "second EM workload, not the headline: a read aligns to 1 + Poisson(2) isoforms of its gene "
+                        "(capped at the gene's size) and its haplotype mask differs from locus to locus (each "
+                        "(locus, haplotype) alignment dropped with p = 0.1): gbrs_amd/synth_torch.py "
+                        "make_multi_isoform_device; same sample model, R, H, L as the headline",
+                "value": args.steps / v["dt"], "unit": "iters/s", "ms_per_step": v["dt"] / args.steps * 1e3,
+                "entries": v["N"], "entries_per_read": v["N"] / args.rows,
+                "loci_per_read": v["mean_loci_per_read"],
+                "words_per_read": int(vi.num_device_words) / max(int(vi.num_rows), 1),
+                "device_words": int(vi.num_device_words), "tiles": int(vi.num_tiles), "slots": int(vi.num_slots),
+                "long_rows": int(vi.num_long_rows),
+                "estep_kernel_ms": v["estep_ms"], "estep_bytes": int(vi.estep_bytes),
+                "algorithmic_bytes": int(vi.algorithmic_bytes),
+                "roofline": {"bound": "hbm", "achieved": v_priced / v_estep_s / 1e9 if v_estep_s > 0 else None,
+                             "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                             "frac": v_priced / v_estep_s / 1e9 / HBM_PEAK_GBS if v_estep_s > 0 else None,
+                             "priced_bytes": v_priced, "traffic": None},
+                "time_to_solution": v.get("solve"), "state_check": v.get("check")}
         if not args.no_hmm and world == 1:
             line["hmm"] = hmm_bench(args, torch)
         if e2e is not None:

@@ -23,7 +23,7 @@ EXPORTS = [
     "gbrs_hmm_create", "gbrs_hmm_set_expression", "gbrs_hmm_set_eprob", "gbrs_hmm_run",
     "gbrs_hmm_get", "gbrs_hmm_info", "gbrs_hmm_destroy", "gbrs_interpolate", "gbrs_genoprob_dosage",
     "gbrs_compress_create", "gbrs_compress_get", "gbrs_compress_destroy",
-    "gbrs_format_double", "gbrs_write_locus_table", "gbrs_parse_length_table",
+    "gbrs_format_double", "gbrs_write_locus_table", "gbrs_parse_length_table", "gbrs_parse_genotype_table",
     "gbrs_decode_chunks", "gbrs_inflate_backend", "gbrs_zip_directory", "gbrs_npz_stack", "gbrs_zip_read_members", "gbrs_parse_number_table",
 ]
 
@@ -157,6 +157,8 @@ def _host_signatures():
         "gbrs_zip_read_members": [vp, u64, i64, vp, vp, vp, vp, vp, i32],
         "gbrs_parse_number_table": [C.c_char_p, i64, i64, i32, vp],
         "gbrs_parse_length_table": [C.c_char_p, i64, C.c_char_p, vp, i64, C.c_char_p, vp, i32, dbl, vp],
+        "gbrs_parse_genotype_table": [C.c_char_p, i64, C.c_char_p, vp, i64, C.c_char_p, vp, i32, vp, vp, i32, vp,
+                                      C.POINTER(i64)],
         "gbrs_write_locus_table": [C.c_char_p, C.c_char_p, vp, i64, i32, i64, i64, vp, C.c_char_p, vp, C.c_char_p, vp, vp],
     }
 

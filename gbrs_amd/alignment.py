@@ -132,6 +132,10 @@ class AlignmentPropertyMatrix:
                 self.groups.append([self.lid[t] for t in item[1:]])
         self.gname = np.array(self.gname)
         self.num_groups = len(self.gname)
+        # while the caller's thread still decodes the index arrays: the reports and `-G` need both
+        self.group_csr()
+        from .em import _blob_cached
+        _blob_cached(self.gname)
 
     def group_csr(self):
         """(group_ptr int64[G+1], members int64[...]) with members ascending and unique per group:

@@ -600,4 +600,66 @@ int gbrs_parse_length_table(const char *text, int64_t text_len, const char *name
     return 0;
 }
 
+// The call table of `gbrs quantify -G` (gbrs/emase_utils.py:262-268: `#` lines that open the file skipped, then
+// `<gene> TAB <call>[ TAB ...]` lines; every character of the call names a haplotype).  Per gene: the OR of the
+// haplotype bits of all its lines (the mask accumulates), and the call / index of its last line (what the notes
+// keep).  Returns 0 when every line was plain, 1 when some line needs the interpreter's own parsing and error
+// reporting (unknown gene or letter, a line without a second field, bytes outside printable ASCII, a call longer
+// than call_width): the caller then takes the line-by-line path, which raises what the reference raises.
+int gbrs_parse_genotype_table(const char *text, int64_t text_len, const char *gene_names, const int64_t *gene_off,
+                              int64_t n_genes, const char *haps, const int64_t *hap_off, int32_t n_haps,
+                              uint32_t *gene_bits, char *gene_call, int32_t call_width, int32_t *gene_last_line,
+                              int64_t *n_lines) {
+    using gbrs::fail;
+    if (!text || !gene_names || !gene_off || !haps || !hap_off || !gene_bits || !gene_call || !gene_last_line ||
+        n_genes < 1 || n_haps < 1 || n_haps > 32 || text_len < 0 || call_width < 1)
+        return fail(GBRS_ERR_INVALID, "bad argument");
+    int bit_of[128];
+    for (int &b : bit_of) b = -1;
+    for (int h = 0; h < n_haps; ++h)
+        if (hap_off[h + 1] - hap_off[h] == 1 && (unsigned char)haps[hap_off[h]] < 128)
+            bit_of[(unsigned char)haps[hap_off[h]]] = h;                     // a later duplicate name wins, as in dict(zip())
+    std::unordered_map<std::string_view, int64_t> gene_id;
+    gene_id.reserve((size_t)n_genes * 2);
+    for (int64_t g = 0; g < n_genes; ++g)
+        gene_id[std::string_view(gene_names + gene_off[g], (size_t)(gene_off[g + 1] - gene_off[g]))] = g;
+    const char *p = text, *end = text + text_len;
+    while (p < end && *p == '#') {                                            // dropwhile(is_comment)
+        const char *eol = (const char *)std::memchr(p, '\n', (size_t)(end - p));
+        p = eol ? eol + 1 : end;
+    }
+    int64_t line = 0;
+    while (p < end) {
+        const char *eol = (const char *)std::memchr(p, '\n', (size_t)(end - p));
+        const char *next = eol ? eol + 1 : end;
+        const char *le = eol ? eol : end;
+        for (const char *q = p; q < le; ++q)
+            if (((unsigned char)*q < 0x20 && *q != '\t' && *q != '\r') || (unsigned char)*q >= 0x7f) return 1;
+        while (le > p && (le[-1] == '\r' || le[-1] == ' ' || le[-1] == '\t')) --le;      // str.rstrip()
+        const char *tab = (const char *)std::memchr(p, '\t', (size_t)(le - p));
+        if (!tab) return 1;
+        const char *call_end = (const char *)std::memchr(tab + 1, '\t', (size_t)(le - tab - 1));
+        if (!call_end) call_end = le;
+        const auto it = gene_id.find(std::string_view(p, (size_t)(tab - p)));
+        if (it == gene_id.end()) return 1;
+        const int64_t g = it->second;
+        const int64_t clen = call_end - (tab + 1);
+        if (clen > call_width) return 1;
+        uint32_t bits = 0;
+        for (const char *q = tab + 1; q < call_end; ++q) {
+            const int b = bit_of[(unsigned char)*q];
+            if (b < 0) return 1;
+            bits |= 1u << b;
+        }
+        gene_bits[g] |= bits;
+        std::memset(gene_call + g * call_width, 0, (size_t)call_width);
+        std::memcpy(gene_call + g * call_width, tab + 1, (size_t)clen);
+        gene_last_line[g] = (int32_t)line;
+        ++line;
+        p = next;
+    }
+    if (n_lines) *n_lines = line;
+    return 0;
+}
+
 }  // extern "C"

@@ -281,14 +281,37 @@ _blob_cache = {}
 
 def _blob_cached(names):
     """_blob of a name list, remembered per list object: the isoform (and gene) names are written into
-    two reports each."""
+    two reports each.  A numpy string array (the gene names) is laid out without touching its elements."""
     key = id(names)
     hit = _blob_cache.get(key)
     if hit is None or hit[0] is not names:
+        made = None
+        if isinstance(names, np.ndarray) and names.dtype.kind == 'U' and names.ndim == 1:
+            made = _blob_of_unicode_array(names)
+        if made is None:
+            made = _blob([str(x) for x in names])
         if len(_blob_cache) > 4:
             _blob_cache.clear()
-        hit = _blob_cache[key] = (names, _blob([str(x) for x in names]))
+        hit = _blob_cache[key] = (names, made)
     return hit[1]
+
+
+def _blob_of_unicode_array(arr):
+    """(bytes, offsets) of an ASCII 'U' array from its code points, None when a name is not plain ASCII (or holds
+    an inner NUL, which the fixed-width storage cannot tell from padding)."""
+    n, width = len(arr), arr.dtype.itemsize // 4
+    if n == 0 or width == 0:
+        return b'', np.zeros(n + 1, dtype=np.int64)
+    code = np.frombuffer(np.ascontiguousarray(arr).tobytes(), dtype=np.uint32).reshape(n, width)
+    if (code > 127).any():
+        return None
+    used = code != 0
+    length = used.sum(axis=1)
+    if (used != (np.arange(width)[None, :] < length[:, None])).any():
+        return None
+    off = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(length, out=off[1:])
+    return code[used].astype(np.uint8).tobytes(), off
 
 
 def write_locus_table(filename, hap_names, row_names, values, reorder='as-is', notes=None, pool=None):
@@ -313,7 +336,7 @@ def write_locus_table(filename, hap_names, row_names, values, reorder='as-is', n
     totals = np.ascontiguousarray(totals.ravel(), dtype=np.float64)
     n_haps, n_rows = values.shape
     item = values.itemsize
-    names = row_names if isinstance(row_names, list) else [str(x) for x in row_names]
+    names = row_names if isinstance(row_names, (list, np.ndarray)) else [str(x) for x in row_names]
     if len(names) != n_rows:
         raise RuntimeError('The number of names does not match to the matrix shape.')
     name_blob, name_off = _blob_cached(names)

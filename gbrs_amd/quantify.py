@@ -75,7 +75,7 @@ class CallNotes:
 
     def __init__(self, names, text, has_call):
         self.names = names                 # the list / array the table rows are named by
-        self.text = text                   # 'U' array aligned with names: the call, 'None' without one
+        self.text = text                   # 'U' or 'S' array aligned with names: the call, 'None' without one
         self.has_call = has_call           # bool array aligned with names
         self._index = None
 
@@ -83,7 +83,10 @@ class CallNotes:
         if self._index is None:
             self._index = {str(n): k for k, n in enumerate(self.names)}
         k = self._index[str(name)]
-        return str(self.text[k]) if self.has_call[k] else None
+        if not self.has_call[k]:
+            return None
+        v = self.text[k]
+        return v.decode() if isinstance(v, bytes) else str(v)
 
     def __len__(self):
         return len(self.text)
@@ -93,14 +96,69 @@ class CallNotes:
         name list this column was built over (or a call is not plain ASCII)."""
         if row_names is not self.names:
             return None
-        n, width = len(self.text), self.text.dtype.itemsize // 4
-        code = np.frombuffer(self.text.tobytes(), dtype=np.uint32).reshape(n, width)
-        if (code > 127).any():
-            return None
+        n, item = len(self.text), self.text.dtype.itemsize
+        if self.text.dtype.kind == 'S':
+            code = np.frombuffer(self.text.tobytes(), dtype=np.uint8).reshape(n, item)
+        else:
+            code = np.frombuffer(self.text.tobytes(), dtype=np.uint32).reshape(n, item // 4)
+            if (code > 127).any():
+                return None
         used = code != 0
         off = np.zeros(n + 1, dtype=np.int64)
         np.cumsum(used.sum(axis=1), out=off[1:])
         return code[used].astype(np.uint8).tobytes(), off
+
+
+def _mark_loci(aln_mat, gidx, bits, text, note_type):
+    """allowed bits per locus and the isoform notes from per-line (gene index, haplotype bits, call) in file
+    order: every line marks the loci of its gene; an isoform keeps the call of the last line that names it."""
+    L = aln_mat.num_loci
+    allowed = np.zeros(L, dtype=np.uint32)
+    iso_text, iso_has = np.full(L, 'None', dtype=note_type), np.zeros(L, dtype=bool)
+    ptr, mem = aln_mat.group_csr()
+    n = len(gidx)
+    start, size = ptr[gidx], ptr[gidx + 1] - ptr[gidx]
+    line_of = np.repeat(np.arange(n, dtype=np.int64), size)
+    first = np.zeros(n, dtype=np.int64)
+    np.cumsum(size[:-1], out=first[1:])
+    loci = mem[start[line_of] + (np.arange(len(line_of), dtype=np.int64) - first[line_of])]
+    np.bitwise_or.at(allowed, loci, bits[line_of])
+    iso_text[loci] = text[line_of]                               # a repeated index keeps the last line's call
+    iso_has[loci] = True
+    return allowed, CallNotes(aln_mat.lname, iso_text, iso_has)
+
+
+def genotype_mask_from_file(aln_mat, genotype_file):
+    """diplotype_mask(aln_mat, read_genotype_table(genotype_file)) with the table parsed by the library
+    (gbrs_parse_genotype_table); None when the file has a line that needs the interpreter's own parsing and errors."""
+    from . import _lib
+    from .em import _blob, _blob_cached
+    G, H = len(aln_mat.gname), aln_mat.num_haplotypes
+    with open(genotype_file, 'rb') as fh:
+        raw = fh.read()
+    gene_blob, gene_off = _blob_cached(aln_mat.gname)
+    hap_blob, hap_off = _blob(aln_mat.hname)
+    width = 8
+    gene_bits = np.zeros(G, dtype=np.uint32)
+    gene_call = np.zeros(G, dtype=f'S{width}')
+    last_line = np.full(G, -1, dtype=np.int32)
+    import ctypes as C
+    n_lines = C.c_int64(0)
+    st = _lib.load().gbrs_parse_genotype_table(raw, len(raw), gene_blob, _lib.ptr(gene_off), G, hap_blob,
+                                               _lib.ptr(hap_off), H, _lib.ptr(gene_bits), _lib.ptr(gene_call), width,
+                                               _lib.ptr(last_line), C.byref(n_lines))
+    if st != 0:
+        if st < 0:
+            _lib.check(st)
+        return None
+    has = last_line >= 0
+    gene_text = np.where(has, gene_call, np.bytes_(b'None')).astype(f'S{width}')
+    gnotes = CallNotes(aln_mat.gname, gene_text, has)
+    # the called genes in the order of their last lines: an isoform listed under two genes keeps the later one's call
+    gidx = np.flatnonzero(has)
+    gidx = gidx[np.argsort(last_line[gidx], kind='stable')]
+    allowed, tnotes = _mark_loci(aln_mat, gidx, gene_bits[gidx], gene_text[gidx], f'S{width}')
+    return allowed, gnotes, tnotes
 
 
 def diplotype_mask(aln_mat, calls):
@@ -118,12 +176,11 @@ def diplotype_mask(aln_mat, calls):
     text = np.asarray(texts, dtype='U') if n else np.zeros(0, dtype='U1')
     width = text.dtype.itemsize // 4
     note_type = f'U{max(width, 4)}'
-    gene_text, iso_text = np.full(G, 'None', dtype=note_type), np.full(L, 'None', dtype=note_type)
-    gene_has, iso_has = np.zeros(G, dtype=bool), np.zeros(L, dtype=bool)
-    allowed = np.zeros(L, dtype=np.uint32)
-    gnotes, tnotes = CallNotes(aln_mat.gname, gene_text, gene_has), CallNotes(aln_mat.lname, iso_text, iso_has)
+    gene_text, gene_has = np.full(G, 'None', dtype=note_type), np.zeros(G, dtype=bool)
+    gnotes = CallNotes(aln_mat.gname, gene_text, gene_has)
     if n == 0:
-        return allowed, gnotes, tnotes
+        return (np.zeros(L, dtype=np.uint32), gnotes,
+                CallNotes(aln_mat.lname, np.full(L, 'None', dtype=note_type), np.zeros(L, dtype=bool)))
     gene_index = {name: k for k, name in enumerate(aln_mat.gname.tolist())}
     found = itemgetter(*genes)(gene_index)                       # KeyError on a gene the group file does not list
     gidx = np.asarray(found if n > 1 else (found,), dtype=np.int64)
@@ -134,18 +191,9 @@ def diplotype_mask(aln_mat, calls):
     bit_of = np.array([np.uint32(1) << np.uint32(hap_index[chr(cp)]) if cp else np.uint32(0)     # KeyError on an
                        for cp in uniq.tolist()], dtype=np.uint32)                                # unknown letter
     bits = np.bitwise_or.reduce(bit_of[inv].reshape(n, width), axis=1)
-    # every line marks the loci of its gene
-    ptr, mem = aln_mat.group_csr()
-    start, size = ptr[gidx], ptr[gidx + 1] - ptr[gidx]
-    line_of = np.repeat(np.arange(n, dtype=np.int64), size)
-    first = np.zeros(n, dtype=np.int64)
-    np.cumsum(size[:-1], out=first[1:])
-    loci = mem[start[line_of] + (np.arange(len(line_of), dtype=np.int64) - first[line_of])]
-    np.bitwise_or.at(allowed, loci, bits[line_of])
+    allowed, tnotes = _mark_loci(aln_mat, gidx, bits, text, note_type)
     gene_text[gidx] = text                                       # a repeated index keeps the last line's call
     gene_has[gidx] = True
-    iso_text[loci] = text[line_of]
-    iso_has[loci] = True
     return allowed, gnotes, tnotes
 
 
@@ -226,7 +274,8 @@ def quantify(alignment_file: str, group_file: str = None, length_file: str = Non
     else:
         outbase = f'{outbase}.diploid'
         logger.info(f'Loading and processing genotype calls from: {genotype_file}')
-        allowed, gene_notes, isoform_notes = diplotype_mask(aln_mat, read_genotype_table(genotype_file))
+        allowed, gene_notes, isoform_notes = genotype_mask_from_file(aln_mat, genotype_file) or \
+            diplotype_mask(aln_mat, read_genotype_table(genotype_file))
         aln_mat.set_haplotype_mask(allowed)        # applied on the device when the EM handle is built
     logger.debug(f'Outbase now: {outbase}')
     marks['mask'] = clock() - t0

@@ -374,6 +374,20 @@ int gbrs_parse_length_table(const char *text, int64_t text_len, const char *name
                             int64_t n_loci, const char *haps, const int64_t *hap_off, int32_t n_haps,
                             double read_length, double *eff_out);
 
+/* The genotype call table of `gbrs quantify -G` (gbrs/emase_utils.py:262-268) parsed natively: text is the whole file
+ * (`#` lines that open it are skipped, then `<gene> TAB <call>[ TAB ...]` lines, every character of a call a
+ * haplotype name); gene_names / haps are byte blobs with n + 1 offsets.  Per gene g (caller zeroes / presets the
+ * arrays): gene_bits[g] |= the haplotype bits of each of its lines (the reference's mask accumulates over lines),
+ * gene_call[g * call_width ...] = the call of its last line, zero padded, gene_last_line[g] = that line's index
+ * (what the notes keep; -1 preset = no call).  n_lines receives the number of data lines.  Returns 0 when every
+ * line was plain, 1 when some line needs the caller's own permissive line-by-line parsing and error reporting
+ * (unknown gene or haplotype letter, a line without a second field, bytes outside printable ASCII, a call longer
+ * than call_width). */
+int gbrs_parse_genotype_table(const char *text, int64_t text_len, const char *gene_names, const int64_t *gene_off,
+                              int64_t n_genes, const char *haps, const int64_t *hap_off, int32_t n_haps,
+                              uint32_t *gene_bits, char *gene_call, int32_t call_width, int32_t *gene_last_line,
+                              int64_t *n_lines);
+
 /* The numbers of a `label TAB v1 TAB ... TAB vn` table (the genes.tpm report `gbrs reconstruct` reads,
  * gbrs/gbrs_utils.py:450-459): text holds exactly n_rows such lines (header removed), out receives n_rows x n_cols
  * doubles.  Returns 0, or 1 when a line is not of that plain form (the caller then parses it its own way). */

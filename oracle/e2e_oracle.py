@@ -6,9 +6,10 @@ It restates the reference's two workflows with the numpy oracles of this directo
 per-line Python file handling the reference uses, so its stage times stand in for the reference's on a
 box where the reference itself cannot run (/root/reference does not travel; PyTables is absent):
 
-  quantify     gbrs/emase_utils.py:180-332  load alignment file + group file -> EMfactory.prepare
-               (length file parsed line by line, EMfactory.py:60-94) -> run(model 4) -> 4 TSV reports
-               written value by value with str() (EMfactory.py:289-380)
+  quantify     gbrs/emase_utils.py:180-332  load alignment file + group file [-> the `-G` genotype mask: one line of
+               the call table at a time into an (H x L) mask, multiply(axis=2) + eliminate_zeros, :240-273]
+               -> EMfactory.prepare (length file parsed line by line, EMfactory.py:60-94) -> run(model 4)
+               -> 4 TSV reports written value by value with str() (EMfactory.py:289-380)
   reconstruct  gbrs/gbrs_utils.py:382-609   load avecs / gene order / TPM / tprob -> per gene emission
                (np.load()[gene] per gene, :490) -> forward, backward, posterior, Viterbi per chromosome
                -> genoprobs.npz, genotypes.tsv, genotypes.npz
@@ -17,7 +18,7 @@ Differences that favour this baseline over the real reference: the alignment fil
 (np.load + zlib) instead of PyTables HDF5, and the unused t2t_mat double loop of EMfactory.prepare
 (:48-59, Models 1-3 only) is skipped.
 
-Usage:  python oracle/e2e_oracle.py quantify  ALN.npz GROUPS LENGTHS OUTBASE
+Usage:  python oracle/e2e_oracle.py quantify  ALN.npz GROUPS LENGTHS OUTBASE [GENOTYPES.tsv]
         python oracle/e2e_oracle.py reconstruct GENES.tpm TPROB.npz AVECS.npz GPOS.npz FAI OUTBASE
 Prints one JSON line with the stage times.
 """
@@ -34,16 +35,19 @@ from oracle.em_oracle import EMOracle  # noqa: E402
 from oracle import hmm_oracle  # noqa: E402
 
 
-def _write_table(path, hnames, names, values):
+def _write_table(path, hnames, names, values, notes=None):
     totals = values.sum(axis=0)
     data = np.vstack((values, totals))
     with open(path, "w") as fh:
-        fh.write("locus\t" + "\t".join(hnames) + "\ttotal\n")
+        fh.write("locus\t" + "\t".join(hnames) + "\ttotal" + ("\tnotes" if notes is not None else "") + "\n")
         for k in range(len(names)):
-            fh.write("\t".join([names[k]] + list(map(str, data[:, k].ravel()))) + "\n")
+            fh.write("\t".join([names[k]] + list(map(str, data[:, k].ravel()))))
+            if notes is not None:
+                fh.write("\t%s" % notes[names[k]])
+            fh.write("\n")
 
 
-def quantify(aln_file, group_file, length_file, outbase, tol=1e-4, max_iters=999):
+def quantify(aln_file, group_file, length_file, outbase, genotype_file=None, tol=1e-4, max_iters=999):
     t = {}
     t0 = time.perf_counter()
     with np.load(aln_file, allow_pickle=False) as z:
@@ -61,8 +65,35 @@ def quantify(aln_file, group_file, length_file, outbase, tol=1e-4, max_iters=999
             gname.append(item[0])
             groups.append([lid[x] for x in item[1:]])
     t["load"] = time.perf_counter() - t0
-    t0 = time.perf_counter()
     hid = dict(zip(hname, range(H)))
+    o = EMOracle(R, L, H, indptr, indices, count)
+    kind = "multiway"
+    gtcall_g = gtcall_t = None
+    if genotype_file is not None:
+        # gbrs/emase_utils.py:240-273, line by line as there
+        t0 = time.perf_counter()
+        kind = "diploid"
+        gid = dict(zip(gname, range(len(gname))))
+        gtmask = np.zeros((H, L))
+        gtcall_g = dict.fromkeys(gname)
+        gtcall_t = dict.fromkeys(lname)
+        with open(genotype_file) as fh:
+            started = False
+            for line in fh:
+                if not started and line.startswith("#"):
+                    continue
+                started = True
+                item = line.rstrip().split("\t")
+                g, gt = item[:2]
+                gtcall_g[g] = gt
+                hid2set = np.array([hid[c] for c in gt])
+                tid2set = np.array(groups[gid[g]])
+                gtmask[tuple(np.meshgrid(hid2set, tid2set))] = 1.0
+                for tt in tid2set:
+                    gtcall_t[lname[tt]] = gt
+        o.apply_genotype_mask(gtmask)
+        t["mask"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
     eff = np.zeros((L, H))
     with open(length_file) as fh:
         for line in fh:
@@ -70,7 +101,6 @@ def quantify(aln_file, group_file, length_file, outbase, tol=1e-4, max_iters=999
             locus, hap = item[0].split("_")
             eff[lid[locus], hid[hap]] = max(float(item[1]) - 100 + 1.0, 1.0)
     eff = eff.transpose()
-    o = EMOracle(R, L, H, indptr, indices, count)
     o.prepare(0.0, eff)
     t["em_setup"] = time.perf_counter() - t0
     t0 = time.perf_counter()
@@ -79,19 +109,20 @@ def quantify(aln_file, group_file, length_file, outbase, tol=1e-4, max_iters=999
     t["em_iterations"] = n
     t0 = time.perf_counter()
     theta = o.theta * (1000000.0 / o.theta.sum())
-    _write_table(f"{outbase}.multiway.isoforms.tpm", hname, lname, theta)
+    _write_table(f"{outbase}.{kind}.isoforms.tpm", hname, lname, theta, gtcall_t)
     counts = o.expected_read_counts()
-    _write_table(f"{outbase}.multiway.isoforms.expected_read_counts", hname, lname, counts)
+    _write_table(f"{outbase}.{kind}.isoforms.expected_read_counts", hname, lname, counts, gtcall_t)
     # scipy hands the reference this product as the transpose of a C-ordered (G x H) array, and the
     # full .sum() below adds in memory order (EMfactory.py:349-354)
     gene = np.asfortranarray(EMOracle.group_sums(theta, groups))
     gene *= 1000000.0 / gene.sum()
-    _write_table(f"{outbase}.multiway.genes.tpm", hname, gname, gene)
-    _write_table(f"{outbase}.multiway.genes.expected_read_counts", hname, gname,
-                 np.asfortranarray(EMOracle.group_sums(counts, groups)))
+    _write_table(f"{outbase}.{kind}.genes.tpm", hname, gname, gene, gtcall_g)
+    _write_table(f"{outbase}.{kind}.genes.expected_read_counts", hname, gname,
+                 np.asfortranarray(EMOracle.group_sums(counts, groups)), gtcall_g)
     t["reports"] = time.perf_counter() - t0
     t["rows"] = R
     t["entries"] = int(sum(len(i) for i in indices))
+    t["entries_in_em"] = int(sum(len(i) for i in o.indices))
     return t
 
 
@@ -138,6 +169,6 @@ def reconstruct(expr_file, tprob_file, avec_file, gpos_file, fai_file, outbase):
 if __name__ == "__main__":
     t_start = time.perf_counter()
     cmd = sys.argv[1]
-    out = quantify(*sys.argv[2:6]) if cmd == "quantify" else reconstruct(*sys.argv[2:8])
+    out = quantify(*sys.argv[2:7]) if cmd == "quantify" else reconstruct(*sys.argv[2:8])
     out["total_in_process"] = time.perf_counter() - t_start
     print(json.dumps(out), flush=True)

@@ -1,14 +1,17 @@
 #!/usr/bin/env python3
-"""End-to-end wall clock of `gbrs quantify` + `gbrs reconstruct` (file in -> reports out), the quantity
-BASELINE.json's ">= 50x" is stated on (gbrs/emase_utils.py:180-332, gbrs/gbrs_utils.py:382-609).
+"""End-to-end wall clock of the three-command GBRS pipeline, files in -> reports out: `gbrs quantify` ->
+`gbrs reconstruct` -> `gbrs quantify -G genotypes.tsv` (gbrs/emase_utils.py:180-332,
+gbrs/gbrs_utils.py:382-609).  BASELINE.json's ">= 50x" is stated on the first two.
 
   1. builds the BASELINE configs[1] sample with the bench generator and writes it as an EMASE file
      (`.h5` through libhdf5 and/or the `.npz` mirror), with its group and length files;
-  2. runs `python -m gbrs_amd quantify ...` and `python -m gbrs_amd reconstruct ...` as fresh child
-     processes (interpreter start, imports and HIP initialisation are inside the measured wall clock) and
-     collects the per-stage times the drivers record (GBRS_STAGE_TIMES);
-  3. runs oracle/e2e_oracle.py (the numpy restatement of the reference workflow, one core) on a row
-     subsample of the same sample and scales its row-dependent stages linearly to the full size.
+  2. runs `python -m gbrs_amd quantify ...`, `... reconstruct ...` on its genes.tpm and `... quantify -G` on the
+     genotypes.tsv that leaves behind, each as a fresh child process (interpreter start, imports and HIP
+     initialisation are inside the measured wall clock) and collects the per-stage times the drivers record
+     (GBRS_STAGE_TIMES);
+  3. runs oracle/e2e_oracle.py (the numpy restatement of the reference workflow, one core per command) on the
+     same files - on the FULL sample when the host has the memory for it (>= 128 GB; three one-core processes side
+     by side), else on a row subsample whose row-dependent stages are scaled linearly, and says which.
 
 Prints one JSON object.  Needs an MI355X.  Usage:
     python scripts/e2e_bench.py [--rows N] [--format h5|npz|both] [--cpu-rows M] [--workdir DIR] [--keep]
@@ -83,7 +86,20 @@ def build_sample(workdir, rows, haps, loci, fmt, cpu_rows):
         out["files"]["npz"] = p
         out["write_s"]["npz"] = time.perf_counter() - t1
     out["bytes"] = {k: os.path.getsize(v) for k, v in out["files"].items()}
-    if cpu_rows:
+    if cpu_rows >= rows and "npz" in out["files"]:
+        out["cpu_sub"], out["cpu_sub_entries"] = out["files"]["npz"], N
+    elif cpu_rows >= rows:
+        # the whole sample as the `.npz` mirror the one-core baseline reads (members deflated on all cores here; the
+        # baseline inflates them on its one)
+        from gbrs_amd.npzfast import savez_compressed
+        p = os.path.join(workdir, "full.npz")
+        members = dict(shape=np.asarray((loci, haps, rows), dtype=np.int64), hname=np.array(hname), lname=np.array(lname))
+        for h in range(haps):
+            members[f"indptr{h}"] = ip[h]
+            members[f"indices{h}"] = ix[h]
+        savez_compressed(p, members)
+        out["cpu_sub"], out["cpu_sub_entries"] = p, N
+    elif cpu_rows:
         out["cpu_sub"], out["cpu_sub_entries"] = write_cpu_subsample(workdir, (ip, ix, eff, lname, hname),
                                                                      min(cpu_rows, rows), loci, haps)
     out["build_s"] = time.perf_counter() - t0
@@ -177,24 +193,62 @@ def run_cli(argv, workdir, tag):
     return wall, st
 
 
-def run_oracle(argv):
+def start_oracle(argv):
     env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1", PYTHONPATH=ROOT)
-    t0 = time.time()
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "oracle", "e2e_oracle.py")] + argv, env=env,
-                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    return time.time(), subprocess.Popen([sys.executable, os.path.join(ROOT, "oracle", "e2e_oracle.py")] + argv, env=env,
+                                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+
+
+def finish_oracle(started, what):
+    t0, proc = started
+    out, err = proc.communicate()
     wall = time.time() - t0
-    if r.returncode != 0:
-        raise RuntimeError(f"oracle {argv[0]} failed: {r.stderr[-2000:]}")
-    return wall, json.loads(r.stdout.strip().split("\n")[-1])
+    if proc.returncode != 0:
+        raise RuntimeError(f"oracle {what} failed: {err[-2000:]}")
+    return wall, json.loads(out.strip().split("\n")[-1])
+
+
+def run_oracle(argv):
+    return finish_oracle(start_oracle(argv), argv[0])
+
+
+def host_memory_gb():
+    try:
+        return os.sysconf("SC_PAGE_SIZE") * os.sysconf("SC_PHYS_PAGES") / 2.0**30
+    except (ValueError, OSError):
+        return 0.0
+
+
+FULL_CPU_MIN_GB = 128.0        # the one-core oracle needs ~40 GB per quantify process at 40M reads
+
+
+def best_of(runs):
+    best = min(runs, key=lambda r: r["wall_s"])
+    return dict(wall_s=best["wall_s"], stages=best["stages"], all_wall_s=[r["wall_s"] for r in runs])
+
+
+def scaled_quantify(wall, st, scale, iters_full):
+    """A subsample's one-core quantify extrapolated to the full sample: stages that walk the reads scale linearly in
+    them; parsing the L-sized tables, the genotype table, the reports and process start do not."""
+    per_iter = st["em_run"] / max(st["em_iterations"], 1)
+    return st["load"] * scale + st["em_setup"] * scale + st.get("mask", 0.0) + per_iter * scale * iters_full \
+        + st["reports"] + (wall - st["total_in_process"])
 
 
 def measure(rows=40_000_000, haps=8, loci=120_000, fmt="h5", cpu_rows=2_000_000, workdir=None, keep=False,
-            repeats=2, with_cpu=True):
+            repeats=2, with_cpu=True, cpu_full="auto"):
+    """cpu_full: "auto" = the one-core baseline runs on the whole sample when the host has FULL_CPU_MIN_GB of memory,
+    "yes" / "no" force it."""
     own = workdir is None
     workdir = tempfile.mkdtemp(prefix="gbrs_e2e_") if own else workdir
     os.makedirs(workdir, exist_ok=True)
-    res = dict(workload=f"configs[1]/[2]: R={rows} reads x H={haps} x L={loci} isoforms from file, quantify "
-                        "(Model 4, tol 1e-4, 4 reports) then reconstruct on its genes.tpm (20 chromosomes)")
+    mem_gb = host_memory_gb()
+    full = with_cpu and (cpu_full == "yes" or (cpu_full == "auto" and mem_gb >= FULL_CPU_MIN_GB))
+    if full:
+        cpu_rows = rows
+    res = dict(workload=f"configs[1]/[2]: R={rows} reads x H={haps} x L={loci} isoforms from file: quantify (Model 4, "
+                        "tol 1e-4, 4 reports), reconstruct on its genes.tpm (20 chromosomes), quantify -G on the "
+                        "genotypes.tsv of that (diploid pass)")
     try:
         sample = build_sample_in_child(workdir, rows, haps, loci, fmt, cpu_rows if with_cpu else 0)
         res["sample"] = dict(entries=sample["N"], file_bytes=sample["bytes"], write_s=sample["write_s"])
@@ -205,9 +259,7 @@ def measure(rows=40_000_000, haps=8, loci=120_000, fmt="h5", cpu_rows=2_000_000,
                 wall, st = run_cli(["quantify", "-i", path, "-g", sample["group_file"], "-L", sample["length_file"],
                                     "-o", os.path.join(workdir, f"out_{kind}")], workdir, f"q_{kind}")
                 runs.append(dict(wall_s=wall, stages=st))
-            best = min(runs, key=lambda r: r["wall_s"])
-            res["quantify"][kind] = dict(wall_s=best["wall_s"], stages=best["stages"],
-                                         all_wall_s=[r["wall_s"] for r in runs])
+            res["quantify"][kind] = best_of(runs)
         first = next(iter(sample["files"]))
         genes_tpm = os.path.join(workdir, f"out_{first}.multiway.genes.tpm")
         rec, n_genes = write_reconstruct_inputs(workdir, genes_tpm)
@@ -216,34 +268,58 @@ def measure(rows=40_000_000, haps=8, loci=120_000, fmt="h5", cpu_rows=2_000_000,
             wall, st = run_cli(["reconstruct", "-e", genes_tpm, "-t", rec["tprob"], "-x", rec["avecs"], "-g", rec["gpos"],
                                 "-o", os.path.join(workdir, "rec")], workdir, "r")
             runs.append(dict(wall_s=wall, stages=st))
-        best = min(runs, key=lambda r: r["wall_s"])
-        res["reconstruct"] = dict(wall_s=best["wall_s"], stages=best["stages"], genes=n_genes,
-                                  all_wall_s=[r["wall_s"] for r in runs])
+        res["reconstruct"] = dict(best_of(runs), genes=n_genes)
+        # third command: the diploid pass on the genotype calls reconstruct just wrote (gbrs/emase_utils.py:240-273)
+        genotypes = os.path.join(workdir, "rec.genotypes.tsv")
+        runs = []
+        for _ in range(repeats):
+            wall, st = run_cli(["quantify", "-i", sample["files"][first], "-g", sample["group_file"], "-L",
+                                sample["length_file"], "-G", genotypes, "-o", os.path.join(workdir, f"out_{first}")],
+                               workdir, "qg")
+            runs.append(dict(wall_s=wall, stages=st))
+        res["quantify_diploid"] = best_of(runs)
         qbest = min(v["wall_s"] for v in res["quantify"].values())
         res["total_wall_s"] = qbest + res["reconstruct"]["wall_s"]
+        res["pipeline_wall_s"] = res["total_wall_s"] + res["quantify_diploid"]["wall_s"]
         if with_cpu:
             sub, n_sub = sample["cpu_sub"], sample["cpu_sub_entries"]
-            wq, tq = run_oracle(["quantify", sub, sample["group_file"], sample["length_file"],
-                                 os.path.join(workdir, "cpu")])
-            wr, tr = run_oracle(["reconstruct", os.path.join(workdir, "cpu.multiway.genes.tpm"), rec["tprob"],
-                                 rec["avecs"], rec["gpos"], rec["fai"], os.path.join(workdir, "cpu_rec")])
-            scale = rows / float(min(cpu_rows, rows))
-            # row-dependent stages scale with the number of reads; file parsing of the L-sized tables,
-            # report writing and the whole of reconstruct do not
-            per_iter = tq["em_run"] / max(tq["em_iterations"], 1)
+            # three one-core processes side by side (the box's other cores are idle); the two downstream commands read
+            # the device path's genes.tpm / genotypes.tsv, which tests hold equal to the oracle's own
+            pq = start_oracle(["quantify", sub, sample["group_file"], sample["length_file"], os.path.join(workdir, "cpu")])
+            pg = start_oracle(["quantify", sub, sample["group_file"], sample["length_file"], os.path.join(workdir, "cpu"),
+                               genotypes])
+            pr = start_oracle(["reconstruct", genes_tpm, rec["tprob"], rec["avecs"], rec["gpos"], rec["fai"],
+                               os.path.join(workdir, "cpu_rec")])
+            wr, tr = finish_oracle(pr, "reconstruct")
+            wg, tg = finish_oracle(pg, "quantify -G")
+            wq, tq = finish_oracle(pq, "quantify")
+            n_cpu = min(cpu_rows, rows)
+            scale = rows / float(n_cpu)
             iters_full = res["quantify"][first]["stages"].get("em_iterations", tq["em_iterations"])
-            est_q = (tq["load"] * scale) + (tq["em_setup"] * scale) + per_iter * scale * iters_full + tq["reports"] \
-                + (wq - tq["total_in_process"])
+            iters_full_g = res["quantify_diploid"]["stages"].get("em_iterations", tg["em_iterations"])
+            if scale == 1.0:
+                est_q, est_g = wq, wg
+                how = (f"oracle/e2e_oracle.py on the whole sample ({n_sub} entries, .npz mirror of the same reads), one "
+                       f"core per command, the three commands side by side on a host with {os.cpu_count()} cores and "
+                       f"{mem_gb:.0f} GB; nothing scaled or extrapolated")
+            else:
+                est_q = scaled_quantify(wq, tq, scale, iters_full)
+                est_g = scaled_quantify(wg, tg, scale, iters_full_g)
+                how = (f"oracle/e2e_oracle.py on the first {n_cpu} reads ({n_sub} entries) of the same sample as an .npz "
+                       f"file (host memory {mem_gb:.0f} GB < {FULL_CPU_MIN_GB:.0f} GB needed for the whole sample); load, "
+                       f"EM set-up and per-iteration time scaled x{scale:g} linearly in reads at the full sample's "
+                       f"iteration counts ({iters_full}, diploid {iters_full_g}), reports and process start unscaled; "
+                       "reconstruct run whole")
             res["cpu_baseline"] = dict(
-                kind="port", cores=1, host_cores=os.cpu_count(),
-                sample=f"oracle/e2e_oracle.py on the first {min(cpu_rows, rows)} reads ({n_sub} entries) of the same "
-                       f"sample as an .npz file; load, EM set-up and per-iteration time scaled x{scale:g} linearly in "
-                       f"reads, {iters_full} iterations (the full sample's count), reports and process start unscaled; "
-                       "reconstruct run whole",
+                kind="port", cores=1, host_cores=os.cpu_count(), host_memory_gb=mem_gb, full_size=scale == 1.0, sample=how,
                 quantify_measured=dict(wall_s=wq, stages=tq), reconstruct_measured=dict(wall_s=wr, stages=tr),
-                quantify_scaled_s=est_q, reconstruct_s=wr, total_s=est_q + wr)
+                quantify_diploid_measured=dict(wall_s=wg, stages=tg),
+                quantify_scaled_s=est_q, reconstruct_s=wr, quantify_diploid_scaled_s=est_g, total_s=est_q + wr,
+                pipeline_s=est_q + wr + est_g)
             res["speedup_vs_cpu"] = dict(quantify=est_q / qbest, reconstruct=wr / res["reconstruct"]["wall_s"],
-                                         total=(est_q + wr) / res["total_wall_s"])
+                                         quantify_diploid=est_g / res["quantify_diploid"]["wall_s"],
+                                         total=(est_q + wr) / res["total_wall_s"],
+                                         pipeline=(est_q + wr + est_g) / res["pipeline_wall_s"])
     finally:
         if own and not keep:
             shutil.rmtree(workdir, ignore_errors=True)
@@ -261,6 +337,8 @@ def main():
     ap.add_argument("--keep", action="store_true")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--repeats", type=int, default=2)
+    ap.add_argument("--cpu-full", default="auto", choices=["auto", "yes", "no"],
+                    help="one-core baseline on the whole sample (auto: when the host has >= 128 GB)")
     ap.add_argument("--make-sample", action="store_true", help="(internal) child process that writes the sample files")
     a = ap.parse_args()
     if a.make_sample:
@@ -268,7 +346,7 @@ def main():
         return
     subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build()"], cwd=ROOT, check=True,
                    stdout=sys.stderr)             # built in a child: the parent never loads the HIP runtime
-    out = measure(a.rows, a.haps, a.loci, a.format, a.cpu_rows, a.workdir, a.keep, a.repeats, not a.no_cpu)
+    out = measure(a.rows, a.haps, a.loci, a.format, a.cpu_rows, a.workdir, a.keep, a.repeats, not a.no_cpu, a.cpu_full)
     print(json.dumps(out), flush=True)
 
 

@@ -346,9 +346,11 @@ def test_quantify_cli_files(tmp_path, name, use_mask, fmt):
         gt = tmp_path / "gt.tsv"
         with open(gt, "w") as fh:
             fh.write("#Gene_ID\tDiplotype\n")
+            calls = []
             for i, mem in enumerate(groups):
                 hs = np.flatnonzero(gtmask[:, mem[0]])
-                fh.write(f"G{i:07d}\t" + "".join(hn[h] for h in (hs if len(hs) == 2 else [hs[0], hs[0]])) + "\n")
+                calls.append("".join(hn[h] for h in (hs if len(hs) == 2 else [hs[0], hs[0]])))
+                fh.write(f"G{i:07d}\t{calls[-1]}\n")
         argv += ["-G", str(gt)]
         suffix = "diploid"
     assert cli.main(argv) == 0
@@ -358,12 +360,23 @@ def test_quantify_cli_files(tmp_path, name, use_mask, fmt):
         exp_h, exp = _parse_tsv(str(g[key]))
         assert got_h[:len(exp_h)] == exp_h and list(got) == list(exp)
         if use_mask:
+            # notes column: the diplotype called for the row's gene (gbrs/emase_utils.py:265-268)
             assert got_h[-1] == "notes"
+            call_of_gene = {f"G{i:07d}": calls[i] for i in range(len(groups))}
+            call_of = call_of_gene if fname.startswith("genes") else \
+                {ln[m]: calls[i] for i, mem in enumerate(groups) for m in mem}
+            assert all(got[k][-1] == call_of[k] for k in got)
         for k in exp:
             np.testing.assert_allclose([float(x) for x in got[k][:len(exp[k])]], [float(x) for x in exp[k]],
                                        rtol=1e-9, atol=1e-300)
-    assert (tmp_path / f"out.{suffix}.isoforms.alignment_counts").exists()
-    assert (tmp_path / f"out.{suffix}.genes.alignment_counts").exists()
+    # the alignment-count reports are those of the file as it is, whatever `-G` restricted the EM to (the reference
+    # reloads the file for them, gbrs/emase_utils.py:318-331)
+    from gbrs_amd.alignment import load_alignment
+    from gbrs_amd.counts import report_alignment_counts
+    fresh = load_alignment(str(aln), grpfile=str(grp))
+    for level, grp_wise in (("isoform", False), ("gene", True)):
+        report_alignment_counts(fresh, str(tmp_path / f"fresh.{level}"), grp_wise=grp_wise)
+        assert open(tmp_path / f"out.{suffix}.{level}s.alignment_counts").read() == open(tmp_path / f"fresh.{level}").read()
 
 
 def _sharded_worker(rank, world, port, path, out_dir):

@@ -182,7 +182,21 @@ def test_genotype_table_forms(tmp_path):
     odd.write_text("#Gene_ID\tDiplotype\nG0000000\tAB\textra\nG0000001\tCC  \n#G0000002\tDD\nG0000000\tGH\n")
     genes, calls = read_genotype_table(str(odd))
     assert genes == ["G0000000", "G0000001", "#G0000002", "G0000000"] and calls == ["AB", "CC", "DD", "GH"]
+    from gbrs_amd.quantify import genotype_mask_from_file
+    native = genotype_mask_from_file(apm, str(plain))                # the library's parser: same mask, same notes
     allowed, cg, ct = diplotype_mask(apm, read_genotype_table(str(plain)))
+    assert native is not None
+    np.testing.assert_array_equal(native[0], allowed)
+    for mine, theirs, names in ((native[1], cg, apm.gname), (native[2], ct, apm.lname)):
+        assert [mine[k] for k in names] == [theirs[k] for k in names]
+        blob_a, off_a = mine.aligned_blob(names)
+        blob_b, off_b = theirs.aligned_blob(names)
+        assert blob_a == blob_b and np.array_equal(off_a, off_b)
+    assert genotype_mask_from_file(apm, str(odd)) is None            # a `#` line after the header: not a gene it knows
+    spaced = tmp_path / "spaced.tsv"
+    spaced.write_text("#Gene_ID\tDiplotype\nG0000000\tAB\textra\nG0000001\tCC  \n")
+    sp = genotype_mask_from_file(apm, str(spaced))
+    assert sp is not None and sp[1]["G0000001"] == "CC" and set(sp[0][groups[0]].tolist()) == {0b11}
     assert set(allowed[groups[0]].tolist()) == {0b11000011} and set(allowed[groups[1]].tolist()) == {0b100}
     rest = np.setdiff1d(np.arange(apm.num_loci), np.concatenate([groups[0], groups[1]]))
     assert not allowed[rest].any()
@@ -193,8 +207,12 @@ def test_genotype_table_forms(tmp_path):
         diplotype_mask(apm, (["nope"], ["AB"]))                # gene the group file does not list
     bad = tmp_path / "bad.tsv"
     bad.write_text("G0000000\n")
+    assert genotype_mask_from_file(apm, str(bad)) is None
     with pytest.raises(ValueError):
         read_genotype_table(str(bad))
+    for text in ("G0000000\tAZ\n", "nope\tAB\n", "G0000000\tABCDEFGHA\n", "G0000000\tA\xc3\xa9\n"):
+        bad.write_text(text)
+        assert genotype_mask_from_file(apm, str(bad)) is None        # left to the line-by-line path and its errors
 
 
 def test_read_gene_tpm_native_and_fallback_agree(tmp_path):
