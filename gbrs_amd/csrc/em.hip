@@ -445,6 +445,7 @@ struct gbrs_em {
     DevBuf<double> count, eff_len;                 // R ; L*H locus-major
     DevBuf<double> acc_init;                       // L*H: prepare()'s column sums when the file stores values
     bool has_init = false, keep_csc = false;
+    bool stopped = false;          // the device's stop flag is set: every step kernel is a no-op until it is cleared
     DevBuf<double> theta, acc, counts;             // L*H locus-major
     DevBuf<double> tot_prev, tot_new;              // L
     DevBuf<double> partials;                       // 3 * RED_BLOCKS (pseudocount reductions)
@@ -475,6 +476,7 @@ int em_check_float(gbrs_em *em, EmScalars &host) {
     GBRS_TRY(em_flush_err(em));
     GBRS_HIP_CHECK(hipMemcpyAsync(&host, em->scalars.p, sizeof(EmScalars), hipMemcpyDeviceToHost, em->stream));
     GBRS_HIP_CHECK(hipStreamSynchronize(em->stream));
+    em->stopped = host.stop != 0;
     static const bool no_check = std::getenv("GBRS_TUNING_NO_FLOAT_CHECK") != nullptr;   // ablation builds only
     if (host.float_error && !no_check)
         return fail(GBRS_ERR_FLOAT, "invalid value encountered in divide (a read's alignments all have zero abundance)");
@@ -580,14 +582,21 @@ int em_estep(gbrs_em *em, bool materialize = false) {
 // few slots sums them in place, and the loci with many slots get one workgroup each (the leading
 // workgroups), which reduces the slots in fixed order and applies the M-step to that locus itself.
 // No intermediate A vector is written for the gathered loci and there is one launch less per step.
+//
+// Round 3: the launch was ~13 us of a ~115 us iteration and none of it was bandwidth - it is the number of
+// DEPENDENT global loads on its longest path (a round trip is ~0.7 us): stop flag -> locus list -> slot_ptr ->
+// four slot rows at a time -> ... .  Now every path is two round trips: (1) the stop flag, the (locus, first row,
+// end row) record of a heavy / light locus, or class, theta, A and length of a plain element, all in flight
+// together; (2) all the slot rows of the locus at once (a light locus has at most HEAVY_SLOTS of them; a heavy
+// workgroup takes 16 rows per thread and round).  The stop flag only guards the stores.
 #ifndef GBRS_MSTEP_EPT
 #define GBRS_MSTEP_EPT 4
 #endif
 constexpr int MSTEP_EPT = GBRS_MSTEP_EPT;       // elements per thread of the elementwise workgroups (measured 1, 2, 4, 8)
-constexpr int GATHER_CHAINS = 4;   // independent loads in flight per lane of a many-slot locus
+constexpr int HEAVY_ROWS = 16;     // slot rows a thread of a heavy workgroup has in flight
 __global__ void __launch_bounds__(RED_THREADS)
-mstep_gather_kernel(uint32_t L, uint32_t H, uint32_t HP, uint32_t heavy_blocks, uint32_t n_heavy,
-                    const uint32_t *__restrict__ slot_ptr, const uint32_t *__restrict__ heavy_loci,
+mstep_gather_kernel(uint32_t L, uint32_t H, uint32_t HP, uint32_t heavy_blocks, uint32_t light_blocks, uint32_t n_light,
+                    const uint32_t *__restrict__ heavy_range, const uint32_t *__restrict__ light_range,
                     const uint8_t *__restrict__ locus_class,
                     const double *__restrict__ slot_sums, const double *__restrict__ acc,
                     const double *__restrict__ acc_extra, double *__restrict__ theta,
@@ -596,30 +605,105 @@ mstep_gather_kernel(uint32_t L, uint32_t H, uint32_t HP, uint32_t heavy_blocks, 
                     const EmScalars *__restrict__ sc) {
     __shared__ double lds[16];
     __shared__ double heavy_part[RED_THREADS / 64][16];
-    if (sc->stop) return;
+    const int stop = sc->stop;          // scalar load, in flight beside the vector loads below; looked at before the stores
     double t = 0.0, tn = 0.0;
-    // the heavy workgroups come first in the grid: their long dependent chains (hundreds of slots per
-    // locus) start at once and overlap with the elementwise workgroups
-    if (blockIdx.x >= heavy_blocks) {
-        // MSTEP_EPT elements per thread, all loads of the batch issued before the arithmetic: the
-        // kernel is a chain of dependent global loads per element, so the win is memory-level
-        // parallelism, not fewer instructions
+    if (blockIdx.x < heavy_blocks) {
+        // one workgroup per many-slot locus: the largest loci of a deep sample have hundreds of slots whose rows
+        // were written by tiles all over the chip a moment ago
+        const uint32_t l = heavy_range[3 * blockIdx.x], k0 = heavy_range[3 * blockIdx.x + 1], k1 = heavy_range[3 * blockIdx.x + 2];
+        const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        const uint32_t h = threadIdx.x & (HP - 1), sub = threadIdx.x / HP, nsub = blockDim.x / HP;
+        const bool live = h < H;
+        const size_t il = (size_t)l * H + (live ? h : 0);
+        const double t_old = theta[il], ax = acc_extra ? acc_extra[il] : 0.0, ln = eff_len ? eff_len[il] : 1.0;
+        double a = 0.0;
+        for (uint32_t k = k0 + sub; k < k1; k += HEAVY_ROWS * nsub) {          // fixed order: rounds, then rows of a round
+            double r[HEAVY_ROWS];
+#pragma unroll
+            for (int m = 0; m < HEAVY_ROWS; ++m) {
+                const uint32_t km = k + (uint32_t)m * nsub;
+                r[m] = (live && km < k1) ? slot_sums[(size_t)km * H + h] : 0.0;
+            }
+#pragma unroll
+            for (int w = 1; w < HEAVY_ROWS; w <<= 1)
+#pragma unroll
+                for (int m = 0; m + w < HEAVY_ROWS; m += 2 * w) r[m] += r[m + w];
+            a += r[0];
+        }
+        for (uint32_t off = HP; off < 64; off <<= 1) a += __shfl_xor(a, off, WAVE);
+        if (lane < (int)HP) heavy_part[wv][lane] = a;        // the wavefronts' partial sums, added in a fixed order
+        __syncthreads();
+        if (wv == 0) {
+            a = 0.0;
+            if (lane < (int)HP)
+                for (uint32_t w2 = 0; w2 < blockDim.x / 64; ++w2) a += heavy_part[w2][lane];
+            const bool mine = lane < (int)HP && live;
+            if (mine) {
+                t = t_old;
+                const double c = t * (a + ax);
+                tn = eff_len ? c / ln : c;
+                if (!stop) {
+                    counts[il] = c;
+                    theta[il] = tn;
+                }
+            }
+            double tp = t, tq = tn;                       // lanes 0 .. H-1 hold the locus, the others 0
+            for (uint32_t off = 1; off < HP; off <<= 1) {
+                tp += __shfl_xor(tp, off, WAVE);
+                tq += __shfl_xor(tq, off, WAVE);
+            }
+            if (lane == 0 && !stop) {
+                tot_prev[l] = tp;
+                tot_new[l] = tq;
+            }
+        }
+    } else if (blockIdx.x < heavy_blocks + light_blocks) {
+        // one thread per (light locus, haplotype): the locus's 2..HEAVY_SLOTS slot rows all at once, added in slot order
+        const uint64_t i = (uint64_t)(blockIdx.x - heavy_blocks) * blockDim.x + threadIdx.x;
+        const bool live = i < (uint64_t)n_light * H;
+        const uint32_t li = live ? (uint32_t)(i / H) : 0, h = (uint32_t)(i & (H - 1));
+        const uint32_t l = light_range[3 * li], k0 = light_range[3 * li + 1], k1 = light_range[3 * li + 2];
+        const size_t il = (size_t)l * H + h;
+        const double t_old = theta[il], ax = acc_extra ? acc_extra[il] : 0.0, ln = eff_len ? eff_len[il] : 1.0;
+        double r[HEAVY_SLOTS];
+#pragma unroll
+        for (int m = 0; m < HEAVY_SLOTS; ++m) r[m] = k0 + m < k1 ? slot_sums[(size_t)(k0 + m) * H + h] : 0.0;
+        double a = ax;
+#pragma unroll
+        for (int m = 0; m < HEAVY_SLOTS; ++m) a += r[m];
+        if (live) {
+            t = t_old;
+            const double c = t * a;
+            tn = eff_len ? c / ln : c;
+            if (!stop) {
+                counts[il] = c;
+                theta[il] = tn;
+            }
+        }
+        double tp = t, tq = tn;                           // the H lanes of a locus are adjacent
+        for (uint32_t off = 1; off < H; off <<= 1) {
+            tp += __shfl_xor(tp, off, WAVE);
+            tq += __shfl_xor(tq, off, WAVE);
+        }
+        if (live && h == 0 && !stop) {
+            tot_prev[l] = tp;
+            tot_new[l] = tq;
+        }
+    } else {
+        // MSTEP_EPT elements per thread of the loci with at most one slot: class, theta, A and length in one batch of
+        // loads, no second round trip
         const uint64_t n = (uint64_t)L * H;
-        const uint64_t i0 = (uint64_t)(blockIdx.x - heavy_blocks) * MSTEP_EPT * blockDim.x + threadIdx.x;
-        uint32_t cls[MSTEP_EPT], kb[MSTEP_EPT], ke[MSTEP_EPT];
+        const uint64_t i0 = (uint64_t)(blockIdx.x - heavy_blocks - light_blocks) * MSTEP_EPT * blockDim.x + threadIdx.x;
+        uint32_t cls[MSTEP_EPT];
         double av[MSTEP_EPT], tv[MSTEP_EPT], lv[MSTEP_EPT];
 #pragma unroll
         for (int e = 0; e < MSTEP_EPT; ++e) {
             const uint64_t i = i0 + (uint64_t)e * blockDim.x;
             cls[e] = 3;
-            kb[e] = ke[e] = 0;
             av[e] = tv[e] = 0.0;
             lv[e] = 1.0;
             if (i < n) {
-                const uint32_t l = (uint32_t)(i / H);
-                cls[e] = locus_class[l];
-                kb[e] = slot_ptr[l];                      // with the first batch of loads, not after the class is known
-                ke[e] = slot_ptr[l + 1];
+                cls[e] = locus_class[(uint32_t)(i / H)];
                 tv[e] = theta[i];
                 av[e] = acc[i];                           // one slot: stored by its tile; none: stays 0
                 if (acc_extra) av[e] += acc_extra[i];
@@ -630,102 +714,33 @@ mstep_gather_kernel(uint32_t L, uint32_t H, uint32_t HP, uint32_t heavy_blocks, 
         for (int e = 0; e < MSTEP_EPT; ++e) {
             const uint64_t i = i0 + (uint64_t)e * blockDim.x;
             const uint32_t l = (uint32_t)(i / H), h = (uint32_t)(i & (H - 1));
+            const bool mine = i < n && cls[e] < 2;        // classes 2 and 3: the workgroups above
             double te = 0.0, tne = 0.0;
-            if (i < n && cls[e] != 3) {                   // class 3: the heavy workgroups
-                double a = av[e];
-                if (cls[e] == 2) {                        // a few slots: summed in place, in slot order, four loads in flight
-                    a = acc_extra ? acc_extra[i] : 0.0;
-                    const double *sp = slot_sums + h;
-                    uint32_t k = kb[e];
-                    const uint32_t k1 = ke[e];
-                    for (; k + 3 < k1; k += 4) {
-                        const double s0 = sp[(size_t)k * H], s1 = sp[(size_t)(k + 1) * H], s2 = sp[(size_t)(k + 2) * H],
-                                     s3 = sp[(size_t)(k + 3) * H];
-                        a += s0;
-                        a += s1;
-                        a += s2;
-                        a += s3;
-                    }
-                    for (; k < k1; ++k) a += sp[(size_t)k * H];
-                }
+            if (mine) {
                 te = tv[e];
-                const double c = te * a;
+                const double c = te * av[e];
                 tne = eff_len ? c / lv[e] : c;
-                counts[i] = c;
-                theta[i] = tne;
+                if (!stop) {
+                    counts[i] = c;
+                    theta[i] = tne;
+                }
             }
             double tp = te, tq = tne;                     // the H lanes of a locus are adjacent, same class
             for (uint32_t off = 1; off < H; off <<= 1) {
                 tp += __shfl_xor(tp, off, WAVE);
                 tq += __shfl_xor(tq, off, WAVE);
             }
-            if (i < n && h == 0 && cls[e] != 3) {
+            if (mine && h == 0 && !stop) {
                 tot_prev[l] = tp;
                 tot_new[l] = tq;
             }
             t += te;
             tn += tne;
         }
-    } else {
-        // one workgroup per many-slot locus: the largest loci of a deep sample have hundreds of slots whose rows
-        // were written by tiles all over the chip a moment ago - every load is a ~0.6 us miss, so the time of the
-        // whole launch is the number of dependent rounds of its largest locus (one wavefront per locus: 23
-        // rounds for 730 slots; four wavefronts: 6)
-        const uint32_t hv = blockIdx.x;
-        if (hv < n_heavy) {
-            const uint32_t l = heavy_loci[hv];
-            const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-            const uint32_t h = threadIdx.x & (HP - 1), sub = threadIdx.x / HP, nsub = blockDim.x / HP;
-            const uint32_t k0 = slot_ptr[l], k1 = slot_ptr[l + 1];
-            double a = 0.0;
-            if (h < H) {
-                // GATHER_CHAINS independent chains per lane over the locus's consecutive slot rows
-                double ac[GATHER_CHAINS];
-#pragma unroll
-                for (int c = 0; c < GATHER_CHAINS; ++c) ac[c] = 0.0;
-                uint32_t k = k0 + sub;
-                for (; k + (GATHER_CHAINS - 1) * nsub < k1; k += GATHER_CHAINS * nsub) {
-#pragma unroll
-                    for (int c = 0; c < GATHER_CHAINS; ++c) ac[c] += slot_sums[(size_t)(k + c * nsub) * H + h];
-                }
-                for (; k < k1; k += nsub) ac[0] += slot_sums[(size_t)k * H + h];
-#pragma unroll
-                for (int w = 1; w < GATHER_CHAINS; w <<= 1)
-#pragma unroll
-                    for (int c = 0; c + w < GATHER_CHAINS; c += 2 * w) ac[c] += ac[c + w];
-                a = ac[0];
-            }
-            for (uint32_t off = HP; off < 64; off <<= 1) a += __shfl_xor(a, off, WAVE);
-            if (lane < (int)HP) heavy_part[wv][lane] = a;        // the wavefronts' partial sums, added in a fixed order
-            __syncthreads();
-            if (wv == 0) {
-                a = 0.0;
-                if (lane < (int)HP)
-                    for (uint32_t w2 = 0; w2 < blockDim.x / 64; ++w2) a += heavy_part[w2][lane];
-                if (lane < (int)HP && h < H) {
-                    const size_t i = (size_t)l * H + h;
-                    if (acc_extra) a += acc_extra[i];
-                    t = theta[i];
-                    const double c = t * a;
-                    tn = eff_len ? c / eff_len[i] : c;
-                    counts[i] = c;
-                    theta[i] = tn;
-                }
-                double tp = t, tq = tn;                       // lanes 0 .. H-1 hold the locus, the others 0
-                for (uint32_t off = 1; off < HP; off <<= 1) {
-                    tp += __shfl_xor(tp, off, WAVE);
-                    tq += __shfl_xor(tq, off, WAVE);
-                }
-                if (lane == 0) {
-                    tot_prev[l] = tp;
-                    tot_new[l] = tq;
-                }
-            }
-        }
     }
     const double a = block_sum(t, lds);
     const double b = block_sum(tn, lds);
-    if (threadIdx.x == 0) {
+    if (threadIdx.x == 0 && !stop) {
         msums[blockIdx.x] = a;
         msums[cap + blockIdx.x] = b;
     }
@@ -795,9 +810,10 @@ int em_launch_mstep_gather(gbrs_em *em) {
     const uint64_t n = (uint64_t)em->L * em->H;
     const unsigned elem_blocks = (unsigned)((n + (uint64_t)RED_THREADS * MSTEP_EPT - 1) / ((uint64_t)RED_THREADS * MSTEP_EPT));
     const unsigned heavy_blocks = (unsigned)tl.n_heavy;         // one workgroup per many-slot locus
-    em->msum_blocks = elem_blocks + heavy_blocks;
-    hipLaunchKernelGGL(mstep_gather_kernel, dim3(elem_blocks + heavy_blocks), dim3(RED_THREADS), 0, em->stream, em->L,
-                       em->H, HP, heavy_blocks, (uint32_t)tl.n_heavy, tl.slot_ptr.p, tl.heavy_loci.p,
+    const unsigned light_blocks = (unsigned)((tl.n_light * em->H + RED_THREADS - 1) / RED_THREADS);
+    em->msum_blocks = elem_blocks + heavy_blocks + light_blocks;
+    hipLaunchKernelGGL(mstep_gather_kernel, dim3(em->msum_blocks), dim3(RED_THREADS), 0, em->stream, em->L,
+                       em->H, HP, heavy_blocks, light_blocks, (uint32_t)tl.n_light, tl.heavy_range.p, tl.light_range.p,
                        tl.locus_class.p, tl.partials.p, em->acc.p,
                        tl.n_long ? tl.acc_extra.p : (const double *)nullptr, em->theta.p,
                        em->has_len ? em->eff_len.p : (const double *)nullptr, em->counts.p, em->tot_prev.p,
@@ -875,6 +891,7 @@ int em_reset_scalars(gbrs_em *em, bool keep_iters) {
         GBRS_HIP_CHECK(hipStreamSynchronize(em->stream));
         host.iters_done = cur.iters_done;
     }
+    em->stopped = false;
     GBRS_HIP_CHECK(hipMemcpyAsync(em->scalars.p, &host, sizeof(host), hipMemcpyHostToDevice, em->stream));
     GBRS_HIP_CHECK(hipStreamSynchronize(em->stream));
     return GBRS_OK;
@@ -1007,7 +1024,7 @@ int em_create_impl(uint64_t R, uint32_t L, uint32_t H, const uint32_t *const *in
     GBRS_TRY(em->tot_prev.alloc(L));
     GBRS_TRY(em->tot_new.alloc(L));
     GBRS_TRY(em->partials.alloc(3 * RED_BLOCKS));
-    em->msum_cap = (uint32_t)(((uint64_t)L * H + RED_THREADS - 1) / RED_THREADS + L + RED_BLOCKS);   // elementwise workgroups + one per many-slot locus
+    em->msum_cap = (uint32_t)(((uint64_t)L * H + RED_THREADS - 1) / RED_THREADS * 2 + L + RED_BLOCKS);   // elementwise + light workgroups + one per many-slot locus
     GBRS_TRY(em->msums.alloc(2 * (size_t)em->msum_cap + ERR_BLOCKS));
     GBRS_TRY(em->scalars.alloc(1));
     GBRS_HIP_CHECK(hipMemset(em->scalars.p, 0, sizeof(EmScalars)));
@@ -1299,6 +1316,9 @@ int gbrs_em_step(gbrs_em_t *em, int n_iters, double *err_sum_out) {
     if (!em) return fail(GBRS_ERR_INVALID, "handle is NULL");
     if (!em->prepared) return fail(GBRS_ERR_STATE, "prepare() has not been called");
     GBRS_TRY(select_device(em->device));
+    // a run that met its stopping rule left the device's stop flag set; a step asked for by hand is applied anyway
+    // (EMfactory.update_allelic_expression knows no stopping rule)
+    if (em->stopped) GBRS_TRY(em_reset_scalars(em, true));
     const int timed = em->time_steps ? std::min((n_iters + EM_TIME_STRIDE - 1) / EM_TIME_STRIDE, 64) : 0;
     while ((int)em->ev_pool.size() < 3 * timed) {
         hipEvent_t e;

@@ -22,7 +22,10 @@
 
 namespace gbrs {
 
-constexpr int TILE_THREADS = 512;              // 8 waves per workgroup
+#ifndef GBRS_TILE_THREADS
+#define GBRS_TILE_THREADS 512
+#endif
+constexpr int TILE_THREADS = GBRS_TILE_THREADS;   // 8 waves per workgroup
 constexpr int TILE_WAVES = TILE_THREADS / 64;
 #ifndef GBRS_TILE_CAP
 #define GBRS_TILE_CAP 16384                    // capacity of the per-tile dictionary sort (words incl. padding)
@@ -90,6 +93,9 @@ struct TileLayout {
     DevBuf<uint32_t> slot_list;      // n_slots, grouped by locus, ascending slot inside a locus
     DevBuf<uint32_t> heavy_loci;     // loci with more than HEAVY_SLOTS slots
     DevBuf<uint32_t> light_loci;     // loci with 2..HEAVY_SLOTS slots
+    // (locus, first slot row, end slot row) of every heavy / light locus, 3 words each: what the fused gather + M-step
+    // launch reads first, so that its slot rows are one dependent load away instead of three (list -> slot_ptr -> rows)
+    DevBuf<uint32_t> heavy_range, light_range;
     DevBuf<uint32_t> slot_dest;      // n_slots: where the tile epilogue stores a slot: its own index in
                                      // `partials`, or SLOT_DIRECT | locus when the locus has this one slot only
     DevBuf<uint8_t> locus_class;     // L: 0 no slot, 1 one slot (sum goes straight to acc), 2 few, 3 heavy

@@ -1134,6 +1134,20 @@ int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L, uint32_t H, uint6
             else if (sp[l + 1] - sp[l] >= 2) lightv.push_back(l);
         out.n_heavy = heavy.size();
         out.n_light = lightv.size();
+        for (int which = 0; which < 2; ++which) {
+            const std::vector<uint32_t> &loci = which == 0 ? heavy : lightv;
+            DevBuf<uint32_t> &dst = which == 0 ? out.heavy_range : out.light_range;
+            std::vector<uint32_t> rng;
+            rng.reserve(loci.size() * 3);
+            for (uint32_t l : loci) {
+                rng.push_back(l);
+                rng.push_back(sp[l]);
+                rng.push_back(sp[l + 1]);
+            }
+            GBRS_TRY(dst.alloc(std::max<size_t>(rng.size(), 3)));
+            if (!rng.empty()) GBRS_HIP_CHECK(hipMemcpyAsync(dst.p, rng.data(), rng.size() * 4, hipMemcpyHostToDevice, s));
+            GBRS_HIP_CHECK(hipStreamSynchronize(s));          // rng goes out of scope
+        }
         GBRS_TRY(out.light_loci.alloc(std::max<size_t>(lightv.size(), 1)));
         if (!lightv.empty())
             GBRS_HIP_CHECK(hipMemcpyAsync(out.light_loci.p, lightv.data(), lightv.size() * 4, hipMemcpyHostToDevice, s));

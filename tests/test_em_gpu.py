@@ -171,6 +171,29 @@ def test_masked_create_argument_checks(hip_lib):
     hip_lib.gbrs_em_destroy(h)
 
 
+def test_single_step_after_a_run_that_stopped():
+    """EMfactory.update_allelic_expression knows no stopping rule (EMfactory.py:214-232): called after run() has met
+    its tolerance it still applies one more EM step (the device's stop flag of the finished run must not turn the
+    step's kernels into no-ops)."""
+    from oracle.em_oracle import EMOracle
+    g = load_golden([p for p in golden_files("em") if p.endswith("em_h8_len.npz")][0])
+    R, L, H, indptr, indices, count, eff_len, groups, gtmask = em_case_inputs(g)
+    for layout in ("tiles", "csc", "tiles_deterministic"):
+        em = make_factory(g, layout)
+        em.prepare(pseudocount=0.0)
+        em.run(model=4, tol=float(g["tol"]), max_iters=int(g["max_iters"]), verbose=False)
+        assert em.num_iters == int(g["num_iters"])
+        close(em.allelic_expression, g["theta_final"])
+        em.update_allelic_expression(model=4)
+        o = EMOracle(R, L, H, indptr, indices, count)
+        o.prepare(0.0, eff_len)
+        o.theta = np.array(g["theta_final"])
+        o.em_step()
+        close(em.allelic_expression, o.theta)
+        assert not np.allclose(em.allelic_expression, g["theta_final"], rtol=1e-12, atol=0)
+        em.close()
+
+
 def test_em_c1_shape_vs_oracle():
     """BASELINE config 1 (100k reads / 2 haplotypes / 5k isoforms) against the oracle."""
     from gbrs_amd import synth
