@@ -6,7 +6,7 @@ R=$PWD
 mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-B="$R/bench.py --no-e2e --no-cpu-baseline --no-hmm --no-merged-line --no-check"
+B="$R/bench.py --no-e2e --no-cpu-baseline --no-hmm --no-merged-line --no-multi-isoform-line --no-check"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 $B --steps 20 --warmup 2 "$@" > $OUT/kt.log 2>&1
 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAVE_CYCLES SQ_BUSY_CYCLES --output-format csv -d $OUT/pmc_sq -- python3 $B --steps 3 --warmup 1 "$@" > $OUT/pmc_sq.log 2>&1
 rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_VMEM_RD SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT --output-format csv -d $OUT/pmc_sq2 -- python3 $B --steps 3 --warmup 1 "$@" > $OUT/pmc_sq2.log 2>&1
