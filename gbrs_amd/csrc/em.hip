@@ -199,6 +199,51 @@ err_finish_kernel(ErrArgs ea) {
     err_finish_body(ea, blockIdx.x);
 }
 
+// The stopping rule of EMfactory.run (EMfactory.py:266-278) over TWO handles that hold the two locus ranges of one
+// sample (gbrs_amd/dist.py PipelinedShardedEM): err_sum = sum over the loci of both ranges of
+// | tot_new * 1e6 / S_new - tot_prev * 1e6 / S_prev | with S the totals over both.  One workgroup; when the sum is at or
+// under the target it raises both handles' stop flags, so that every later kernel of either handle is a no-op and theta
+// stays the stopping iteration's.
+struct PairSide {
+    uint32_t L;
+    int nblocks;
+    uint32_t cap;
+    const double *tot_prev, *tot_new, *msums;
+    EmScalars *sc;
+};
+struct PairState { int iters, stop; double err; };
+__global__ void __launch_bounds__(1024)
+pair_err_kernel(PairSide a, PairSide b, double target_err, PairState *__restrict__ ps, double *__restrict__ hist,
+                int hist_cap) {
+    __shared__ double lds[16];
+    __shared__ double s_sum[2];
+    if (ps->stop) return;
+    double sp = 0.0, sn = 0.0;
+    for (int i = threadIdx.x; i < a.nblocks; i += blockDim.x) { sp += a.msums[i]; sn += a.msums[a.cap + i]; }
+    for (int i = threadIdx.x; i < b.nblocks; i += blockDim.x) { sp += b.msums[i]; sn += b.msums[b.cap + i]; }
+    sp = block_sum(sp, lds);
+    sn = block_sum(sn, lds);
+    if (threadIdx.x == 0) { s_sum[0] = sp; s_sum[1] = sn; }
+    __syncthreads();
+    const double cp = 1000000.0 / s_sum[0], cn = 1000000.0 / s_sum[1];
+    double e = 0.0;
+    for (uint32_t l = threadIdx.x; l < a.L; l += blockDim.x) e += fabs(a.tot_new[l] * cn - a.tot_prev[l] * cp);
+    for (uint32_t l = threadIdx.x; l < b.L; l += blockDim.x) e += fabs(b.tot_new[l] * cn - b.tot_prev[l] * cp);
+    e = block_sum(e, lds);
+    if (threadIdx.x == 0) {
+        const int it = ps->iters;
+        if (hist && it < hist_cap) hist[it] = e;
+        ps->iters = it + 1;
+        ps->err = e;
+        if (!(e > target_err)) {
+            ps->stop = 1;
+            a.sc->stop = 1;
+            b.sc->stop = 1;
+        }
+        if (!(s_sum[0] > 0.0) || !(s_sum[1] > 0.0) || e != e) a.sc->float_error = 1;
+    }
+}
+
 // pseudocount rule, EMfactory.py:105-111: every haplotype of a locus with any nonzero haplotype
 // gets +pc, then the whole matrix is rescaled to its previous total.
 __global__ void __launch_bounds__(RED_THREADS)
@@ -464,6 +509,15 @@ struct gbrs_em {
     double err_pending_target = -1.0;
     hipEvent_t ev_after_estep = nullptr;      // timed step: recorded between the E-step kernels and the gather
     std::vector<hipEvent_t> ev_pool;                   // 3 events per timed step of gbrs_em_step
+
+    // Pair mode (gbrs_em_pair_*): this handle and a partner hold the two locus ranges of one sample; the stopping rule is
+    // evaluated over both on the device.  The first handle of the pair owns the state.
+    struct PairScalars { int iters, stop; double err; };
+    DevBuf<PairScalars> pair_sc;
+    DevBuf<double> pair_hist;
+    int pair_hist_cap = 0;
+    hipEvent_t pair_ev_mstep = nullptr;    // recorded after every M-step of a handle in pair mode
+    hipEvent_t pair_ev_err = nullptr;      // recorded after the pair's error pass (first handle)
 
     int red_blocks() const { return (int)std::min<uint64_t>(RED_BLOCKS, (L + RED_THREADS - 1) / RED_THREADS); }
 };
@@ -1304,6 +1358,7 @@ int gbrs_em_finish_step(gbrs_em_t *em, double *err_sum_out) {
     GBRS_TRY(select_device(em->device));
     // without a request for err_sum the error pass is deferred into the next E-step launch
     GBRS_TRY(em_finish_step(em, -1.0, /* defer */ err_sum_out == nullptr));
+    if (em->pair_ev_mstep) GBRS_HIP_CHECK(hipEventRecord(em->pair_ev_mstep, em->stream));
     if (err_sum_out) {
         EmScalars host;
         GBRS_TRY(em_check_float(em, host));
@@ -1469,6 +1524,58 @@ int gbrs_em_sync(gbrs_em_t *em) {
     return GBRS_OK;
 }
 
+int gbrs_em_pair_begin(gbrs_em_t *a, gbrs_em_t *b, int max_iters) {
+    if (!a || !b || a == b) return fail(GBRS_ERR_INVALID, "two distinct handles are needed");
+    if (a->device != b->device) return fail(GBRS_ERR_INVALID, "the two handles of a pair live on one device");
+    GBRS_TRY(select_device(a->device));
+    for (gbrs_em *em : {a, b}) {
+        GBRS_TRY(em_reset_scalars(em, false));           // (synchronises the handle's stream)
+        if (!em->pair_ev_mstep) GBRS_HIP_CHECK(hipEventCreateWithFlags(&em->pair_ev_mstep, hipEventDisableTiming));
+    }
+    if (!a->pair_ev_err) GBRS_HIP_CHECK(hipEventCreateWithFlags(&a->pair_ev_err, hipEventDisableTiming));
+    const int cap = std::max(max_iters, 1);
+    if (!a->pair_sc.p) GBRS_TRY(a->pair_sc.alloc(1));
+    if (cap > a->pair_hist_cap) {
+        GBRS_TRY(a->pair_hist.alloc((size_t)cap));
+        a->pair_hist_cap = cap;
+    }
+    GBRS_HIP_CHECK(hipMemset(a->pair_sc.p, 0, sizeof(gbrs_em::PairScalars)));
+    return GBRS_OK;
+}
+
+int gbrs_em_pair_check(gbrs_em_t *a, gbrs_em_t *b, double tol) {
+    if (!a || !b || !a->pair_sc.p || !a->pair_ev_err || !a->pair_ev_mstep || !b->pair_ev_mstep)
+        return fail(GBRS_ERR_STATE, "gbrs_em_pair_begin has not been called on this pair");
+    GBRS_TRY(select_device(a->device));
+    // on b's stream (whose M-step has just been enqueued), after a's M-step; a's next M-step waits for the verdict
+    GBRS_HIP_CHECK(hipStreamWaitEvent(b->stream, a->pair_ev_mstep, 0));
+    static_assert(sizeof(PairState) == sizeof(gbrs_em::PairScalars), "one struct, two names");
+    const PairSide sa{a->L, (int)a->msum_blocks, a->msum_cap, a->tot_prev.p, a->tot_new.p, a->msums.p, a->scalars.p};
+    const PairSide sb{b->L, (int)b->msum_blocks, b->msum_cap, b->tot_prev.p, b->tot_new.p, b->msums.p, b->scalars.p};
+    hipLaunchKernelGGL(pair_err_kernel, dim3(1), dim3(1024), 0, b->stream, sa, sb, 1000000.0 * tol,
+                       reinterpret_cast<PairState *>(a->pair_sc.p), a->pair_hist.p, a->pair_hist_cap);
+    GBRS_HIP_CHECK(hipGetLastError());
+    GBRS_HIP_CHECK(hipEventRecord(a->pair_ev_err, b->stream));
+    GBRS_HIP_CHECK(hipStreamWaitEvent(a->stream, a->pair_ev_err, 0));
+    return GBRS_OK;
+}
+
+int gbrs_em_pair_status(gbrs_em_t *a, gbrs_em_t *b, int *iters_done, int *stopped, double *err_hist, int err_hist_cap) {
+    if (!a || !b || !a->pair_sc.p) return fail(GBRS_ERR_STATE, "gbrs_em_pair_begin has not been called on this pair");
+    GBRS_TRY(select_device(a->device));
+    EmScalars ha, hb;
+    GBRS_TRY(em_check_float(a, ha));                     // flushes deferred passes, synchronises, reports 0/0
+    GBRS_TRY(em_check_float(b, hb));
+    gbrs_em::PairScalars ps;
+    GBRS_HIP_CHECK(hipMemcpy(&ps, a->pair_sc.p, sizeof(ps), hipMemcpyDeviceToHost));
+    if (iters_done) *iters_done = ps.iters;
+    if (stopped) *stopped = ps.stop;
+    if (err_hist && err_hist_cap > 0 && ps.iters > 0)
+        GBRS_HIP_CHECK(hipMemcpy(err_hist, a->pair_hist.p, std::min(ps.iters, std::min(err_hist_cap, a->pair_hist_cap)) * sizeof(double),
+                                 hipMemcpyDeviceToHost));
+    return GBRS_OK;
+}
+
 int gbrs_em_info(gbrs_em_t *em, gbrs_em_info_t *info) {
     if (!em || !info) return fail(GBRS_ERR_INVALID, "NULL argument");
     std::memset(info, 0, sizeof(*info));
@@ -1561,6 +1668,8 @@ int gbrs_em_destroy(gbrs_em_t *em) {
     if (em->ev1) (void)hipEventDestroy(em->ev1);
     if (em->ev2) (void)hipEventDestroy(em->ev2);
     for (auto e : em->ev_pool) (void)hipEventDestroy(e);
+    if (em->pair_ev_mstep) (void)hipEventDestroy(em->pair_ev_mstep);
+    if (em->pair_ev_err) (void)hipEventDestroy(em->pair_ev_err);
     if (em->stream && em->own_stream) (void)hipStreamDestroy(em->stream);
     delete em;
     return GBRS_OK;

@@ -151,9 +151,12 @@ class PipelinedShardedEM:
     HIP stream of its own and issues the collective in line on that stream - wait() is then a no-op and the
     two ranges overlap on the device without any handle: 114 us instead of 184 us per iteration with a
     one-rank RCCL group, scripts/pipelined_host_cost.py.)  pseudocount must be 0
-    (its renormalisation couples the ranges); the stopping rule is evaluated on the host every
-    `check_every` iterations, so a run may go up to check_every - 1 iterations past the reference's
-    stopping point - use ShardedEM when the iteration count has to match."""
+    (its renormalisation couples the ranges).
+
+    run() applies the reference's stopping rule (EMfactory.py:266-278) over BOTH ranges after every iteration, on
+    the device (gbrs_em_pair_check: the two engines of a rank share one stop flag), and looks at the result every
+    `check_every` iterations; iterations enqueued past the stopping one are no-ops, so the iteration count, the err_sum
+    sequence and theta are those of ShardedEM and of the reference."""
 
     def __init__(self, engine_a, engine_b, start_allreduce):
         self.eng = (engine_a, engine_b)
@@ -189,11 +192,11 @@ class PipelinedShardedEM:
         parts = [e.theta() if callable(e.theta) else e.theta for e in self.eng]
         return np.concatenate([np.asarray(parts[0]), np.asarray(parts[1])], axis=1)
 
-    @staticmethod
-    def _err_sum(prev, cur):        # EMfactory.py:268-278
-        a = prev.sum(axis=0)
-        b = cur.sum(axis=0)
-        return float(np.abs(b * (1e6 / b.sum()) - a * (1e6 / a.sum())).sum())
+    def _pair(self):
+        """The shared stopping rule of the two engines: on the device for HIP engines (EmEngine.pair_*), on the host
+        for engines that keep their per-locus totals in numpy (the CPU tests' stand-in)."""
+        a, b = self.eng
+        return _DevicePair(a, b) if hasattr(a, 'pair_check') else _HostPair(a, b)
 
     def run(self, model=4, tol=0.001, max_iters=999, check_every=8):
         if model != 4:
@@ -201,14 +204,66 @@ class PipelinedShardedEM:
                                else f'Multiread model {model} is not implemented by the MI355X path')
         self.num_iters = 0
         self.err_history = []
-        target = 1000000.0 * tol
-        while self.num_iters < max_iters:
-            k = min(check_every, max_iters - self.num_iters)
-            self.step(k - 1)
-            prev = self.theta()
-            self.step(1)
-            err = self._err_sum(prev, self.theta())
-            self.err_history.append(err)
-            if err <= target:
+        if max_iters <= 0 or not 1000000.0 > 1000000.0 * tol:
+            return 0
+        pair = self._pair()
+        pair.begin(max_iters)
+        enqueued = 0
+        while enqueued < max_iters:
+            k = min(check_every, max_iters - enqueued)
+            # k iterations with the rule evaluated after each: E-steps and all-reduces interleave as in step()
+            pend = [self.start(*e.estep_partial()) for e in self.eng]
+            for it in range(k):
+                for i, e in enumerate(self.eng):
+                    pend[i].wait()
+                    e.finish_step(want_err=False)
+                    if i == 1:
+                        pair.check(tol)            # after both M-steps of the iteration, before b's next E-step
+                    if it + 1 < k:
+                        pend[i] = self.start(*e.estep_partial())
+            enqueued += k
+            done, stopped, hist = pair.status(max_iters)
+            self.num_iters, self.err_history = done, [float(x) for x in hist]
+            if stopped:
                 break
         return self.num_iters
+
+
+class _DevicePair:
+    def __init__(self, a, b):
+        self.a, self.b = a, b
+
+    def begin(self, max_iters):
+        self.a.pair_begin(self.b, max_iters)
+
+    def check(self, tol):
+        self.a.pair_check(self.b, tol)
+
+    def status(self, cap):
+        return self.a.pair_status(self.b, cap)
+
+
+class _HostPair:
+    """The same rule for engines that expose `last_totals` = (per-locus totals before, after) of their last M-step and
+    honour a `stopped` attribute (tests/cpu_engine.py)."""
+
+    def __init__(self, a, b):
+        self.a, self.b = a, b
+        self.hist, self.stopped = [], False
+
+    def begin(self, max_iters):
+        self.hist, self.stopped = [], False
+        self.a.stopped = self.b.stopped = False
+
+    def check(self, tol):
+        if self.stopped:
+            return
+        prev = np.concatenate([self.a.last_totals[0], self.b.last_totals[0]])
+        cur = np.concatenate([self.a.last_totals[1], self.b.last_totals[1]])
+        err = float(np.abs(cur * (1e6 / cur.sum()) - prev * (1e6 / prev.sum())).sum())
+        self.hist.append(err)
+        if not err > 1000000.0 * tol:
+            self.stopped = self.a.stopped = self.b.stopped = True
+
+    def status(self, cap):
+        return len(self.hist), self.stopped, np.asarray(self.hist[:cap])

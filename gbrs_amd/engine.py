@@ -153,6 +153,20 @@ class EmEngine:
     def sync(self):
         _lib.check(_lib.load().gbrs_em_sync(self._h))
 
+    # ---- the stopping rule over two handles (the two locus ranges of one sample) ---------------
+    def pair_begin(self, other, max_iters):
+        _lib.check(_lib.load().gbrs_em_pair_begin(self._h, other._h, int(max_iters)))
+
+    def pair_check(self, other, tol):
+        _lib.check(_lib.load().gbrs_em_pair_check(self._h, other._h, float(tol)))
+
+    def pair_status(self, other, cap):
+        """(iterations applied, stopped, err_sum sequence) - synchronises both handles."""
+        it, st = C.c_int(0), C.c_int(0)
+        hist = np.zeros(max(int(cap), 1), dtype=np.float64)
+        _lib.check(_lib.load().gbrs_em_pair_status(self._h, other._h, C.byref(it), C.byref(st), _lib.ptr(hist), len(hist)))
+        return int(it.value), bool(st.value), hist[:min(int(it.value), len(hist))].copy()
+
     def stream(self):
         return _lib.load().gbrs_em_stream(self._h)
 

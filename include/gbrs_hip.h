@@ -201,6 +201,19 @@ void *gbrs_em_stream(gbrs_em_t *em);
 int gbrs_em_set_stream(gbrs_em_t *em, void *stream);
 int gbrs_em_sync(gbrs_em_t *em);
 
+/* Two handles that hold the two locus ranges of ONE sample (cut where no row straddles, GBRS_EM_SIDE_BY_SIDE; the two
+ * engines of a rank in gbrs_amd/dist.py PipelinedShardedEM) share only the stopping rule of EMfactory.run
+ * (emase/EMfactory.py:266-278): err_sum runs over the loci of both, scaled by the totals of both.  These calls evaluate
+ * it on the device, with no host synchronisation in the loop, so that the pair stops at the reference's iteration:
+ *   pair_begin   clears both handles' step scalars and the pair's counters (max_iters sizes the error history)
+ *   pair_check   after gbrs_em_finish_step of BOTH handles for an iteration (a's first): enqueues the rule on b's
+ *                stream behind a's M-step; when err_sum <= 1e6 * tol it raises both handles' stop flags - every later
+ *                kernel of either is a no-op, theta stays the stopping iteration's; a's next M-step waits for it
+ *   pair_status  synchronises and returns the iterations applied, the stop flag and the err_sum sequence */
+int gbrs_em_pair_begin(gbrs_em_t *a, gbrs_em_t *b, int max_iters);
+int gbrs_em_pair_check(gbrs_em_t *a, gbrs_em_t *b, double tol);
+int gbrs_em_pair_status(gbrs_em_t *a, gbrs_em_t *b, int *iters_done, int *stopped, double *err_hist, int err_hist_cap);
+
 typedef struct gbrs_em_info {
     uint64_t num_rows;          /* R as given                                               */
     uint64_t num_entries;       /* N = sum_h nnz_h                                          */

@@ -13,6 +13,8 @@ class NumpyEngine:
         self.theta = np.ones((H, L))
         self.acc = np.zeros((H, L))
         self.counts = np.zeros((H, L))
+        self.stopped = False          # set by the pair's stopping rule (gbrs_amd.dist._HostPair): later steps are no-ops
+        self.last_totals = None       # per-locus totals (before, after) of the last M-step
 
     def _estep(self, theta):
         den = np.zeros(self.R)
@@ -49,11 +51,15 @@ class NumpyEngine:
         return self._estep(self.theta)
 
     def finish_step(self, want_err=True):
+        if self.stopped:
+            return 0.0
+        self.last_totals = (self.theta.sum(axis=0), None)
         prev = self.theta.sum(axis=0)
         prev = prev * (1e6 / prev.sum())
         self.counts = self.theta * self.acc
         new = self.counts / self.eff_len if self.eff_len is not None else self.counts.copy()
         self.theta = new
+        self.last_totals = (self.last_totals[0], new.sum(axis=0))
         cur = new.sum(axis=0)
         cur = cur * (1e6 / cur.sum())
         return float(np.abs(cur - prev).sum())

@@ -489,7 +489,13 @@ def _pipelined_worker(rank, world, port, path, out_dir):
     drv = PipelinedShardedEM(engs[0], engs[1], start_allreduce)
     drv.prepare(0.0)
     drv.step(int(g["num_iters"]))
-    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), theta=drv.theta(), l_split=l_split)
+    theta_fixed = drv.theta()
+    # the reference's stopping rule over both ranges, evaluated on the device after every iteration (gbrs_em_pair_check)
+    # and read every 8: iterations enqueued past the stopping one must be no-ops
+    drv.prepare(0.0)
+    n = drv.run(model=4, tol=float(g["tol"]), max_iters=int(g["max_iters"]), check_every=8)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), theta=theta_fixed, l_split=l_split, n=n, theta_run=drv.theta(),
+             err=np.array(drv.err_history))
     for e in engs:
         e.close()
     dist.barrier()
@@ -510,6 +516,10 @@ def test_two_rank_pipelined_hip_engines(tmp_path):
     np.testing.assert_array_equal(a["theta"], b["theta"])
     assert 0 < int(a["l_split"]) < int(g["num_loci"])
     close(a["theta"], g["theta_final"])
+    assert int(a["n"]) == int(b["n"]) == int(g["num_iters"])
+    np.testing.assert_allclose(a["err"], g["err_history"], rtol=1e-7)
+    np.testing.assert_array_equal(a["theta_run"], b["theta_run"])
+    close(a["theta_run"], g["theta_final"])
 
 
 def _random_rows_problem(R, H, L, seed, min_loci, max_loci, with_count):
