@@ -155,7 +155,7 @@ def _host_signatures():
         "gbrs_format_double": [dbl, C.c_char_p],
         "gbrs_decode_chunks": [C.c_char_p, i64, vp, vp, vp, vp, u64, u32, u64, i32, i32, vp, i32],
         "gbrs_inflate_backend": [],
-        "gbrs_zip_directory": [vp, u64, u64, vp, vp, vp, vp, vp, u64, C.POINTER(u64), C.POINTER(u64)],
+        "gbrs_zip_directory": [vp, u64, u64, vp, vp, vp, vp, vp, vp, u64, C.POINTER(u64), C.POINTER(u64)],
         "gbrs_npz_stack": [vp, u64, i64, vp, vp, vp, vp, vp, u64, u64, vp, vp, i32],
         "gbrs_zip_read_members": [vp, u64, i64, vp, vp, vp, vp, vp, i32],
         "gbrs_parse_number_table": [C.c_char_p, i64, i64, i32, vp],

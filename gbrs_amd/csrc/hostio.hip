@@ -205,7 +205,7 @@ int gbrs_decode_chunks(const char *path, int64_t n_chunks, const uint64_t *file_
     const int fd = open(path, O_RDONLY);
     if (fd < 0) return fail(GBRS_ERR_INVALID, "cannot open %s", path);
     for (int64_t k = 0; k < n_chunks; ++k)
-        if (elem_start[k] >= n_elems && n_elems) { close(fd); return fail(GBRS_ERR_INVALID, "chunk %lld starts outside the dataset", (long long)k); }
+        if (elem_start[k] >= n_elems) { close(fd); return fail(GBRS_ERR_INVALID, "chunk %lld starts outside the dataset", (long long)k); }   // (also: chunks of an empty dataset)
     unsigned nt = threads > 0 ? (unsigned)threads : std::thread::hardware_concurrency();
     if (const char *e = std::getenv("GBRS_IO_THREADS"); threads <= 0 && e && std::atoi(e) > 0) nt = (unsigned)std::atoi(e);
     nt = std::max(1u, std::min({nt, 64u, (unsigned)std::max<int64_t>(n_chunks, 1)}));
@@ -278,8 +278,8 @@ int gbrs_decode_chunks(const char *path, int64_t n_chunks, const uint64_t *file_
 }
 
 int gbrs_zip_directory(const uint8_t *buf, uint64_t len, uint64_t cap, uint16_t *method, uint64_t *csize,
-                       uint64_t *usize, uint64_t *header_off, char *names, uint64_t names_cap, uint64_t *n_members,
-                       uint64_t *names_len) {
+                       uint64_t *usize, uint64_t *header_off, uint32_t *crc32, char *names, uint64_t names_cap,
+                       uint64_t *n_members, uint64_t *names_len) {
     using gbrs::fail;
     using gbrs::rd16; using gbrs::rd32; using gbrs::rd64;
     if (!buf || !n_members || !names_len) return fail(GBRS_ERR_INVALID, "bad argument");
@@ -301,16 +301,16 @@ int gbrs_zip_directory(const uint8_t *buf, uint64_t len, uint64_t cap, uint16_t 
         // zip64: the locator sits right before the end record and points at the zip64 end record
         if (eocd < 20 || rd32(buf + eocd - 20) != 0x07064b50u) return fail(GBRS_ERR_UNSUPPORTED, "zip64 locator missing");
         const uint64_t z = rd64(buf + eocd - 20 + 8);
-        if (z + 56 > len || rd32(buf + z) != 0x06064b50u) return fail(GBRS_ERR_INVALID, "bad zip64 end record");
+        if (z > len || len - z < 56 || rd32(buf + z) != 0x06064b50u) return fail(GBRS_ERR_INVALID, "bad zip64 end record");   // (no wrapping sums on file-supplied offsets)
         n = rd64(buf + z + 32);
         cd_off = rd64(buf + z + 48);
     }
     uint64_t pos = cd_off, nlen_total = 0;
     for (uint64_t k = 0; k < n; ++k) {
-        if (pos + 46 > len || rd32(buf + pos) != 0x02014b50u) return fail(GBRS_ERR_INVALID, "bad central directory entry %llu", (unsigned long long)k);
+        if (pos > len || len - pos < 46 || rd32(buf + pos) != 0x02014b50u) return fail(GBRS_ERR_INVALID, "bad central directory entry %llu", (unsigned long long)k);
         const uint16_t m = rd16(buf + pos + 10), nlen = rd16(buf + pos + 28), xlen = rd16(buf + pos + 30), clen = rd16(buf + pos + 32);
         uint64_t cs = rd32(buf + pos + 20), us = rd32(buf + pos + 24), ho = rd32(buf + pos + 42);
-        if (pos + 46 + nlen + xlen + clen > len) return fail(GBRS_ERR_INVALID, "central directory runs past the file");
+        if (len - pos - 46 < (uint64_t)nlen + xlen + clen) return fail(GBRS_ERR_INVALID, "central directory runs past the file");
         if (cs == 0xFFFFFFFFu || us == 0xFFFFFFFFu || ho == 0xFFFFFFFFu) {
             // zip64 extended information: the 64-bit values of the saturated fields, in this order
             const uint8_t *x = buf + pos + 46 + nlen;
@@ -335,6 +335,7 @@ int gbrs_zip_directory(const uint8_t *buf, uint64_t len, uint64_t cap, uint16_t 
         if (k < cap) {
             if (!method || !csize || !usize || !header_off) return fail(GBRS_ERR_INVALID, "bad argument");
             method[k] = m; csize[k] = cs; usize[k] = us; header_off[k] = ho;
+            if (crc32) crc32[k] = rd32(buf + pos + 16);
             if (names && nlen_total + nlen + 1 <= names_cap) {
                 std::memcpy(names + nlen_total, buf + pos + 46, nlen);
                 names[nlen_total + nlen] = '\n';
@@ -370,9 +371,9 @@ int gbrs_zip_read_members(const uint8_t *buf, uint64_t len, int64_t n, const uin
             if (i >= n || failed.load()) break;
             const int64_t k = order[(size_t)i];
             const uint64_t ho = header_off[k];
-            if (!out[k] || ho + 30 > len || rd32(buf + ho) != 0x04034b50u) { failed = 1; break; }
-            const uint64_t data = ho + 30 + rd16(buf + ho + 26) + rd16(buf + ho + 28);
-            if (data + csize[k] > len) { failed = 1; break; }
+            if (!out[k] || ho > len || len - ho < 30 || rd32(buf + ho) != 0x04034b50u) { failed = 1; break; }
+            const uint64_t data = ho + 30 + rd16(buf + ho + 26) + rd16(buf + ho + 28);     // ho <= len - 30: cannot wrap
+            if (data > len || csize[k] > len - data) { failed = 1; break; }
             if (method[k] == 0) {
                 if (csize[k] != usize[k]) { failed = 2; break; }
                 std::memcpy(out[k], buf + data, usize[k]);
@@ -420,9 +421,9 @@ int gbrs_npz_stack(const uint8_t *buf, uint64_t len, int64_t n, const uint64_t *
             for (int64_t k = k0; k < std::min(n, k0 + GRAIN); ++k) {
                 needs_fallback[k] = 1;
                 const uint64_t ho = header_off[k];
-                if (ho + 30 > len || rd32(buf + ho) != 0x04034b50u) { failed = 1; break; }
+                if (ho > len || len - ho < 30 || rd32(buf + ho) != 0x04034b50u) { failed = 1; break; }
                 const uint64_t data = ho + 30 + rd16(buf + ho + 26) + rd16(buf + ho + 28);
-                if (data + csize[k] > len) { failed = 1; break; }
+                if (data > len || csize[k] > len - data) { failed = 1; break; }
                 if (usize[k] != npy_header_len + item_bytes) continue;      // another shape or dtype: the caller's business
                 const unsigned char *img = nullptr;
                 if (method[k] == 0) {

@@ -90,10 +90,22 @@ def _load():
         H5Lexists=[H, CP, H],
         H5Dget_create_plist=[H], H5Pget_chunk=[H, I, VP], H5Pget_nfilters=[H], H5Pget_layout=[H],
         H5Pget_filter2=[H, U, VP, VP, VP, SZ, CP, VP], H5Pset_shuffle=[H], H5Tget_order=[H],
-        H5Dget_num_chunks=[H, H, VP], H5Dget_chunk_info=[H, H, C.c_uint64, VP, VP, VP, VP],
     )
     for name, args in sig.items():
         getattr(lib, name).argtypes = args
+    # the chunk queries (HDF5 >= 1.10.5) and the user-block query only serve the parallel chunk decoder: without them
+    # every dataset goes through H5Dread
+    optional = dict(H5Dget_num_chunks=[H, H, VP], H5Dget_chunk_info=[H, H, C.c_uint64, VP, VP, VP, VP],
+                    H5Fget_create_plist=[H], H5Pget_userblock=[H, VP], H5Iget_file_id=[H])
+    lib.gbrs_has_chunk_queries = True
+    for name, args in optional.items():
+        try:
+            getattr(lib, name).argtypes = args
+        except AttributeError:
+            lib.gbrs_has_chunk_queries = False
+    if lib.gbrs_has_chunk_queries:
+        lib.H5Fget_create_plist.restype = hid_t
+        lib.H5Iget_file_id.restype = hid_t
     _lib = lib
     return lib
 
@@ -209,10 +221,29 @@ def _read_chunks_parallel(path, d, ftype, space):
     """Decode a 1-D chunked dataset (numeric, little endian, filters within {shuffle, deflate}) chunk by
     chunk on a thread pool.  Returns the array, or None when the dataset does not qualify."""
     lib = _load()
+    if not lib.gbrs_has_chunk_queries:
+        return None
     shape = _dims(space)
     cls, size = lib.H5Tget_class(ftype), int(lib.H5Tget_size(ftype))
     if len(shape) != 1 or cls not in (H5T_INTEGER, H5T_FLOAT) or lib.H5Tget_order(ftype) != 0:
         return None
+    # chunk addresses are relative to the file's base address: a file with a user block (none that PyTables writes)
+    # goes through H5Dread
+    fid = lib.H5Iget_file_id(d)
+    if _id(fid) < 0:
+        return None
+    try:
+        fcpl = lib.H5Fget_create_plist(fid)
+        if _id(fcpl) < 0:
+            return None
+        try:
+            ub = C.c_uint64(1)
+            if lib.H5Pget_userblock(fcpl, C.byref(ub)) < 0 or ub.value != 0:
+                return None
+        finally:
+            lib.H5Pclose(fcpl)
+    finally:
+        lib.H5Fclose(fid)
     n = shape[0]
     if n * size < PARALLEL_MIN_BYTES:
         return None

@@ -24,14 +24,28 @@ import numpy as np
 
 
 class _Member:
-    __slots__ = ('filename', 'compress_type', 'compress_size', 'file_size', 'header_offset')
+    __slots__ = ('filename', 'compress_type', 'compress_size', 'file_size', 'header_offset', 'CRC')
 
-    def __init__(self, filename, compress_type, compress_size, file_size, header_offset):
+    def __init__(self, filename, compress_type, compress_size, file_size, header_offset, crc=None):
         self.filename = filename
         self.compress_type = compress_type
         self.compress_size = compress_size
         self.file_size = file_size
         self.header_offset = header_offset
+        self.CRC = crc                  # from the central directory; None = unknown (never checked)
+
+
+# CRC-32 of the members (numpy.load checks every member on every access and raises BadZipFile: the reference inherits
+# that).  Here: always for a member read on its own when it is deflated or small; for the bulk paths (the transition
+# tables inflated on all cores, the per-gene blocks copied by gbrs_npz_stack) and large stored members only with
+# GBRS_VERIFY_CRC=1 - a pass over 0.4 GB of tables is 0.2-0.4 s, the whole of `gbrs reconstruct`'s file handling.
+VERIFY_ALL = os.environ.get('GBRS_VERIFY_CRC', '0') not in ('', '0')
+STORED_CHECK_MAX = 4 << 20
+
+
+def _check_crc(zi, payload, path):
+    if zi.CRC is not None and (zlib.crc32(payload) & 0xFFFFFFFF) != zi.CRC:
+        raise zipfile.BadZipFile(f'Bad CRC-32 for file {zi.filename!r} in {path}')
 
 
 class FastNpz:
@@ -70,7 +84,7 @@ class FastNpz:
             pos = cd_off
             unpack = struct.Struct('<IHHHHHHIIIHHHHHII').unpack_from
             for _ in range(n_total):
-                (sig, _, _, flags, method, _, _, _, csize, usize, nlen, xlen, clen, _, _, _, hoff) = unpack(mm, pos)
+                (sig, _, _, flags, method, _, _, crc, csize, usize, nlen, xlen, clen, _, _, _, hoff) = unpack(mm, pos)
                 if sig != 0x02014b50:
                     raise ValueError
                 name = mm[pos + 46:pos + 46 + nlen].decode('utf-8' if flags & 0x800 else 'cp437')
@@ -93,13 +107,13 @@ class FastNpz:
                         csize = vals.pop(0)
                     if hoff == 0xFFFFFFFF:
                         hoff = vals.pop(0)
-                zi = _Member(name, method, csize, usize, hoff)
+                zi = _Member(name, method, csize, usize, hoff, crc)
                 out.append(zi)
                 pos += 46 + nlen + xlen + clen
             return out
         except (ValueError, struct.error, IndexError):
             with zipfile.ZipFile(self.path) as zf:
-                return [_Member(z.filename, z.compress_type, z.compress_size, z.file_size, z.header_offset)
+                return [_Member(z.filename, z.compress_type, z.compress_size, z.file_size, z.header_offset, z.CRC)
                         for z in zf.infolist()]
 
     def _native_directory(self):
@@ -113,16 +127,17 @@ class FastNpz:
             return None
         view = np.frombuffer(self._mm, dtype=np.uint8)
         n, nbytes = C.c_uint64(0), C.c_uint64(0)
-        if lib.gbrs_zip_directory(_lib.ptr(view), view.size, 0, None, None, None, None, None, 0, C.byref(n), C.byref(nbytes)):
+        if lib.gbrs_zip_directory(_lib.ptr(view), view.size, 0, None, None, None, None, None, None, 0, C.byref(n), C.byref(nbytes)):
             return None
         count = int(n.value)
         method = np.empty(count, dtype=np.uint16)
         csize = np.empty(count, dtype=np.uint64)
         usize = np.empty(count, dtype=np.uint64)
         hoff = np.empty(count, dtype=np.uint64)
+        crc = np.empty(count, dtype=np.uint32)
         names = np.empty(int(nbytes.value), dtype=np.uint8)
         if lib.gbrs_zip_directory(_lib.ptr(view), view.size, count, _lib.ptr(method), _lib.ptr(csize), _lib.ptr(usize),
-                                  _lib.ptr(hoff), _lib.ptr(names), names.size, C.byref(n), C.byref(nbytes)):
+                                  _lib.ptr(hoff), _lib.ptr(crc), _lib.ptr(names), names.size, C.byref(n), C.byref(nbytes)):
             return None
         try:
             text = names.tobytes().decode('utf-8')
@@ -132,7 +147,8 @@ class FastNpz:
         if len(labels) != count:
             return None
         self._native = (method, csize, usize, hoff)          # arrays for stack()
-        return [_Member(labels[k], int(method[k]), int(csize[k]), int(usize[k]), int(hoff[k])) for k in range(count)]
+        crcs = crc.tolist()
+        return [_Member(labels[k], int(method[k]), int(csize[k]), int(usize[k]), int(hoff[k]), crcs[k]) for k in range(count)]
 
     def __contains__(self, name):
         return name in self._info
@@ -183,12 +199,19 @@ class FastNpz:
             method, off, csize = self._payload(zi)
             if method == zipfile.ZIP_STORED:
                 dt, shape, doff = self._npy_header(self._mm, off)
-                return np.frombuffer(self._mm, dtype=dt, count=int(np.prod(shape, dtype=np.int64)),
-                                     offset=off + doff).reshape(shape)
+                small = csize <= STORED_CHECK_MAX
+                if small or VERIFY_ALL:
+                    _check_crc(zi, memoryview(self._mm)[off:off + csize], self.path)
+                a = np.frombuffer(self._mm, dtype=dt, count=int(np.prod(shape, dtype=np.int64)),
+                                  offset=off + doff).reshape(shape)
+                # small members are handed out as arrays of their own (aligned, writable, as numpy.load's are); the
+                # large transition tables stay views of the page cache
+                return a.copy() if small else a
             if method == zipfile.ZIP_DEFLATED:
                 raw = zlib.decompress(self._mm[off:off + csize], -15, zi.file_size)
+                _check_crc(zi, raw, self.path)
                 dt, shape, doff = self._npy_header(raw)
-                return np.frombuffer(raw, dtype=dt, count=int(np.prod(shape, dtype=np.int64)), offset=doff).reshape(shape)
+                return np.frombuffer(bytearray(raw), dtype=dt, count=int(np.prod(shape, dtype=np.int64)), offset=doff).reshape(shape)
         except ValueError:
             pass
         return self._numpy_load(name)
@@ -229,6 +252,10 @@ class FastNpz:
             if lib.gbrs_zip_read_members(_lib.ptr(view), view.size, len(names), _lib.ptr(hoff), _lib.ptr(method),
                                          _lib.ptr(csize), _lib.ptr(usize), ptrs, 0):
                 return None
+            if VERIFY_ALL:
+                from concurrent.futures import ThreadPoolExecutor
+                with ThreadPoolExecutor(max_workers=min(16, len(names))) as pool:      # zlib.crc32 drops the GIL
+                    list(pool.map(lambda t: _check_crc(self._info[t[0]], t[1], self.path), zip(names, images)))
             out = []
             for im in images:
                 dt, shape, doff = self._npy_header(im)

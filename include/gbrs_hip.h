@@ -414,8 +414,8 @@ int gbrs_parse_number_table(const char *text, int64_t text_len, int64_t n_rows, 
  * and the blob size come back in n_members / names_len, so a first call with cap = 0 sizes the second.
  * GBRS_ERR_UNSUPPORTED: multi-disk archive (the caller falls back to zipfile). */
 int gbrs_zip_directory(const uint8_t *buf, uint64_t len, uint64_t cap, uint16_t *method, uint64_t *csize,
-                       uint64_t *usize, uint64_t *header_off, char *names, uint64_t names_cap, uint64_t *n_members,
-                       uint64_t *names_len);
+                       uint64_t *usize, uint64_t *header_off, uint32_t *crc32 /* nullable: the members' CRC-32 */,
+                       char *names, uint64_t names_cap, uint64_t *n_members, uint64_t *names_len);
 /* n members' plain contents (their .npy images), member k into out[k] (usize[k] bytes, caller allocated), copied or
  * inflated on `threads` threads (0 = all cores), largest member first. */
 int gbrs_zip_read_members(const uint8_t *buf, uint64_t len, int64_t n, const uint64_t *header_off, const uint16_t *method,

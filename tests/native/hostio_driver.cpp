@@ -214,9 +214,9 @@ int main(int argc, char **argv) {
         std::vector<uint64_t> cs(n), us(n), ho(n);
         std::vector<char> names(4096);
         uint64_t count = 0, nbytes = 0;
-        CHECK(gbrs_zip_directory(zip.data(), zip.size(), 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, &count, &nbytes) == 0);
+        CHECK(gbrs_zip_directory(zip.data(), zip.size(), 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, &count, &nbytes) == 0);
         CHECK(count == (uint64_t)n && nbytes == (uint64_t)n * 13);
-        CHECK(gbrs_zip_directory(zip.data(), zip.size(), n, method.data(), cs.data(), us.data(), ho.data(), names.data(), names.size(),
+        CHECK(gbrs_zip_directory(zip.data(), zip.size(), n, method.data(), cs.data(), us.data(), ho.data(), nullptr, names.data(), names.size(),
                                  &count, &nbytes) == 0);
         CHECK(std::strncmp(names.data(), "gene0000.npy\ngene0001.npy\n", 26) == 0 && ho[7] == offs[7] && us[7] == 192 && method[7] == 0);
         std::vector<unsigned char> out(n * item, 0), fb(n, 9);
@@ -258,7 +258,7 @@ int main(int argc, char **argv) {
         // every truncation of the tail, and random byte damage anywhere: any status, no out-of-bounds access
         for (size_t cut = 1; cut < 200 && cut < zip.size(); ++cut) {
             std::vector<unsigned char> t(zip.begin(), zip.end() - (long)cut);
-            (void)gbrs_zip_directory(t.data(), t.size(), n, method.data(), cs.data(), us.data(), ho.data(), names.data(), names.size(),
+            (void)gbrs_zip_directory(t.data(), t.size(), n, method.data(), cs.data(), us.data(), ho.data(), nullptr, names.data(), names.size(),
                                      &count, &nbytes);
         }
         for (int trial = 0; trial < 3000; ++trial) {
@@ -266,12 +266,76 @@ int main(int argc, char **argv) {
             for (int hits = 0; hits < 1 + trial % 4; ++hits) t[rng() % t.size()] = (unsigned char)rng();
             std::vector<uint16_t> m2(n);
             std::vector<uint64_t> c2(n), u2(n), h2(n);
-            if (gbrs_zip_directory(t.data(), t.size(), n, m2.data(), c2.data(), u2.data(), h2.data(), names.data(), names.size(),
+            std::vector<uint32_t> crcs(n);
+            if (gbrs_zip_directory(t.data(), t.size(), n, m2.data(), c2.data(), u2.data(), h2.data(), crcs.data(), names.data(), names.size(),
                                    &count, &nbytes) == 0 && count == (uint64_t)n)
                 (void)gbrs_npz_stack(t.data(), t.size(), n, h2.data(), m2.data(), c2.data(), u2.data(),
                                      (const uint8_t *)npy_header.data(), npy_header.size(), item, out.data(), fb.data(), 2);
         }
-        CHECK(gbrs_zip_directory(zip.data(), 10, 0, nullptr, nullptr, nullptr, nullptr, nullptr, 0, &count, &nbytes) < 0);
+        CHECK(gbrs_zip_directory(zip.data(), 10, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, &count, &nbytes) < 0);
+        // offsets and sizes near 2^64 (a crafted zip64 record): the sums header + size wrap around, the checks must not
+        {
+            std::vector<std::vector<unsigned char>> imgs(n, std::vector<unsigned char>(192));
+            std::vector<uint8_t *> ptrs(n);
+            for (int k = 0; k < n; ++k) ptrs[k] = imgs[k].data();
+            for (uint64_t huge : {(uint64_t)~0ull, (uint64_t)(~0ull - 29), (uint64_t)(~0ull - 100), (uint64_t)1 << 63}) {
+                ho[4] = huge;
+                CHECK(gbrs_zip_read_members(zip.data(), zip.size(), n, ho.data(), method.data(), cs.data(), us.data(), ptrs.data(), 2) < 0);
+                CHECK(gbrs_npz_stack(zip.data(), zip.size(), n, ho.data(), method.data(), cs.data(), us.data(),
+                                     (const uint8_t *)npy_header.data(), npy_header.size(), item, out.data(), fb.data(), 2) < 0);
+                ho[4] = offs[4];
+                cs[4] = huge;
+                CHECK(gbrs_zip_read_members(zip.data(), zip.size(), n, ho.data(), method.data(), cs.data(), us.data(), ptrs.data(), 2) < 0);
+                CHECK(gbrs_npz_stack(zip.data(), zip.size(), n, ho.data(), method.data(), cs.data(), us.data(),
+                                     (const uint8_t *)npy_header.data(), npy_header.size(), item, out.data(), fb.data(), 2) < 0);
+                cs[4] = us[4];
+            }
+            // a zip64 end record whose offset wraps: end-of-central-directory with saturated fields + a locator
+            std::vector<unsigned char> z64(zip.begin(), zip.begin() + cd_off + cd_size);
+            for (uint64_t where : {(uint64_t)(~0ull - 10), (uint64_t)(~0ull - 55), (uint64_t)zip.size() * 2}) {
+                std::vector<unsigned char> t = z64;
+                put32(t, 0x07064b50u); put32(t, 0);
+                for (int b = 0; b < 8; ++b) t.push_back((unsigned char)(where >> (8 * b)));
+                put32(t, 1);
+                put32(t, 0x06054b50u); put16(t, 0); put16(t, 0); put16(t, 0xFFFF); put16(t, 0xFFFF); put32(t, 0xFFFFFFFFu);
+                put32(t, 0xFFFFFFFFu); put16(t, 0);
+                CHECK(gbrs_zip_directory(t.data(), t.size(), n, method.data(), cs.data(), us.data(), ho.data(), nullptr, names.data(),
+                                         names.size(), &count, &nbytes) < 0);
+            }
+        }
+    }
+    // ---- gbrs_decode_chunks: chunks of an empty dataset are refused (the element count used to underflow)
+    {
+        const uint64_t addr[1] = {0}, bytes[1] = {16}, start[1] = {0};
+        const uint32_t fmask[1] = {0};
+        unsigned char sink[64];
+        CHECK(gbrs_decode_chunks("/dev/null", 1, addr, bytes, start, fmask, 4, 4, 0, -1, -1, sink, 1) < 0);
+    }
+    // ---- gbrs_parse_genotype_table: plain lines, repeated genes, lines the caller has to take, truncations
+    {
+        const std::string genes = "G1G22G3", haps = "ABCD";
+        const int64_t goff[4] = {0, 2, 5, 7}, hoff[5] = {0, 1, 2, 3, 4};
+        uint32_t bits[3];
+        char call[3 * 4];
+        int32_t last[3];
+        int64_t nl = -1;
+        auto reset = [&]() { std::memset(bits, 0, sizeof(bits)); std::memset(call, 0, sizeof(call)); last[0] = last[1] = last[2] = -1; };
+        const std::string t = "#Gene_ID\tDiplotype\n#more\nG22\tAB\nG1\tCC\textra\nG22\tDA  \n";
+        reset();
+        CHECK(gbrs_parse_genotype_table(t.data(), (int64_t)t.size(), genes.data(), goff, 3, haps.data(), hoff, 4, bits, call, 4,
+                                        last, &nl) == 0);
+        CHECK(nl == 3 && bits[0] == 4u && bits[1] == (1u | 2u | 8u) && bits[2] == 0 && last[0] == 1 && last[1] == 2 && last[2] == -1);
+        CHECK(std::strncmp(call + 4, "DA", 4) == 0 && std::strncmp(call, "CC", 4) == 0);
+        for (const char *bad : {"G9\tAB\n", "G1\tAE\n", "G1\n", "G1\tABCDA\n", "\n", "G1\tA\xc3\xa9\n", "G1\tAB\nG1 \tAB\n"}) {
+            reset();
+            CHECK(gbrs_parse_genotype_table(bad, (int64_t)std::strlen(bad), genes.data(), goff, 3, haps.data(), hoff, 4, bits, call,
+                                            4, last, &nl) == 1);
+        }
+        for (size_t cut = 0; cut <= t.size(); ++cut) {
+            reset();
+            (void)gbrs_parse_genotype_table(t.data(), (int64_t)cut, genes.data(), goff, 3, haps.data(), hoff, 4, bits, call, 4, last, &nl);
+        }
+        CHECK(gbrs_parse_genotype_table(nullptr, 0, genes.data(), goff, 3, haps.data(), hoff, 4, bits, call, 4, last, &nl) < 0);
     }
     std::printf("hostio sanitizer driver: ok (inflate backend %d)\n", gbrs_inflate_backend());
     return 0;

@@ -105,3 +105,40 @@ def test_damaged_files_fall_back_or_fail_cleanly(tmp_path):
     last = list(z.files)[-1]
     with pytest.raises(Exception):
         z.stack([last, list(z.files)[0]], (8, 8))
+
+
+def test_bit_rot_is_reported_like_numpy_load(tmp_path, monkeypatch):
+    """A member whose payload no longer matches its CRC-32 raises BadZipFile when read on its own (numpy.load's
+    behaviour, which the reference inherits); the bulk paths check under GBRS_VERIFY_CRC=1."""
+    import zipfile
+    from gbrs_amd import npzfast
+    rng = np.random.default_rng(3)
+    arrays = {f"g{k:03d}": rng.random((8, 8)) for k in range(20)}
+    arrays["big"] = rng.random(100_000)
+    for writer, name in ((np.savez, "stored.npz"), (np.savez_compressed, "deflated.npz")):
+        p = tmp_path / name
+        writer(p, **arrays)
+        raw = bytearray(p.read_bytes())
+        z = npzfast.FastNpz(str(p))
+        zi = z._info["g007"]
+        _, off, csize = z._payload(zi)
+        z.close()
+        raw[off + csize - 3] ^= 0x5A                       # inside the member's data, sizes unchanged
+        bad = tmp_path / ("bad_" + name)
+        bad.write_bytes(bytes(raw))
+        z = npzfast.FastNpz(str(bad))
+        assert z._info["g007"].CRC is not None
+        np.testing.assert_array_equal(z["g006"], arrays["g006"])
+        assert z["g006"].flags.writeable and z["g006"].flags.aligned
+        with pytest.raises((zipfile.BadZipFile, zlib_error())):
+            z["g007"]
+        monkeypatch.setattr(npzfast, "VERIFY_ALL", True)
+        with pytest.raises((zipfile.BadZipFile, zlib_error())):
+            z.read_many(list(arrays))
+        monkeypatch.setattr(npzfast, "VERIFY_ALL", False)
+        z.close()
+
+
+def zlib_error():
+    import zlib
+    return zlib.error
