@@ -39,16 +39,18 @@ def alignment_counts(apm, grp_wise=False, device=0):
 
 
 def report_alignment_counts(apm, filename, grp_wise=False, device=0):
-    """File format of AlignmentPropertyMatrix.report_alignment_counts (:442-459)."""
+    """File format of AlignmentPropertyMatrix.report_alignment_counts (:442-459): per locus the alignment counts and
+    the allele-unique counts of every haplotype, then the locus-unique count, each as str(float64).  Written by the
+    library's table writer (gbrs_write_locus_table: the same digits), 2.1 M numbers per sample at DO size."""
+    import os
+    from .em import _blob_cached
     aln, uniq, lu, names = alignment_counts(apm, grp_wise=grp_wise, device=device)
-    cntdata = np.vstack((aln, uniq))
-    cntdata = np.vstack((cntdata, lu))
-    with open(filename, 'w') as fhout:
-        fhout.write('locus\t' + '\t'.join([f'aln_{h}' for h in apm.hname]) + '\t')
-        fhout.write('\t'.join([f'uniq_{h}' for h in apm.hname]) + '\t')
-        fhout.write('locus_uniq' + '\n')
-        for locus_id in range(len(names)):
-            lout = [names[locus_id]]
-            lout.extend(list(map(str, cntdata[:, locus_id].ravel())))
-            fhout.write('\t'.join(lout))
-            fhout.write('\n')
+    values = np.ascontiguousarray(np.vstack((aln, uniq)))          # (2H x Lo): value(row r, column c) at c * Lo + r
+    totals = np.ascontiguousarray(lu, dtype=np.float64)
+    names = names if isinstance(names, list) else [str(x) for x in names]
+    name_blob, name_off = _blob_cached(names)
+    head = 'locus\t' + '\t'.join([f'aln_{h}' for h in apm.hname]) + '\t' + \
+        '\t'.join([f'uniq_{h}' for h in apm.hname]) + '\t' + 'locus_uniq' + '\n'
+    n_cols, n_rows = values.shape
+    _lib.check(_lib.load().gbrs_write_locus_table(os.fsencode(filename), head.encode(), _lib.ptr(values), n_rows, n_cols, 1,
+                                                  n_rows, _lib.ptr(totals), name_blob, _lib.ptr(name_off), None, None, None))

@@ -301,6 +301,10 @@ struct ChromDesc {
     int64_t bp_off;       // offset (in S entries) of the chromosome's backpointer rows
     int64_t chunk_off;    // offset (in BT_B-row chunks) of the chromosome's backtrace chunk maps
     int32_t n_genes, n_trans;
+    // Blocked scan (hmm_blocked.inc): a descriptor may stand for a run of genes of a chromosome whose recursion starts
+    // from an injected boundary vector instead of the chromosome's own start / end.
+    int32_t inject;       // -1: the natural start; else the slot of the block's boundary vector
+    int32_t real_chrom;   // the chromosome whose last gene this descriptor ends on (forward / delta), else -1
 };
 
 // ---- cross-lane helpers on DPP (no LDS crossbar on the recursion's critical path) ------------
@@ -812,11 +816,14 @@ forward_wave_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *__
                     const double *__restrict__ eprob, const double *__restrict__ peprob,
                     const double *__restrict__ init_vec, double *__restrict__ xsum,
                     double *__restrict__ invz, double *__restrict__ delta,
-                    int32_t *__restrict__ last_state) {
+                    int32_t *__restrict__ last_state, const double *__restrict__ inject, int n_real_chrom) {
     static_assert(SS % 2 == 0 && SS <= 64, "one lane per state, 16-byte aligned rows");
     __shared__ __attribute__((aligned(16))) double buf[SB][2][SS];
     const int chrom = order[blockIdx.y];
     const ChromDesc cd = chroms[chrom];
+    // injected start (blocked scan): the descriptor's first gene belongs to the previous block - its vector comes from
+    // `inject` ([sample][slot][state]) and nothing is stored for it
+    const bool injected = cd.inject >= 0;
     constexpr int role = ROLE;
     const int n = cd.n_genes;
     if (n <= 0) return;
@@ -869,9 +876,13 @@ forward_wave_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *__
         double y_own[SB];
 #pragma unroll
         for (int b = 0; b < SB; ++b) {
-            y_own[b] = exp(init_vec[jr] + eprob[g0[b] * SS + jr]);
+            if (injected) {
+                y_own[b] = inject[((int64_t)min((int)blockIdx.x * SB + b, n_samples - 1) * gridDim.y + cd.inject) * SS + jr];
+            } else {
+                y_own[b] = exp(init_vec[jr] + eprob[g0[b] * SS + jr]);
+                if (act && sv[b]) xsum[g0[b] * SS + j] = exp(init_vec[j]);   // so that log(x) + e reproduces init + e
+            }
             if (act) buf[b][0][j] = y_own[b];
-            if (act && sv[b]) xsum[g0[b] * SS + j] = exp(init_vec[j]);   // so that log(x) + e reproduces init + e
         }
         wave_lds_fence();
         // Z of the vector in buf[.][cur] comes out of the same broadcast reads as the products:
@@ -884,7 +895,7 @@ forward_wave_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *__
 #endif
 #if !defined(HMM_ABLATE_STORES)
             if (act && sv[b]) {
-                if (j == 0) invz[g0[b] + i_prev] = inv_z;
+                if (j == 0 && (i_prev > 0 || !injected)) invz[g0[b] + i_prev] = inv_z;
             }
 #endif
             return inv_z;
@@ -967,9 +978,14 @@ forward_wave_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *__
     // role 1: Viterbi values in the log domain (adds and max only: exact)
 #pragma unroll
     for (int b = 0; b < SB; ++b) {
-        const double d0 = init_vec[jr] + EM[g0[b] * SS + jr];
+        double d0;
+        if (injected) {
+            d0 = inject[((int64_t)min((int)blockIdx.x * SB + b, n_samples - 1) * gridDim.y + cd.inject) * SS + jr];
+        } else {
+            d0 = init_vec[jr] + EM[g0[b] * SS + jr];
+            if (act && sv[b]) delta[g0[b] * SS + j] = d0;
+        }
         if (act) buf[b][0][j] = d0;
-        if (act && sv[b]) delta[g0[b] * SS + j] = d0;
     }
     wave_lds_fence();
     auto step = [&](int o, const double (&tc)[SS], const double (&e)[SB], double (&tn)[SS], double (&e_n)[SB]) {
@@ -1022,13 +1038,13 @@ forward_wave_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *__
 #pragma unroll
     for (int u = 0; u < NSET - 1; ++u)
         if (o + u < n_ord) step(o + u, pr[u], em_r[u], pr[(u + NSET - 1) % NSET], em_r[(u + NSET - 1) % NSET]);
-    if (j < SB && blockIdx.x * SB + j < n_samples) {      // sid = argmax delta[:, n-1] (first max)
+    if (j < SB && blockIdx.x * SB + j < n_samples && cd.real_chrom >= 0) {      // sid = argmax delta[:, n-1] (first max)
         const double *dl = buf[j][cur];
         double bv = dl[0];
         int bk = 0;
         for (int s = 1; s < SS; ++s)
             if (dl[s] > bv) { bv = dl[s]; bk = s; }
-        last_state[(int64_t)(blockIdx.x * SB + j) * gridDim.y + chrom] = bk;
+        last_state[(int64_t)(blockIdx.x * SB + j) * n_real_chrom + cd.real_chrom] = bk;
     }
 }
 
@@ -1310,12 +1326,14 @@ template <int SS, int NSET, int SB>
 __global__ void __launch_bounds__(64)
 backward_wave_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *__restrict__ chroms,
                      const int32_t *__restrict__ order, const double *__restrict__ pprob_t,
-                     const double *__restrict__ peprob, double *__restrict__ bhat, double *__restrict__ bscale) {
+                     const double *__restrict__ peprob, double *__restrict__ bhat, double *__restrict__ bscale,
+                     const double *__restrict__ inject) {
     static_assert(SS % 2 == 0 && SS <= 64, "one lane per state, 16-byte aligned rows");
     __shared__ __attribute__((aligned(16))) double buf[SB][2][SS];
     const ChromDesc cd = chroms[order[blockIdx.y]];
     const int n = cd.n_genes;
     if (n <= 0) return;
+    const bool injected = cd.inject >= 0;       // blocked scan: the last gene is the next block's; its pe * bt comes from `inject`
     const int j = threadIdx.x;
     const bool act = j < SS;
     const int jr = act ? j : SS - 1;
@@ -1332,10 +1350,14 @@ backward_wave_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *_
 #pragma unroll
     for (int b = 0; b < SB; ++b) {
         const int64_t o = (g0[b] + n - 1) * SS + jr;
-        if (act) buf[b][0][j] = peprob[o];
-        if (act && sv[b]) {
-            bhat[o] = 1.0;
-            if (j == 0) bscale[g0[b] + n - 1] = 1.0;
+        if (injected) {
+            if (act) buf[b][0][j] = inject[((int64_t)min((int)blockIdx.x * SB + b, n_samples - 1) * gridDim.y + cd.inject) * SS + jr];
+        } else {
+            if (act) buf[b][0][j] = peprob[o];
+            if (act && sv[b]) {
+                bhat[o] = 1.0;
+                if (j == 0) bscale[g0[b] + n - 1] = 1.0;
+            }
         }
     }
     // order o <-> gene i = n-2-o, transition block i (the host checked n_trans >= n-1)
@@ -1973,6 +1995,8 @@ backtrace_write_kernel(int S, int64_t genes_per_sample, int64_t bp_per_sample, i
     }
 }
 
+#include "hmm_blocked.inc"
+
 // ---- post-processing of the posteriors (gbrs_utils.py:612-697 interpolate, :863-938 export) ---
 
 // Linear interpolation of the rows of y (S x n points at ascending x) onto xq, operation order of
@@ -2042,6 +2066,14 @@ struct gbrs_hmm {
     DevBuf<uint16_t> bp, bt_exit;             // backpointers; per-chunk exit maps of the backtrace
     DevBuf<int32_t> last_state, states, calls;
     double t_emis = 0, t_fwd = 0, t_bwd = 0, t_bt = 0, t_run = 0;
+    // blocked scan (hmm_blocked.inc; 36 states, up to HMM_BLOCKED_MAX samples): the chromosomes cut into blocks
+    int n_vb = 0, blk_samples = 0;
+    bool last_blocked = false;                // the last run's backward chains started from injected vectors
+    DevBuf<BlockRange> d_ranges;
+    DevBuf<int32_t> d_first_block, d_vorder;  // blocks of chromosome c: first_block[c] .. first_block[c+1]; identity order
+    DevBuf<ChromDesc> d_vfwd, d_vbwd;         // the blocks as descriptors of the forward / delta and of the backward chains
+    DevBuf<double> g_f, g_b, g_d, inj_f, inj_b, inj_d;   // block operators [sample][block][36][36], boundary vectors [sample][block][36]
+    DevBuf<int32_t> e_f, e_b;                 // power-of-two exponents of the operators' columns
 };
 
 namespace {
@@ -2101,6 +2133,9 @@ int hmm_make_logs(gbrs_hmm *h) {
     if (!h->scaler.p) GBRS_TRY(h->scaler.alloc(gs));
     if (h->free_backward) {
         if (!h->bcorr.p) GBRS_TRY(h->bcorr.alloc(gs));
+        if (h->last_blocked)            // the blocks' backward chains become one free-running chain again (hmm_blocked.inc)
+            hipLaunchKernelGGL(blocked_bscale_fix_kernel, dim3(h->n_vb, h->n_samples), dim3(64), 0, h->stream, h->total_genes,
+                               h->n_vb, h->d_ranges.p, h->peprob.p, h->bhat.p, h->inj_b.p, h->bscale.p);
         hipLaunchKernelGGL(beta_corr_kernel, dim3(h->n_samples, h->n_chrom), dim3(256), 0, h->stream, h->total_genes,
                            h->d_chroms.p, h->invz.p, h->bscale.p, h->bcorr.p);
     }
@@ -2139,6 +2174,87 @@ int hmm_make_logs(gbrs_hmm *h) {
 #ifndef HMM_NSET_M
 #define HMM_NSET_M 3      // register sets (transition blocks in flight) of the MFMA sweeps
 #endif
+
+#ifndef HMM_BLOCKED_MAX
+#define HMM_BLOCKED_MAX 2     // 36 states, at most this many samples: the blocked scan (the operators cost 36 columns per block)
+#endif
+#ifndef HMM_BLOCK_GENES
+#define HMM_BLOCK_GENES 40    // genes per block aimed at (at most HMM_BLOCKS_MAX blocks per chromosome)
+#endif
+#ifndef HMM_BLOCKS_MAX
+#define HMM_BLOCKS_MAX 64
+#endif
+
+// The block structure of the handle's chromosomes and the buffers of the blocked scan for n_samples samples.
+int hmm_prepare_blocks(gbrs_hmm *h) {
+    const int S = h->S;
+    if (h->n_vb == 0) {
+        int block_genes = HMM_BLOCK_GENES, blocks_max = HMM_BLOCKS_MAX;
+        if (const char *env = std::getenv("GBRS_TUNING_HMM_BLOCK_GENES"); env && std::atoi(env) > 1) block_genes = std::atoi(env);
+        if (const char *env = std::getenv("GBRS_TUNING_HMM_BLOCKS_MAX"); env && std::atoi(env) > 0) blocks_max = std::atoi(env);
+        std::vector<BlockRange> ranges;
+        std::vector<int32_t> first(h->n_chrom + 1, 0);
+        std::vector<ChromDesc> vf, vb;
+        for (int c = 0; c < h->n_chrom; ++c) {
+            const ChromDesc &cd = h->chroms[c];
+            const int n = cd.n_genes;
+            const int nb = std::max(1, std::min(blocks_max, n / block_genes));
+            const int len = (n + nb - 1) / nb;
+            first[c] = (int32_t)ranges.size();
+            for (int lo = 0; lo < n; lo += len) {
+                const int hi = std::min(n, lo + len);
+                const int v = (int)ranges.size();
+                ranges.push_back(BlockRange{cd.gene_off, cd.trans_off, lo, hi, n, c});
+                ChromDesc f = cd, b = cd;           // bp_off / chunk_off are not used by the chain kernels
+                if (lo > 0) {                       // forward / delta: starts on the previous block's last gene
+                    f.gene_off = cd.gene_off + lo - 1;
+                    f.trans_off = cd.trans_off + lo - 1;
+                    f.n_genes = hi - lo + 1;
+                    f.inject = v;
+                } else {
+                    f.n_genes = hi;
+                }
+                f.n_trans = f.n_genes;              // every step of the block has its transition block
+                f.real_chrom = hi == n ? c : -1;
+                b.gene_off = cd.gene_off + lo;
+                b.trans_off = cd.trans_off + lo;
+                if (hi < n) {                       // backward: ends on the next block's first gene
+                    b.n_genes = hi - lo + 1;
+                    b.inject = v;
+                } else {
+                    b.n_genes = n - lo;
+                }
+                b.n_trans = b.n_genes;
+                b.real_chrom = -1;
+                vf.push_back(f);
+                vb.push_back(b);
+            }
+        }
+        first[h->n_chrom] = (int32_t)ranges.size();
+        const int VB = (int)ranges.size();
+        std::vector<int32_t> ident(VB);
+        for (int v = 0; v < VB; ++v) ident[v] = v;
+        GBRS_TRY(h->d_ranges.alloc(VB));
+        GBRS_TRY(h->d_first_block.alloc(first.size()));
+        GBRS_TRY(h->d_vorder.alloc(VB));
+        GBRS_TRY(h->d_vfwd.alloc(VB));
+        GBRS_TRY(h->d_vbwd.alloc(VB));
+        GBRS_HIP_CHECK(hipMemcpy(h->d_ranges.p, ranges.data(), VB * sizeof(BlockRange), hipMemcpyHostToDevice));
+        GBRS_HIP_CHECK(hipMemcpy(h->d_first_block.p, first.data(), first.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        GBRS_HIP_CHECK(hipMemcpy(h->d_vorder.p, ident.data(), VB * sizeof(int32_t), hipMemcpyHostToDevice));
+        GBRS_HIP_CHECK(hipMemcpy(h->d_vfwd.p, vf.data(), VB * sizeof(ChromDesc), hipMemcpyHostToDevice));
+        GBRS_HIP_CHECK(hipMemcpy(h->d_vbwd.p, vb.data(), VB * sizeof(ChromDesc), hipMemcpyHostToDevice));
+        h->n_vb = VB;
+    }
+    if (h->blk_samples < h->n_samples) {
+        const size_t nb = (size_t)h->n_vb * h->n_samples;
+        GBRS_TRY(h->g_f.alloc(nb * S * S)); GBRS_TRY(h->g_b.alloc(nb * S * S)); GBRS_TRY(h->g_d.alloc(nb * S * S));
+        GBRS_TRY(h->e_f.alloc(nb * S)); GBRS_TRY(h->e_b.alloc(nb * S));
+        GBRS_TRY(h->inj_f.alloc(nb * S)); GBRS_TRY(h->inj_b.alloc(nb * S)); GBRS_TRY(h->inj_d.alloc(nb * S));
+        h->blk_samples = h->n_samples;
+    }
+    return GBRS_OK;
+}
 
 // SS_WAVE > 0: the single-wave chain kernels for that (even, <= 64) state count; otherwise KMAX / MAXT /
 // EXACT select the quad chains (EXACT, S = 4*KMAX > 64) or the generic multi-wave kernels.
@@ -2190,7 +2306,14 @@ int hmm_launch(gbrs_hmm *h) {
             int mfma_min = HMM_MFMA_MIN;
             if (const char *env = std::getenv("GBRS_TUNING_HMM_MFMA"); env) mfma_min = std::atoi(env) > 0 ? std::atoi(env) : INT_MAX;
             const bool mfma = SS == MF_S && h->n_samples >= mfma_min && h->total_trans > 0;
-            if (mfma && !h->amat_f.p) {
+            // GBRS_TUNING_HMM_BLOCKED = largest batch that takes the blocked scan (0: never)
+            int blocked_max = HMM_BLOCKED_MAX;
+            if (const char *env = std::getenv("GBRS_TUNING_HMM_BLOCKED"); env) blocked_max = std::atoi(env);
+            const bool blocked = SS == MF_S && !mfma && h->n_samples <= blocked_max && h->total_trans > 0;
+            if (blocked) GBRS_TRY(hmm_prepare_blocks(h));
+            h->last_blocked = blocked;
+            const dim3 blk_grid(h->n_samples, std::max(h->n_vb, 1));
+            if ((mfma || blocked) && !h->amat_f.p) {
                 GBRS_TRY(h->amat_f.alloc((size_t)h->total_trans * MF_BLK));
                 GBRS_TRY(h->amat_b.alloc((size_t)h->total_trans * MF_BLK));
                 hipLaunchKernelGGL(mfma_blocks_kernel, dim3(4096), dim3(256), 0, sa, h->total_trans, h->tprob.p,
@@ -2205,9 +2328,21 @@ int hmm_launch(gbrs_hmm *h) {
                                        h->xsum.p, h->invz.p);
                     return;
                 }
+                if (blocked) {
+                    hipLaunchKernelGGL((blockmat_mfma_kernel<0>), dim3(3, h->n_vb, h->n_samples), dim3(64), 0, st, h->total_genes,
+                                       h->d_ranges.p, h->amat_f.p, h->peprob.p, h->g_f.p, h->e_f.p);
+                    hipLaunchKernelGGL((combine_sumprod_kernel<0>), dim3(h->n_chrom, h->n_samples), dim3(64), 0, st, h->total_genes,
+                                       h->n_vb, h->d_ranges.p, h->d_first_block.p, h->g_f.p, h->e_f.p, h->init_vec.p, h->eprob.p,
+                                       h->peprob.p, h->inj_f.p);
+                    hipLaunchKernelGGL(k_alpha, blk_grid, dim3(64), 0, st, h->n_samples, h->total_genes,
+                                       h->d_vfwd.p, h->d_vorder.p, h->tprob_q.p, h->pprob.p, h->eprob.p, h->peprob.p,
+                                       h->init_vec.p, h->xsum.p, h->invz.p, h->delta.p, h->last_state.p, h->inj_f.p, h->n_chrom);
+                    return;
+                }
                 hipLaunchKernelGGL(k_alpha, wave_grid, dim3(64), 0, st, h->n_samples, h->total_genes,
                                    h->d_chroms.p, h->d_order.p, h->tprob_q.p, h->pprob.p, h->eprob.p, h->peprob.p,
-                                   h->init_vec.p, h->xsum.p, h->invz.p, h->delta.p, h->last_state.p);
+                                   h->init_vec.p, h->xsum.p, h->invz.p, h->delta.p, h->last_state.p, (const double *)nullptr,
+                                   h->n_chrom);
             };
             launch_back = [=](hipStream_t st) {
                 if (mfma) {
@@ -2216,8 +2351,19 @@ int hmm_launch(gbrs_hmm *h) {
                                        h->bscale.p);
                     return;
                 }
+                if (blocked) {
+                    hipLaunchKernelGGL((blockmat_mfma_kernel<1>), dim3(3, h->n_vb, h->n_samples), dim3(64), 0, st, h->total_genes,
+                                       h->d_ranges.p, h->amat_b.p, h->peprob.p, h->g_b.p, h->e_b.p);
+                    hipLaunchKernelGGL((combine_sumprod_kernel<1>), dim3(h->n_chrom, h->n_samples), dim3(64), 0, st, h->total_genes,
+                                       h->n_vb, h->d_ranges.p, h->d_first_block.p, h->g_b.p, h->e_b.p, h->init_vec.p, h->eprob.p,
+                                       h->peprob.p, h->inj_b.p);
+                    hipLaunchKernelGGL(k_back, blk_grid, dim3(64), 0, st, h->n_samples, h->total_genes,
+                                       h->d_vbwd.p, h->d_vorder.p, h->pprob_t.p, h->peprob.p, h->bhat.p, h->bscale.p, h->inj_b.p);
+                    return;
+                }
                 hipLaunchKernelGGL(k_back, wave_grid, dim3(64), 0, st, h->n_samples, h->total_genes,
-                                   h->d_chroms.p, h->d_order.p, h->pprob_t.p, h->peprob.p, h->bhat.p, h->bscale.p);
+                                   h->d_chroms.p, h->d_order.p, h->pprob_t.p, h->peprob.p, h->bhat.p, h->bscale.p,
+                                   (const double *)nullptr);
             };
             // GBRS_TUNING_HMM_DLANES = smallest batch that takes the samples-on-lanes delta chain (0: never)
             int dl_min = HMM_DLANES_MIN;
@@ -2230,9 +2376,20 @@ int hmm_launch(gbrs_hmm *h) {
                                        h->init_vec.p, h->delta.p, h->last_state.p);
                     return;
                 }
+                if (blocked) {
+                    hipLaunchKernelGGL(blockmat_maxplus_kernel, dim3(3, h->n_vb, h->n_samples), dim3(64 * DL_WAVES), 0, st,
+                                       h->total_genes, h->d_ranges.p, h->tprob.p, h->eprob.p, h->g_d.p);
+                    hipLaunchKernelGGL(combine_maxplus_kernel, dim3(h->n_chrom, h->n_samples), dim3(64), 0, st, h->total_genes,
+                                       h->n_vb, h->d_ranges.p, h->d_first_block.p, h->g_d.p, h->init_vec.p, h->eprob.p, h->inj_d.p);
+                    hipLaunchKernelGGL(k_delta, blk_grid, dim3(64), 0, st, h->n_samples, h->total_genes,
+                                       h->d_vfwd.p, h->d_vorder.p, h->tprob_q.p, h->pprob.p, h->eprob.p, h->peprob.p,
+                                       h->init_vec.p, h->xsum.p, h->invz.p, h->delta.p, h->last_state.p, h->inj_d.p, h->n_chrom);
+                    return;
+                }
                 hipLaunchKernelGGL(k_delta, wave_grid, dim3(64), 0, st, h->n_samples, h->total_genes,
                                    h->d_chroms.p, h->d_order.p, h->tprob_q.p, h->pprob.p, h->eprob.p, h->peprob.p,
-                                   h->init_vec.p, h->xsum.p, h->invz.p, h->delta.p, h->last_state.p);
+                                   h->init_vec.p, h->xsum.p, h->invz.p, h->delta.p, h->last_state.p, (const double *)nullptr,
+                                   h->n_chrom);
             };
         } else {
             const dim3 quad_grid(h->n_samples, h->n_chrom), quad_block(threads);
@@ -2349,6 +2506,8 @@ int gbrs_hmm_create(int num_haps, int n_chrom, const int32_t *n_genes, const int
         h->total_chunks += (std::min(n_genes[c], n_trans[c]) + BT_B - 1) / BT_B;
         cd.n_genes = n_genes[c];
         cd.n_trans = n_trans[c];
+        cd.inject = -1;
+        cd.real_chrom = c;
         h->total_genes += n_genes[c];
         h->total_trans += n_trans[c];
         h->total_bp += std::min(n_genes[c], n_trans[c]);

@@ -43,6 +43,62 @@ def test_hmm_matches_reference_golden(path):
     hmm.close()
 
 
+@pytest.mark.parametrize("block_genes", [2, 5, 9])
+@pytest.mark.parametrize("path", [p for p in golden_files("hmm") if "h8" in p], ids=lambda p: p.split("/")[-1][:-4])
+def test_blocked_scan_matches_reference_golden(path, block_genes, monkeypatch):
+    """The blocked scan of the 36-state recursions (hmm_blocked.inc: block transfer operators on MFMA / max-plus, a
+    sequential combine, the chain kernels inside all blocks at once) with blocks of 2, 5 and 9 genes, so that the
+    goldens' short chromosomes are cut many times: the same tolerances as the unblocked run, calls bit-exact."""
+    monkeypatch.setenv("GBRS_TUNING_HMM_BLOCK_GENES", str(block_genes))
+    monkeypatch.setenv("GBRS_TUNING_HMM_BLOCKED", "2")
+    g = load_golden(path)
+    c = hmm_case_inputs(g)
+    chroms = c["chroms"]
+    hmm = build(c)
+    hmm.set_expression([c["expr"][ch] for ch in chroms], [c["avecs"][ch] for ch in chroms],
+                       [c["has_avec"][ch] for ch in chroms], float(g["expr_threshold"]), float(g["sigma"]))
+    hmm.run()
+    want = ("gamma", "states", "calls", "alpha", "beta", "delta", "scaler")
+    for ci, ch in enumerate(chroms):
+        r = hmm.get(ci, want=want)
+        np.testing.assert_array_equal(r["states"], g[f"states_{ch}"])
+        np.testing.assert_array_equal(r["calls"], g[f"calls_{ch}"])
+        np.testing.assert_allclose(r["alpha"], g[f"alpha_{ch}"], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(r["scaler"], g[f"scaler_{ch}"], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(r["beta"], g[f"beta_{ch}"], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(r["delta"], g[f"delta_{ch}"], rtol=1e-9, atol=1e-9)
+        gap = viterbi_decision_margins(c["tprob"][ch], g[f"delta_{ch}"]).min()
+        assert np.max(np.abs(r["delta"] - g[f"delta_{ch}"])) < 1e-6 * gap
+        np.testing.assert_allclose(r["gamma"], g[f"gamma_{ch}"], rtol=1e-8, atol=1e-300)
+    hmm.close()
+
+
+def test_blocked_scan_equals_the_unblocked_chains_at_size(monkeypatch):
+    """40k genes, 20 chromosomes, one sample: the blocked scan (64 blocks per long chromosome) against the unblocked
+    chains of the same library - posteriors, log-domain arrays and delta at 1e-9, Viterbi path identical."""
+    from gbrs_amd import synth
+    from gbrs_amd.hmm import DiplotypeHMM
+    prob = synth.make_hmm_problem(H=8)
+    chroms = prob.chroms
+    ex = [np.array([prob.expr[g] for g in prob.gene_ids[c]]) for c in chroms]
+    ha = [np.array([g in prob.avecs for g in prob.gene_ids[c]], dtype=np.uint8) for c in chroms]
+    av = [np.array([prob.avecs.get(g, np.zeros((8, 8))) for g in prob.gene_ids[c]]) for c in chroms]
+    res = {}
+    for mode in ("0", "2"):
+        monkeypatch.setenv("GBRS_TUNING_HMM_BLOCKED", mode)
+        hmm = DiplotypeHMM(8, chroms, [len(prob.gene_ids[c]) for c in chroms], [prob.tprob[c] for c in chroms])
+        hmm.set_expression(ex, av, ha, 1.5, 0.12)
+        hmm.run()
+        res[mode] = [hmm.get(ci, want=("gamma", "states", "calls", "alpha", "beta", "delta", "scaler")) for ci in (0, 7, 19)]
+        hmm.close()
+    for a, b in zip(res["0"], res["2"]):
+        np.testing.assert_array_equal(a["states"], b["states"])
+        np.testing.assert_array_equal(a["calls"], b["calls"])
+        for k in ("alpha", "beta", "delta", "scaler"):
+            np.testing.assert_allclose(b[k], a[k], rtol=1e-9, atol=1e-9)
+        np.testing.assert_allclose(b["gamma"], a["gamma"], rtol=1e-8, atol=1e-300)
+
+
 @pytest.mark.parametrize("path", golden_files("hmm")[:2], ids=lambda p: p.split("/")[-1][:-4])
 def test_hmm_with_host_emissions_and_sample_batch(path):
     """set_eprob path with the reference's own emissions, 3 identical samples in one launch."""
