@@ -1271,6 +1271,48 @@ viterbi_bp_kernel(int S, int n_samples, int64_t genes_per_sample, int64_t bp_per
     }
 }
 
+// Backpointers for few samples and a single-wave state count: one wavefront takes BPW_ROWS consecutive genes of a
+// chromosome; lane j loads row j of every block from the lane-ordered table (coalesced, as the chain kernels do), the
+// delta row goes through LDS as broadcast reads.  viterbi_bp_kernel above launches one 256-thread workgroup per gene
+// and stages the block in LDS - with one sample that is 52 k workgroups of which 36 threads work (0.12 ms, on the
+// critical path of the Viterbi chain); this form is ~5 k wavefronts.
+constexpr int BPW_ROWS = 8;
+template <int SS>
+__global__ void __launch_bounds__(64)
+viterbi_bp_wave_kernel(int n_samples, int64_t genes_per_sample, int64_t bp_per_sample,
+                       const ChromDesc *__restrict__ chroms, const double *__restrict__ tprob_q,
+                       const double *__restrict__ delta, uint16_t *__restrict__ bp) {
+    __shared__ __attribute__((aligned(16))) double drow[SS];
+    const ChromDesc cd = chroms[blockIdx.y];
+    const int rows = min(cd.n_genes, cd.n_trans);
+    const int t0 = blockIdx.x * BPW_ROWS;
+    if (t0 >= rows) return;
+    const int j = threadIdx.x;
+    const bool act = j < SS;
+    const int jr = act ? j : SS - 1;
+    for (int t = t0; t < min(t0 + BPW_ROWS, rows); ++t) {
+        double tr[SS];
+        load_lane<SS>(tprob_q + (cd.trans_off + t) * (int64_t)SS * SS, jr, tr);
+        for (int sample = 0; sample < n_samples; ++sample) {
+            const double *d = delta + ((int64_t)sample * genes_per_sample + cd.gene_off + t) * SS;
+            wave_lds_fence();
+            if (act) drow[j] = d[j];
+            wave_lds_fence();
+            const double2 *dv = reinterpret_cast<const double2 *>(drow);
+            double best = 0.0;
+            int best_k = 0;
+#pragma unroll
+            for (int m = 0; m < SS / 2; ++m) {           // first maximum, np.argmax's rule
+                const double2 v = dv[m];
+                const double a = v.x + tr[2 * m], c = v.y + tr[2 * m + 1];
+                if (m == 0 || a > best) { best = a; best_k = 2 * m; }
+                if (c > best) { best = c; best_k = 2 * m + 1; }
+            }
+            if (act) bp[((int64_t)sample * bp_per_sample + cd.bp_off + t) * SS + j] = (uint16_t)best_k;
+        }
+    }
+}
+
 // Backpointers for the quad chains: same result as viterbi_bp_kernel, but the block comes straight
 // from the lane-ordered table (coalesced, no 148 KB LDS image) into registers and is reused for
 // every sample; 4 lanes per state, quad argmax with np.argmax's first-max rule.
@@ -2329,7 +2371,7 @@ int hmm_launch(gbrs_hmm *h) {
                     return;
                 }
                 if (blocked) {
-                    hipLaunchKernelGGL((blockmat_mfma_kernel<0>), dim3(3, h->n_vb, h->n_samples), dim3(64), 0, st, h->total_genes,
+                    hipLaunchKernelGGL((blockmat_mfma_kernel<0>), dim3(h->n_vb, h->n_samples), dim3(64), 0, st, h->total_genes,
                                        h->d_ranges.p, h->amat_f.p, h->peprob.p, h->g_f.p, h->e_f.p);
                     hipLaunchKernelGGL((combine_sumprod_kernel<0>), dim3(h->n_chrom, h->n_samples), dim3(64), 0, st, h->total_genes,
                                        h->n_vb, h->d_ranges.p, h->d_first_block.p, h->g_f.p, h->e_f.p, h->init_vec.p, h->eprob.p,
@@ -2352,7 +2394,7 @@ int hmm_launch(gbrs_hmm *h) {
                     return;
                 }
                 if (blocked) {
-                    hipLaunchKernelGGL((blockmat_mfma_kernel<1>), dim3(3, h->n_vb, h->n_samples), dim3(64), 0, st, h->total_genes,
+                    hipLaunchKernelGGL((blockmat_mfma_kernel<1>), dim3(h->n_vb, h->n_samples), dim3(64), 0, st, h->total_genes,
                                        h->d_ranges.p, h->amat_b.p, h->peprob.p, h->g_b.p, h->e_b.p);
                     hipLaunchKernelGGL((combine_sumprod_kernel<1>), dim3(h->n_chrom, h->n_samples), dim3(64), 0, st, h->total_genes,
                                        h->n_vb, h->d_ranges.p, h->d_first_block.p, h->g_b.p, h->e_b.p, h->init_vec.p, h->eprob.p,
@@ -2377,7 +2419,7 @@ int hmm_launch(gbrs_hmm *h) {
                     return;
                 }
                 if (blocked) {
-                    hipLaunchKernelGGL(blockmat_maxplus_kernel, dim3(3, h->n_vb, h->n_samples), dim3(64 * DL_WAVES), 0, st,
+                    hipLaunchKernelGGL(blockmat_maxplus_kernel, dim3(h->n_vb, h->n_samples), dim3(64 * MP_WAVES), 0, st,
                                        h->total_genes, h->d_ranges.p, h->tprob.p, h->eprob.p, h->g_d.p);
                     hipLaunchKernelGGL(combine_maxplus_kernel, dim3(h->n_chrom, h->n_samples), dim3(64), 0, st, h->total_genes,
                                        h->n_vb, h->d_ranges.p, h->d_first_block.p, h->g_d.p, h->init_vec.p, h->eprob.p, h->inj_d.p);
@@ -2423,7 +2465,12 @@ int hmm_launch(gbrs_hmm *h) {
                 hipLaunchKernelGGL((viterbi_bp_quad_kernel<KMAX>), dim3(h->max_bp_rows, h->n_chrom), dim3(threads), 0,
                                    sc, h->n_samples, h->total_genes, h->total_bp, h->d_chroms.p, h->tprob_q.p,
                                    h->delta.p, h->bp.p);
-            else
+            else if (WAVE && h->n_samples <= 4) {
+                if constexpr (WAVE)
+                    hipLaunchKernelGGL((viterbi_bp_wave_kernel<(WAVE ? SS_WAVE : 2)>), dim3((h->max_bp_rows + BPW_ROWS - 1) / BPW_ROWS, h->n_chrom),
+                                       dim3(64), 0, sc, h->n_samples, h->total_genes, h->total_bp, h->d_chroms.p,
+                                       h->tprob_q.p, h->delta.p, h->bp.p);
+            } else
                 hipLaunchKernelGGL(viterbi_bp_kernel, dim3(h->max_bp_rows, h->n_chrom), dim3(256),
                                    bp_lds, sc, S, h->n_samples, h->total_genes,
                                    h->total_bp, h->d_chroms.p, h->tprob.p, h->delta.p, h->bp.p);
@@ -2515,7 +2562,11 @@ int gbrs_hmm_create(int num_haps, int n_chrom, const int32_t *n_genes, const int
     }
     GBRS_HIP_CHECK(hipStreamCreateWithFlags(&h->stream, hipStreamDefault));
     GBRS_HIP_CHECK(hipStreamCreateWithFlags(&h->stream_b, hipStreamNonBlocking));
-    GBRS_HIP_CHECK(hipStreamCreateWithFlags(&h->stream_c, hipStreamNonBlocking));
+    {   // the Viterbi chain (delta -> backpointers -> backtrace) is the longest of the three: its stream goes first
+        int lo_pri = 0, hi_pri = 0;
+        GBRS_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo_pri, &hi_pri));
+        GBRS_HIP_CHECK(hipStreamCreateWithPriority(&h->stream_c, hipStreamNonBlocking, hi_pri));
+    }
     for (auto &e : h->ev) GBRS_HIP_CHECK(hipEventCreate(&e));
     for (hipEvent_t *e : {&h->ev_fork, &h->ev_b, &h->ev_c1, &h->ev_c}) GBRS_HIP_CHECK(hipEventCreate(e));
     GBRS_TRY(h->d_chroms.alloc(n_chrom));
