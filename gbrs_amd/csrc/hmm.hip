@@ -53,6 +53,14 @@ constexpr int EM_GENES = 64 / EM_LANES;
 #endif
 constexpr int EM_BATCH_MIN = HMM_EM_BATCH_MIN, EM_BATCH_SPB = HMM_EM_BATCH_SPB;
 
+// one-wavefront workgroups: LDS instructions of a wavefront execute in order, so a compiler fence replaces the barrier
+// (__syncthreads would also wait for the global loads and stores in flight)
+__device__ __forceinline__ void em_wave_fence() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+}
+
 __global__ void __launch_bounds__(64)
 emission_kernel(int H, int S, int64_t n_genes, int n_samples, const double *__restrict__ expr,
                 const double *__restrict__ avecs, const uint8_t *__restrict__ has_avec,
@@ -60,7 +68,8 @@ emission_kernel(int H, int S, int64_t n_genes, int n_samples, const double *__re
                 double *__restrict__ eprob, double *__restrict__ peprob) {
     extern __shared__ double lds[];
     const int HH = H * H, av_stride = HH + 1, ex_stride = H + 1, out_stride = S + 1;
-    double *l_av = lds, *l_ex = l_av + EM_GENES * av_stride, *l_out = l_ex + EM_GENES * ex_stride;
+    double *l_av = lds, *l_ex = l_av + EM_GENES * av_stride, *l_out = l_ex + EM_GENES * ex_stride,
+           *l_pe = l_out + EM_GENES * out_stride;
     const int64_t blocks_per_sample = (n_genes + EM_GENES - 1) / EM_GENES;
     const int sample = (int)(blockIdx.x / blocks_per_sample);
     const int64_t g0 = (blockIdx.x % blocks_per_sample) * EM_GENES;
@@ -74,7 +83,7 @@ emission_kernel(int H, int S, int64_t n_genes, int n_samples, const double *__re
     const int lg = tid / EM_LANES, q = tid % EM_LANES;
     const bool in_range = lg < ng;
     const double *e = l_ex + lg * ex_stride;
-    double *out = l_out + lg * out_stride;
+    double *out = l_out + lg * out_stride, *pout = l_pe + lg * out_stride;
     double *U = l_av + lg * av_stride;
     // states of this lane: a contiguous chunk [s_lo, s_hi) of the upper-triangular order
     const int spl = (S + EM_LANES - 1) / EM_LANES;
@@ -144,19 +153,24 @@ emission_kernel(int H, int S, int64_t n_genes, int n_samples, const double *__re
         }
     }
     __syncthreads();
-    if (live) {
+    if (in_range && !live) {
+        for (int s = s_lo; s < s_hi; ++s) pout[s] = exp(init_vec[s]);
+    } else if (live) {
         double psum = 0.0;
         for (int s = 0; s < S; ++s) psum += out[s];
-        for (int s = s_lo; s < s_hi; ++s) out[s] = log(out[s] / psum + TINY);
+        for (int s = s_lo; s < s_hi; ++s) {
+            const double pr = out[s] / psum + TINY;
+            out[s] = log(pr);
+            pout[s] = pr;                      // pe = exp(e) without the round trip through the logarithm
+        }
     }
     __syncthreads();
-    // the log emissions, and pe = exp(e) for the probability-domain sweeps (exp_emission_kernel's values)
+    // the log emissions, and pe = exp(e) for the probability-domain sweeps
     double *dst = eprob + ((int64_t)sample * n_genes + g0) * S;
     double *pdst = peprob + ((int64_t)sample * n_genes + g0) * S;
     for (int x = tid; x < ng * S; x += 64) {
-        const double v = l_out[(x / S) * out_stride + x % S];
-        dst[x] = v;
-        pdst[x] = exp(v);
+        dst[x] = l_out[(x / S) * out_stride + x % S];
+        pdst[x] = l_pe[(x / S) * out_stride + x % S];
     }
 }
 
@@ -177,7 +191,7 @@ emission_batch_kernel(int64_t n_genes, int n_samples, int samples_per_block, con
     constexpr int SPL = (S + EM_LANES - 1) / EM_LANES;
     constexpr int av_stride = HH + 1, ex_stride = H + 1, out_stride = S + 1;
     __shared__ double l_av[EM_GENES * av_stride], l_ex[EM_GENES * ex_stride], l_u[EM_GENES * ex_stride],
-        l_out[EM_GENES * out_stride];
+        l_out[EM_GENES * out_stride], l_pe[EM_GENES * out_stride], l_init[2 * S];
     const int64_t g0 = (int64_t)blockIdx.x * EM_GENES;
     const int ng = (int)min((int64_t)EM_GENES, n_genes - g0);
     const int s_begin = blockIdx.y * samples_per_block, s_end = min(n_samples, s_begin + samples_per_block);
@@ -186,7 +200,7 @@ emission_batch_kernel(int64_t n_genes, int n_samples, int samples_per_block, con
     // one expression element per lane and sample, fetched one sample ahead
     const bool has_e = tid < ng * H;
     double e_next = has_e && s_begin < s_end ? expr[((int64_t)s_begin * n_genes + g0) * H + tid] : 0.0;
-    __syncthreads();
+    em_wave_fence();
     const int lg = tid / EM_LANES, q = tid % EM_LANES;
     const bool in_range = lg < ng;
     double *U = l_av + lg * av_stride;
@@ -204,7 +218,7 @@ emission_batch_kernel(int64_t n_genes, int n_samples, int samples_per_block, con
             U[q * H + x] = rn != 0.0 ? a / rn : a;
         }
     }
-    __syncthreads();
+    em_wave_fence();
     const int s_lo = min(S, q * SPL), s_hi = min(S, s_lo + SPL);
     double G[SPL][H];                          // unit diplotype vectors of this lane's states
     {
@@ -240,11 +254,15 @@ emission_batch_kernel(int64_t n_genes, int n_samples, int samples_per_block, con
     const double sg = naive ? 0.450 : sigma;
     const double denom = -2 * sg * sg;
     const double *e = l_ex + lg * ex_stride;
-    double *out = l_out + lg * out_stride;
+    double *out = l_out + lg * out_stride, *pout = l_pe + lg * out_stride;
+    if (tid < S) {                             // log and linear start values: e and pe of a gene below the threshold
+        l_init[tid] = init_vec[tid];
+        l_init[S + tid] = exp(init_vec[tid]);
+    }
     for (int sample = s_begin; sample < s_end; ++sample) {
         if (has_e) l_ex[(tid / H) * ex_stride + tid % H] = e_next;
         if (has_e && sample + 1 < s_end) e_next = expr[((int64_t)(sample + 1) * n_genes + g0) * H + tid];
-        __syncthreads();
+        em_wave_fence();
         double esum = 0.0;
         if (in_range)
             for (int x = 0; x < H; ++x) esum += e[x];
@@ -254,9 +272,14 @@ emission_batch_kernel(int64_t n_genes, int n_samples, int samples_per_block, con
             const double nrm = norm ? seq_norm(e, H, 1) : 1.0;
             l_u[lg * ex_stride + q] = norm ? e[q] / nrm : e[q];
         }
-        __syncthreads();
+        em_wave_fence();
         if (in_range && !live) {
-            for (int s = s_lo; s < s_hi; ++s) out[s] = init_vec[s];
+#pragma unroll
+            for (int t = 0; t < SPL; ++t)
+                if (s_lo + t < s_hi) {
+                    out[s_lo + t] = l_init[s_lo + t];
+                    pout[s_lo + t] = l_init[S + s_lo + t];
+                }
         } else if (live) {
             double u[H];
 #pragma unroll
@@ -273,19 +296,22 @@ emission_batch_kernel(int64_t n_genes, int n_samples, int samples_per_block, con
                 out[s_lo + t] = exp(d / denom);
             }
         }
-        __syncthreads();
+        em_wave_fence();
         if (live) {
             double psum = 0.0;
             for (int s = 0; s < S; ++s) psum += out[s];
-            for (int s = s_lo; s < s_hi; ++s) out[s] = log(out[s] / psum + TINY);
+            for (int s = s_lo; s < s_hi; ++s) {
+                const double pr = out[s] / psum + TINY;
+                out[s] = log(pr);
+                pout[s] = pr;                  // pe = exp(e) without the round trip through the logarithm
+            }
         }
-        __syncthreads();
+        em_wave_fence();
         double *dst = eprob + ((int64_t)sample * n_genes + g0) * S;
         double *pdst = peprob + ((int64_t)sample * n_genes + g0) * S;
         for (int x = tid; x < ng * S; x += 64) {
-            const double v = l_out[(x / S) * out_stride + x % S];
-            dst[x] = v;
-            pdst[x] = exp(v);
+            dst[x] = l_out[(x / S) * out_stride + x % S];
+            pdst[x] = l_pe[(x / S) * out_stride + x % S];
         }
     }
 }
@@ -2039,6 +2065,66 @@ backtrace_write_kernel(int S, int64_t genes_per_sample, int64_t bp_per_sample, i
 
 #include "hmm_blocked.inc"
 
+// Backpointers for many samples (S = 36): the SAMPLES on the lanes.  viterbi_bp_kernel gives a sample's 36 targets a
+// lane each, so every lane re-reads the sample's delta row from memory (36 loads per lane and sample, two or three
+// distinct addresses per wavefront): 13 G loads at 256 samples, bound by the address units (4.56 ms alone, and the
+// posterior next to it runs at a third of its speed).  Here a lane holds its sample's delta row in registers (18 16-byte
+// loads), the transition block is read from LDS at wave-uniform addresses (one broadcast b128 read per two entries), and
+// a (target, source) pair is four vector instructions: add, compare, maximum, select of the index.  Four targets make one
+// 8-byte store of the sample's backpointer row.  First maximum, as np.argmax.
+#ifndef HMM_BPL_MIN
+#define HMM_BPL_MIN 32        // samples from which viterbi_bp_lanes_kernel replaces viterbi_bp_kernel
+#endif
+constexpr int BPL_WAVES = 4;
+template <int SS>
+__global__ void __launch_bounds__(64 * BPL_WAVES)
+viterbi_bp_lanes_kernel(int n_samples, int64_t genes_per_sample, int64_t bp_per_sample,
+                        const ChromDesc *__restrict__ chroms, const double *__restrict__ tprob,
+                        const double *__restrict__ delta, uint16_t *__restrict__ bp) {
+    static_assert(SS % 4 == 0, "four backpointers per store");
+    __shared__ __attribute__((aligned(16))) double tl[SS * SS];
+    const ChromDesc cd = chroms[blockIdx.y];
+    const int t = blockIdx.x;
+    if (t >= min(cd.n_genes, cd.n_trans)) return;
+    const double2 *T = reinterpret_cast<const double2 *>(tprob + (cd.trans_off + t) * (int64_t)SS * SS);
+    for (int x = threadIdx.x; x < SS * SS / 2; x += blockDim.x) reinterpret_cast<double2 *>(tl)[x] = T[x];
+    const int sample = blockIdx.z * blockDim.x + threadIdx.x;
+    const bool act = sample < n_samples;
+    const int64_t row = (int64_t)(act ? sample : n_samples - 1) * genes_per_sample + cd.gene_off + t;
+    const double2 *d2 = reinterpret_cast<const double2 *>(delta + row * SS);
+    double d[SS];
+#pragma unroll
+    for (int m = 0; m < SS / 2; ++m) {
+        const double2 v = d2[m];
+        d[2 * m] = v.x;
+        d[2 * m + 1] = v.y;
+    }
+    __syncthreads();
+    uint2 *out = reinterpret_cast<uint2 *>(bp + ((int64_t)(act ? sample : n_samples - 1) * bp_per_sample + cd.bp_off + t) * SS);
+    uint64_t packed = 0;                          // the last four backpointers, 16 bits each
+#pragma unroll 1
+    for (int j = 0; j < SS; ++j) {
+        const double2 *tr = reinterpret_cast<const double2 *>(tl + j * SS);
+        double best = 0.0;
+        uint32_t best_k = 0;
+#pragma unroll
+        for (int m = 0; m < SS / 2; ++m) {
+            const double2 tv = tr[m];
+            const double a = d[2 * m] + tv.x, c = d[2 * m + 1] + tv.y;
+            if (m == 0) {
+                best = a;
+            } else {
+                best_k = a > best ? 2 * m : best_k;
+                best = max_f64(best, a);
+            }
+            best_k = c > best ? 2 * m + 1 : best_k;
+            best = max_f64(best, c);
+        }
+        packed = (packed >> 16) | ((uint64_t)best_k << 48);
+        if ((j & 3) == 3 && act) out[j >> 2] = make_uint2((uint32_t)packed, (uint32_t)(packed >> 32));
+    }
+}
+
 // ---- post-processing of the posteriors (gbrs_utils.py:612-697 interpolate, :863-938 export) ---
 
 // Linear interpolation of the rows of y (S x n points at ascending x) onto xq, operation order of
@@ -2452,11 +2538,16 @@ int hmm_launch(gbrs_hmm *h) {
             };
         }
         const size_t bp_lds = (size_t)S * (S + 1) * sizeof(double);
+        // GBRS_TUNING_HMM_BPLANES = smallest batch that takes the samples-on-lanes backpointer kernel (0: never)
+        int bpl_min = HMM_BPL_MIN;
+        if (const char *env = std::getenv("GBRS_TUNING_HMM_BPLANES"); env) bpl_min = std::atoi(env) > 0 ? std::atoi(env) : INT_MAX;
         GBRS_HIP_CHECK(hipEventRecord(h->ev_fork, sa));
         GBRS_HIP_CHECK(hipStreamWaitEvent(sb, h->ev_fork, 0));
         GBRS_HIP_CHECK(hipStreamWaitEvent(sc, h->ev_fork, 0));
         launch_alpha(sa);
         GBRS_HIP_CHECK(hipEventRecord(h->ev[2], sa));
+        if (const char *env = std::getenv("GBRS_TUNING_HMM_BACK_AFTER"); env && std::atoi(env))
+            GBRS_HIP_CHECK(hipStreamWaitEvent(sb, h->ev[2], 0));
         launch_back(sb);
         GBRS_HIP_CHECK(hipEventRecord(h->ev_b, sb));
         launch_delta(sc);
@@ -2470,6 +2561,11 @@ int hmm_launch(gbrs_hmm *h) {
                     hipLaunchKernelGGL((viterbi_bp_wave_kernel<(WAVE ? SS_WAVE : 2)>), dim3((h->max_bp_rows + BPW_ROWS - 1) / BPW_ROWS, h->n_chrom),
                                        dim3(64), 0, sc, h->n_samples, h->total_genes, h->total_bp, h->d_chroms.p,
                                        h->tprob_q.p, h->delta.p, h->bp.p);
+            } else if (WAVE && SS_WAVE == MF_S && h->n_samples >= bpl_min) {
+                const int per_wg = std::min(64 * BPL_WAVES, ((h->n_samples + 63) / 64) * 64);
+                hipLaunchKernelGGL((viterbi_bp_lanes_kernel<MF_S>), dim3(h->max_bp_rows, h->n_chrom, (h->n_samples + per_wg - 1) / per_wg),
+                                   dim3(per_wg), 0, sc, h->n_samples, h->total_genes, h->total_bp, h->d_chroms.p, h->tprob.p,
+                                   h->delta.p, h->bp.p);
             } else
                 hipLaunchKernelGGL(viterbi_bp_kernel, dim3(h->max_bp_rows, h->n_chrom), dim3(256),
                                    bp_lds, sc, S, h->n_samples, h->total_genes,
@@ -2644,7 +2740,7 @@ int gbrs_hmm_set_expression(gbrs_hmm_t *h, int n_samples, const double *const *e
     }
     const int64_t total = h->total_genes * n_samples;
     GBRS_HIP_CHECK(hipEventRecord(h->ev[0], h->stream));
-    const size_t em_lds = (size_t)EM_GENES * ((H * H + 1) + (H + 1) + (h->S + 1)) * sizeof(double);
+    const size_t em_lds = (size_t)EM_GENES * ((H * H + 1) + (H + 1) + 2 * (h->S + 1)) * sizeof(double);
     const int64_t em_blocks = ((h->total_genes + EM_GENES - 1) / EM_GENES) * n_samples;
     (void)total;
     if (H == EM_LANES && n_samples >= EM_BATCH_MIN) {

@@ -199,6 +199,7 @@ def test_hmm_sample_batches_and_short_chromosomes(n_samples, minus_one, monkeypa
     from oracle import hmm_oracle
     monkeypatch.setenv("GBRS_TUNING_HMM_MFMA", "16")
     monkeypatch.setenv("GBRS_TUNING_HMM_DLANES", "16")       # and the samples-on-lanes delta chain
+    monkeypatch.setenv("GBRS_TUNING_HMM_BPLANES", "5")       # and the samples-on-lanes backpointers (partly filled wavefronts)
     lens = [1, 2, 3, 4, 5, 7, 63, 64, 65, 129, 200]
     probs = [synth.make_hmm_problem(H=8, genes_per_chrom=lens, seed=1234 + s, tprob_len_minus_one=minus_one)
              for s in range(n_samples)]
@@ -224,6 +225,36 @@ def test_hmm_sample_batches_and_short_chromosomes(n_samples, minus_one, monkeypa
                 np.testing.assert_allclose(r[k], res[c][k], rtol=1e-9, atol=1e-9, err_msg=f"{k} sample {s} chrom {c}")
             np.testing.assert_allclose(r["gamma"], res[c]["gamma"], rtol=1e-8, atol=1e-300)
     hmm.close()
+
+
+def test_hmm_backpointers_on_lanes_second_sample_group(monkeypatch):
+    """260 samples: the samples-on-lanes backpointer kernel with a second, nearly empty group of 256 samples; the
+    Viterbi paths and calls equal those of the one-target-per-lane kernel bit for bit."""
+    from gbrs_amd import synth
+    from gbrs_amd.hmm import DiplotypeHMM
+    n_samples = 260
+    p0 = synth.make_hmm_problem(H=8, genes_per_chrom=[1, 2, 31, 70], seed=77)
+    chroms = p0.chroms
+    rng = np.random.default_rng(5)
+    ex, av, ha = [], [], []
+    for c in chroms:
+        ids = p0.gene_ids[c]
+        e = np.array([p0.expr[g] for g in ids])
+        ex.append(np.stack([e] + [rng.gamma(1.0, 5.0, size=e.shape) * (rng.random(e.shape) < 0.6) for _ in range(n_samples - 1)]))
+        ha.append(np.array([g in p0.avecs for g in ids], dtype=np.uint8))
+        av.append(np.array([p0.avecs.get(g, np.zeros((8, 8))) for g in ids]))
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("GBRS_TUNING_HMM_BPLANES", mode)
+        hmm = DiplotypeHMM(8, chroms, [len(p0.gene_ids[c]) for c in chroms], [p0.tprob[c] for c in chroms])
+        hmm.set_expression(ex, av, ha, 1.5, 0.12)
+        hmm.run()
+        out[mode] = [[hmm.get(ci, sample=s, want=("states", "calls")) for ci in range(len(chroms))] for s in range(n_samples)]
+        hmm.close()
+    for s in range(n_samples):
+        for ci in range(len(chroms)):
+            np.testing.assert_array_equal(out["0"][s][ci]["states"], out["1"][s][ci]["states"], err_msg=f"sample {s} chrom {ci}")
+            np.testing.assert_array_equal(out["0"][s][ci]["calls"], out["1"][s][ci]["calls"])
 
 
 def test_hmm_large_batch_default_dispatch():
