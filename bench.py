@@ -685,6 +685,8 @@ def main():
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS if achieved else None,
                      "traffic": None, "kernel": "tile_estep_kernel (E-step)", "kernel_ms": em["estep_ms"],
+                     "limited_by": "vector issue + LDS (valu_util, lds_idx_active below); the per-launch working set "
+                                   "fits the 256 MB Infinity Cache, so the HBM fraction is context, not the bound",
                      "kernel_bytes": estep_bytes, "priced_bytes": priced_estep,
                      "algorithmic_bytes": algo,
                      "note": "achieved = E-step bytes (word stream, tile headers, dictionary, theta gather, slot "
@@ -723,7 +725,7 @@ def main():
             line["roofline"]["traffic"] = pt[key]["bytes_per_launch"]
             line["roofline"]["traffic_source"] = pt[key]["source"]
             for k in ("valu_insts_per_launch", "valu_util", "shader_clock_mhz", "lds_bank_conflict_cycles",
-                      "valu_insts_per_word", "pmc_round"):
+                      "lds_idx_active_cycles", "lds_util", "valu_insts_per_word", "pmc_round"):
                 if k in pt[key]:
                     line["roofline"][k] = pt[key][k]
     except (OSError, ValueError):

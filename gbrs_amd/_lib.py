@@ -19,7 +19,8 @@ EXPORTS = [
     "gbrs_em_get", "gbrs_em_set_theta", "gbrs_em_group_sums", "gbrs_em_estep_partial",
     "gbrs_em_finish_step", "gbrs_em_prepare_partial", "gbrs_em_finish_prepare", "gbrs_em_stream",
     "gbrs_em_set_stream",
-    "gbrs_em_sync", "gbrs_em_pair_begin", "gbrs_em_pair_check", "gbrs_em_pair_status", "gbrs_em_info", "gbrs_alignment_counts", "gbrs_em_destroy",
+    "gbrs_em_sync", "gbrs_em_pair_begin", "gbrs_em_pair_check", "gbrs_em_pair_status", "gbrs_em_info", "gbrs_alignment_counts",
+    "gbrs_counts_create", "gbrs_counts_get", "gbrs_counts_destroy", "gbrs_em_destroy",
     "gbrs_hmm_create", "gbrs_hmm_set_expression", "gbrs_hmm_set_eprob", "gbrs_hmm_run",
     "gbrs_hmm_get", "gbrs_hmm_info", "gbrs_hmm_destroy", "gbrs_interpolate", "gbrs_genoprob_dosage",
     "gbrs_compress_create", "gbrs_compress_get", "gbrs_compress_destroy",
@@ -121,6 +122,9 @@ def load():
         "gbrs_em_set_stream": [vp, vp],
         "gbrs_em_info": [vp, C.POINTER(EmInfo)],
         "gbrs_alignment_counts": [u64, u32, u32, pp, pp, vp, vp, u32, i32, vp, vp, vp],
+        "gbrs_counts_create": [u64, u32, u32, pp, pp, vp, i32, pp],
+        "gbrs_counts_get": [vp, vp, u32, vp, vp, vp],
+        "gbrs_counts_destroy": [vp],
         "gbrs_em_destroy": [vp],
         "gbrs_hmm_create": [i32, i32, vp, vp, pp, i32, pp],
         "gbrs_hmm_set_expression": [vp, i32, pp, pp, pp, dbl, dbl],

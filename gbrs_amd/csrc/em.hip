@@ -522,6 +522,18 @@ struct gbrs_em {
     int red_blocks() const { return (int)std::min<uint64_t>(RED_BLOCKS, (L + RED_THREADS - 1) / RED_THREADS); }
 };
 
+// gbrs_counts_*: the alignments of `--report-alignment-counts` on the device, and the workspace of the last get
+struct gbrs_counts {
+    int device = 0;
+    uint64_t R = 0, n = 0;
+    uint32_t L = 0, H = 0;
+    gbrs::DevBuf<uint32_t> ent_row;
+    gbrs::DevBuf<uint64_t> col_ptr;
+    gbrs::DevBuf<double> d_count;
+    hipStream_t s = nullptr;
+    gbrs::CountsWork *work = nullptr;
+};
+
 namespace {
 
 int em_flush_err(gbrs_em *em);
@@ -1617,32 +1629,44 @@ int gbrs_em_info(gbrs_em_t *em, gbrs_em_info_t *info) {
     return GBRS_OK;
 }
 
-int gbrs_alignment_counts(uint64_t R, uint32_t L, uint32_t H, const uint32_t *const *indptr,
-                          const uint32_t *const *indices, const double *count, const int32_t *locus_group,
-                          uint32_t num_out_loci, int device, double *aln_counts, double *allele_unique,
-                          double *locus_unique) {
+int gbrs_counts_create(uint64_t R, uint32_t L, uint32_t H, const uint32_t *const *indptr,
+                       const uint32_t *const *indices, const double *count, int device, gbrs_counts_t **out) {
+    if (!out) return fail(GBRS_ERR_INVALID, "out is NULL");
+    *out = nullptr;
     if (H < 1 || H > 32 || L < 1 || R < 1 || R > 0xFFFFFFFFull || !indptr || !indices)
         return fail(GBRS_ERR_INVALID, "The shape must be a tuple of three positive integers (H <= 32, R < 2^32).");
+    GBRS_TRY(select_device(device));
+    gbrs_counts *c = new gbrs_counts();
+    struct Guard { gbrs_counts *p; ~Guard() { if (p) gbrs_counts_destroy(p); } } guard{c};
+    c->device = device;
+    c->R = R; c->L = L; c->H = H;
+    GBRS_HIP_CHECK(hipStreamCreateWithFlags(&c->s, hipStreamDefault));
+    GBRS_TRY(upload_csc(R, L, H, indptr, indices, false, c->ent_row, c->col_ptr, c->n));
+    if (count) {
+        GBRS_TRY(c->d_count.alloc(R));
+        GBRS_HIP_CHECK(hipMemcpy(c->d_count.p, count, R * sizeof(double), hipMemcpyHostToDevice));
+    }
+    GBRS_HIP_CHECK(hipDeviceSynchronize());
+    GBRS_TRY(check_row_ids(c->n, c->ent_row.p, R, c->s));
+    c->work = counts_work_new();
+    guard.p = nullptr;
+    *out = c;
+    return GBRS_OK;
+}
+
+int gbrs_counts_get(gbrs_counts_t *c, const int32_t *locus_group, uint32_t num_out_loci, double *aln_counts,
+                    double *allele_unique, double *locus_unique) {
+    if (!c) return fail(GBRS_ERR_INVALID, "handle is NULL");
+    const uint32_t L = c->L, H = c->H;
     const uint32_t Lout = locus_group ? num_out_loci : L;
     if (Lout < 1 || Lout >= (1u << 27)) return fail(GBRS_ERR_INVALID, "bad number of output loci");
     if (locus_group)
         for (uint32_t l = 0; l < L; ++l)
             if (locus_group[l] < -1 || (locus_group[l] >= 0 && (uint32_t)locus_group[l] >= Lout))
                 return fail(GBRS_ERR_INVALID, "locus_group[%u] out of range", l);
-    GBRS_TRY(select_device(device));
-    hipStream_t s = nullptr;
-    GBRS_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamDefault));
-    struct SG { hipStream_t s; ~SG() { (void)hipStreamDestroy(s); } } sg{s};
-    DevBuf<uint32_t> ent_row;
-    DevBuf<uint64_t> col_ptr;
-    uint64_t n = 0;
-    GBRS_TRY(upload_csc(R, L, H, indptr, indices, false, ent_row, col_ptr, n));
-    DevBuf<double> d_count, d_aln, d_uniq, d_lu;
+    GBRS_TRY(select_device(c->device));
+    DevBuf<double> d_aln, d_uniq, d_lu;
     DevBuf<int32_t> d_group;
-    if (count) {
-        GBRS_TRY(d_count.alloc(R));
-        GBRS_HIP_CHECK(hipMemcpy(d_count.p, count, R * sizeof(double), hipMemcpyHostToDevice));
-    }
     if (locus_group) {
         GBRS_TRY(d_group.alloc(L));
         GBRS_HIP_CHECK(hipMemcpy(d_group.p, locus_group, L * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -1650,14 +1674,35 @@ int gbrs_alignment_counts(uint64_t R, uint32_t L, uint32_t H, const uint32_t *co
     GBRS_TRY(d_aln.alloc((size_t)H * Lout));
     GBRS_TRY(d_uniq.alloc((size_t)H * Lout));
     GBRS_TRY(d_lu.alloc(Lout));
-    GBRS_HIP_CHECK(hipDeviceSynchronize());
-    GBRS_TRY(check_row_ids(n, ent_row.p, R, s));
-    GBRS_TRY(alignment_counts_device(R, L, H, n, ent_row.p, col_ptr.p, count ? d_count.p : nullptr,
-                                     locus_group ? d_group.p : nullptr, Lout, d_aln.p, d_uniq.p, d_lu.p, s));
+    GBRS_TRY(alignment_counts_device(c->R, L, H, c->n, c->ent_row.p, c->col_ptr.p, c->d_count.p,
+                                     locus_group ? d_group.p : nullptr, Lout, d_aln.p, d_uniq.p, d_lu.p, c->s, c->work));
     if (aln_counts) GBRS_HIP_CHECK(hipMemcpy(aln_counts, d_aln.p, d_aln.bytes(), hipMemcpyDeviceToHost));
     if (allele_unique) GBRS_HIP_CHECK(hipMemcpy(allele_unique, d_uniq.p, d_uniq.bytes(), hipMemcpyDeviceToHost));
     if (locus_unique) GBRS_HIP_CHECK(hipMemcpy(locus_unique, d_lu.p, d_lu.bytes(), hipMemcpyDeviceToHost));
     return GBRS_OK;
+}
+
+int gbrs_counts_destroy(gbrs_counts_t *c) {
+    if (!c) return GBRS_OK;
+    (void)hipSetDevice(c->device);
+    if (c->s) {
+        (void)hipStreamSynchronize(c->s);
+        (void)hipStreamDestroy(c->s);
+    }
+    if (c->work) counts_work_free(c->work);
+    delete c;
+    return GBRS_OK;
+}
+
+int gbrs_alignment_counts(uint64_t R, uint32_t L, uint32_t H, const uint32_t *const *indptr,
+                          const uint32_t *const *indices, const double *count, const int32_t *locus_group,
+                          uint32_t num_out_loci, int device, double *aln_counts, double *allele_unique,
+                          double *locus_unique) {
+    gbrs_counts_t *c = nullptr;
+    GBRS_TRY(gbrs_counts_create(R, L, H, indptr, indices, count, device, &c));
+    const int st = gbrs_counts_get(c, locus_group, num_out_loci, aln_counts, allele_unique, locus_unique);
+    (void)gbrs_counts_destroy(c);
+    return st;
 }
 
 int gbrs_em_destroy(gbrs_em_t *em) {

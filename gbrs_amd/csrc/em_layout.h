@@ -138,9 +138,14 @@ int compress_device(CompressResult &out, uint64_t R, uint32_t L, uint32_t H, uin
 
 // `--report-alignment-counts`: aln/uniq are (H x Lout) row-major, locus_uniq is Lout, all DEVICE
 // buffers; locus_group (device, nullable) maps locus -> output column (gene level).
+// device workspace of alignment_counts_device, kept between calls on the same alignments (gbrs_counts_*)
+struct CountsWork;
+CountsWork *counts_work_new();
+void counts_work_free(CountsWork *w);
 int alignment_counts_device(uint64_t R, uint32_t L, uint32_t H, uint64_t N, const uint32_t *ent_row,
                             const uint64_t *col_ptr, const double *count, const int32_t *locus_group,
-                            uint32_t Lout, double *aln, double *uniq, double *locus_uniq, hipStream_t s);
+                            uint32_t Lout, double *aln, double *uniq, double *locus_uniq, hipStream_t s,
+                            CountsWork *work = nullptr);
 
 // shared by em.hip and em_layout.hip -----------------------------------------------------------
 __device__ __forceinline__ uint32_t find_column(const uint64_t *__restrict__ col_ptr, uint32_t lo,

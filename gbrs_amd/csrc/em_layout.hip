@@ -567,32 +567,45 @@ __global__ void count_accum_kernel(uint64_t n, uint32_t Lout, const uint64_t *__
     if (new_pair && nloc_row[r] == 1) atomicAdd(&locus_uniq[l], w);
 }
 
+struct CountsWork {
+    Scratch sc;
+    DevBuf<BuildFlags> d_flags;
+    DevBuf<uint64_t> keys, keys2;
+    DevBuf<uint32_t> nnz_row, nloc_row;
+    uint64_t n = 0, rows = 0;
+};
+CountsWork *counts_work_new() { return new CountsWork(); }
+void counts_work_free(CountsWork *w) { delete w; }
+
 int alignment_counts_device(uint64_t R, uint32_t L, uint32_t H, uint64_t N, const uint32_t *ent_row,
                             const uint64_t *col_ptr, const double *count, const int32_t *locus_group,
-                            uint32_t Lout, double *aln, double *uniq, double *locus_uniq, hipStream_t s) {
+                            uint32_t Lout, double *aln, double *uniq, double *locus_uniq, hipStream_t s,
+                            CountsWork *work) {
     GBRS_HIP_CHECK(hipMemsetAsync(aln, 0, (size_t)H * Lout * 8, s));
     GBRS_HIP_CHECK(hipMemsetAsync(uniq, 0, (size_t)H * Lout * 8, s));
     GBRS_HIP_CHECK(hipMemsetAsync(locus_uniq, 0, (size_t)Lout * 8, s));
     if (N == 0) { GBRS_HIP_CHECK(hipStreamSynchronize(s)); return GBRS_OK; }
-    Scratch sc;
-    DevBuf<BuildFlags> d_flags;
-    GBRS_TRY(d_flags.alloc(1));
-    GBRS_HIP_CHECK(hipMemsetAsync(d_flags.p, 0, sizeof(BuildFlags), s));
-    DevBuf<uint64_t> keys, keys2;
-    DevBuf<uint32_t> nnz_row, nloc_row;
-    GBRS_TRY(keys.alloc(N)); GBRS_TRY(keys2.alloc(N)); GBRS_TRY(nnz_row.alloc(R)); GBRS_TRY(nloc_row.alloc(R));
-    GBRS_HIP_CHECK(hipMemsetAsync(nnz_row.p, 0, nnz_row.bytes(), s));
-    GBRS_HIP_CHECK(hipMemsetAsync(nloc_row.p, 0, nloc_row.bytes(), s));
+    CountsWork local;
+    CountsWork &w = work ? *work : local;
+    if (w.n != N || w.rows != R || !w.keys.p) {
+        GBRS_TRY(w.d_flags.alloc(1));
+        GBRS_TRY(w.keys.alloc(N)); GBRS_TRY(w.keys2.alloc(N)); GBRS_TRY(w.nnz_row.alloc(R)); GBRS_TRY(w.nloc_row.alloc(R));
+        w.n = N;
+        w.rows = R;
+    }
+    GBRS_HIP_CHECK(hipMemsetAsync(w.d_flags.p, 0, sizeof(BuildFlags), s));
+    GBRS_HIP_CHECK(hipMemsetAsync(w.nnz_row.p, 0, w.nnz_row.bytes(), s));
+    GBRS_HIP_CHECK(hipMemsetAsync(w.nloc_row.p, 0, w.nloc_row.bytes(), s));
     hipLaunchKernelGGL(count_keys_kernel, dim3(grid_for(N)), dim3(256), 0, s, N, H * L, L, R, col_ptr, ent_row,
-                       locus_group, keys.p, d_flags.p);
+                       locus_group, w.keys.p, w.d_flags.p);
     // the dropped key is all ones: within the compared bits it is larger than every real key (Lout < 2^27),
     // so dropped entries end up behind all real ones
-    GBRS_TRY(sort_keys64(sc, keys.p, keys2.p, N, 32 + bits_for(R - 1), s));
-    hipLaunchKernelGGL(count_rowstat_kernel, dim3(grid_for(N)), dim3(256), 0, s, N, keys2.p, nnz_row.p, nloc_row.p);
-    hipLaunchKernelGGL(count_accum_kernel, dim3(grid_for(N)), dim3(256), 0, s, N, Lout, keys2.p, nnz_row.p, nloc_row.p,
+    GBRS_TRY(sort_keys64(w.sc, w.keys.p, w.keys2.p, N, 32 + bits_for(R - 1), s));
+    hipLaunchKernelGGL(count_rowstat_kernel, dim3(grid_for(N)), dim3(256), 0, s, N, w.keys2.p, w.nnz_row.p, w.nloc_row.p);
+    hipLaunchKernelGGL(count_accum_kernel, dim3(grid_for(N)), dim3(256), 0, s, N, Lout, w.keys2.p, w.nnz_row.p, w.nloc_row.p,
                        count, aln, uniq, locus_uniq);
     BuildFlags hf{};
-    GBRS_HIP_CHECK(hipMemcpyAsync(&hf, d_flags.p, sizeof(hf), hipMemcpyDeviceToHost, s));
+    GBRS_HIP_CHECK(hipMemcpyAsync(&hf, w.d_flags.p, sizeof(hf), hipMemcpyDeviceToHost, s));
     GBRS_HIP_CHECK(hipStreamSynchronize(s));
     GBRS_HIP_CHECK(hipGetLastError());
     if (hf.bad_row) return fail(GBRS_ERR_INVALID, "indices hold a row id >= num_rows");

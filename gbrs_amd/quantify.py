@@ -302,17 +302,18 @@ def quantify(alignment_file: str, group_file: str = None, length_file: str = Non
 
     if report_alignment_counts:
         t0 = clock()
-        from .counts import report_alignment_counts as write_counts
+        from .counts import AlignmentCounter, report_alignment_counts as write_counts
         # the reference reloads the file for this report (gbrs/emase_utils.py:318-331), so the counts are always those
         # of the unmasked alignments; a `-G` mask here is a note for the device and leaves the host arrays as loaded -
         # unless something (--report-posterior) has carried it out on them since
         fresh = aln_mat if genotype_file is None or aln_mat.haplotype_mask is not None else \
             load_alignment(alignment_file, grpfile=group_file)
-        for level, grp_wise in (('isoform', False), ('gene', True)):
-            if grp_wise and group_file is None:
-                continue
-            path = f'{outbase}.{level}s.alignment_counts'
-            logger.info(f'Generating {level} Alignment Counts: {path}')
-            write_counts(fresh, path, grp_wise=grp_wise, device=device)
+        with AlignmentCounter(fresh, device=device) as counter:       # one upload of the alignments for both levels
+            for level, grp_wise in (('isoform', False), ('gene', True)):
+                if grp_wise and group_file is None:
+                    continue
+                path = f'{outbase}.{level}s.alignment_counts'
+                logger.info(f'Generating {level} Alignment Counts: {path}')
+                write_counts(fresh, path, grp_wise=grp_wise, device=device, counter=counter)
         marks['alignment_counts'] = clock() - t0
     logger.debug('Done')

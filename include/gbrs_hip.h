@@ -251,6 +251,17 @@ int gbrs_alignment_counts(uint64_t num_rows, uint32_t num_loci, uint32_t num_hap
                           const double *count, const int32_t *locus_group, uint32_t num_out_loci,
                           int device, double *aln_counts, double *allele_unique, double *locus_unique);
 
+/* The same in three calls, for callers that want both levels (the `quantify -a` command writes the isoform-level and
+ * the gene-level report, AlignmentPropertyMatrix.py:442-459 twice): create uploads the alignments once, every get
+ * computes one set of counts (locus_group / num_out_loci as above) and re-uses the device workspace of the last. */
+typedef struct gbrs_counts gbrs_counts_t;
+int gbrs_counts_create(uint64_t num_rows, uint32_t num_loci, uint32_t num_haps,
+                       const uint32_t *const *indptr, const uint32_t *const *indices,
+                       const double *count, int device, gbrs_counts_t **out);
+int gbrs_counts_get(gbrs_counts_t *c, const int32_t *locus_group, uint32_t num_out_loci,
+                    double *aln_counts, double *allele_unique, double *locus_unique);
+int gbrs_counts_destroy(gbrs_counts_t *c);
+
 int gbrs_em_destroy(gbrs_em_t *em);
 
 /* `gbrs compress` numeric body (gbrs/emase_utils.py:60-103): rows with identical alignment patterns

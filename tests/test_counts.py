@@ -56,6 +56,19 @@ def test_counts_hip_bit_exact(path, tmp_path):
         p = tmp_path / f"{level}.tsv"
         report_alignment_counts(apm, str(p), grp_wise=grp_wise)
         assert open(p).read() == str(g[f"text_{level}"])
+    # one upload, both levels (gbrs_counts_create / _get), in either order and twice: the workspace is re-used
+    from gbrs_amd.counts import AlignmentCounter
+    with AlignmentCounter(apm) as counter:
+        for level, grp_wise in (("genes", True), ("isoforms", False), ("genes", True)):
+            a, u, lu, names = counter.counts(grp_wise)
+            np.testing.assert_array_equal(a, g[f"{level}_aln"])
+            np.testing.assert_array_equal(u, g[f"{level}_uniq"])
+            np.testing.assert_array_equal(lu, g[f"{level}_locus_uniq"])
+            p = tmp_path / f"{level}.counter.tsv"
+            report_alignment_counts(apm, str(p), grp_wise=grp_wise, counter=counter)
+            assert open(p).read() == str(g[f"text_{level}"])
+    with pytest.raises(RuntimeError, match="closed"):
+        counter.counts()
 
 
 @pytest.mark.gpu
