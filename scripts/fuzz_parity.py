@@ -59,7 +59,14 @@ def hmm_case(rng):
     H = int(rng.choice([2, 3, 4, 5, 7, 8, 8, 8, 9, 16]))
     nch = int(rng.integers(1, 6))
     lens = [int(x) for x in rng.integers(1, 90 if H == 16 else 400, size=nch)]
-    ns = int(rng.choice([1, 1, 2, 4, 5, 7, 16, 25, 40]))      # from 16 on: the MFMA sweeps (GBRS_TUNING_HMM_MFMA below)
+    ns = int(rng.choice([1, 1, 2, 3, 4, 5, 7, 16, 25, 40]))   # from 16 on: the MFMA sweeps (GBRS_TUNING_HMM_MFMA below)
+    # the blocked scan (1-2 samples, 36 states) with blocks short enough to cut these small chromosomes many times, and
+    # the samples-on-lanes backpointers with partly filled wavefronts
+    tuning = {"GBRS_TUNING_HMM_BLOCK_GENES": str(int(rng.choice([2, 3, 5, 9, 17, 40]))),
+              "GBRS_TUNING_HMM_BLOCKS_MAX": str(int(rng.choice([2, 5, 64]))),
+              "GBRS_TUNING_HMM_BLOCKED": str(int(rng.choice([0, 2, 2, 4]))),
+              "GBRS_TUNING_HMM_BPLANES": str(int(rng.choice([5, 32])))}
+    os.environ.update(tuning)
     style = str(rng.choice(["benign", "do"])) if H == 8 else "benign"
     minus_one = bool(rng.integers(0, 2))
     seed = int(rng.integers(1, 1 << 30))
@@ -87,7 +94,8 @@ def hmm_case(rng):
                 np.testing.assert_allclose(r[k], res[c][k], rtol=1e-9, atol=1e-9)
             np.testing.assert_allclose(r["gamma"], res[c]["gamma"], rtol=1e-8, atol=1e-300)
     hmm.close()
-    return f"HMM H={H} lens={lens} samples={ns} tprob_n-1={minus_one} tables={style}"
+    return (f"HMM H={H} lens={lens} samples={ns} tprob_n-1={minus_one} tables={style} "
+            + " ".join(f"{k[16:].lower()}={v}" for k, v in tuning.items()))
 
 
 def main():
