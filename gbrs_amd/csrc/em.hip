@@ -1519,6 +1519,15 @@ int gbrs_em_group_sums(gbrs_em_t *em, int64_t G, const int64_t *group_ptr, const
 
 void *gbrs_em_stream(gbrs_em_t *em) { return em ? (void *)em->stream : nullptr; }
 
+#if defined(GBRS_DIAG_TILE_TIMES)
+// diagnostic build only: device buffer of 8 x uint64 per E-step workgroup (nullptr switches the stamps off)
+int gbrs_debug_set_tile_stamps(void *device_ptr) {
+    unsigned long long *p = static_cast<unsigned long long *>(device_ptr);
+    GBRS_HIP_CHECK(hipMemcpyToSymbol(HIP_SYMBOL(g_tile_stamps), &p, sizeof(p)));
+    return GBRS_OK;
+}
+#endif
+
 int gbrs_em_set_stream(gbrs_em_t *em, void *stream) {
     if (!em) return fail(GBRS_ERR_INVALID, "handle is NULL");
     GBRS_TRY(select_device(em->device));
