@@ -46,6 +46,7 @@ GBRS_EM_DETERMINISTIC = 32
 GBRS_EM_KEEP_CSC = 64
 GBRS_EM_SIDE_BY_SIDE = 128
 GBRS_EM_ONE_SHOT = 256
+GBRS_EM_NO_LOCUS_SETS = 512
 
 
 class EmInfo(C.Structure):
@@ -58,6 +59,7 @@ class EmInfo(C.Structure):
         ("num_tiles", C.c_uint64), ("num_slots", C.c_uint64), ("num_long_rows", C.c_uint64),
         ("num_heavy_loci", C.c_uint64), ("num_light_loci", C.c_uint64), ("estep_bytes", C.c_uint64),
         ("retained_build_bytes", C.c_uint64),
+        ("num_locus_sets", C.c_uint64),
     ]
 
 

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/gbrs_hip.h"
@@ -87,6 +88,10 @@ struct DevBuf {
         return GBRS_OK;
     }
     size_t bytes() const { return n * sizeof(T); }
+    void swap(DevBuf &o) {
+        std::swap(p, o.p);
+        std::swap(n, o.n);
+    }
 };
 
 // Wall-clock checkpoints of the one-off build steps, printed to stderr when GBRS_TUNING_BUILD_TIMES=1.

@@ -104,7 +104,17 @@ struct TileLayout {
     DevBuf<uint64_t> long_ptr;       // n_long + 1 offsets into long_loc / long_mask
     DevBuf<uint32_t> long_loc, long_mask;
     DevBuf<double> long_weight;      // n_long
-    DevBuf<double> acc_extra;        // L*H, global-atomic target of the long-row kernel
+    DevBuf<double> acc_extra;        // Lx*H, global-atomic target of the long-row kernel
+    // Locus sets (GBRS_EM_NO_LOCUS_SETS switches them off).  A read whose alignments to several loci all carry the same
+    // haplotype mask contributes  sum_h m_h * (theta[l1,h] + theta[l2,h] + ...)  to its denominator and the same v to every
+    // one of those loci: the set {l1, l2, ...} behaves like one locus with theta = the sum of its members'.  The build
+    // gives every distinct such set an id n_loci + k ("virtual locus"), the read becomes ONE word on that id, and the
+    // layout (dictionaries, slots, gather) treats the n_loci_ext = n_loci + n_sets ids alike; after the gather a real
+    // locus adds the sums of the sets it belongs to (ls_ptr / ls_list, ascending: a fixed order), after the M-step the
+    // sets' theta are re-summed from their members (set_ptr / set_members).
+    uint32_t n_loci_ext = 0, n_sets = 0;
+    DevBuf<uint32_t> set_ptr, set_members;   // n_sets + 1 offsets; member loci of every set, ascending
+    DevBuf<uint32_t> ls_ptr, ls_list;        // n_loci + 1 offsets; the sets (as k = id - n_loci) a real locus belongs to
     // GBRS_EM_ONE_SHOT: the build temporaries stay allocated until the layout goes (common.h, DeferFrees): a
     // process that handles one sample and exits never pays for returning them.  Without the flag they are freed in
     // one pass when the build ends.
@@ -124,7 +134,8 @@ struct TileLayout {
 int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L, uint32_t H, uint64_t N,
                       const uint32_t *ent_row, const uint64_t *col_ptr, const double *count,
                       bool merge_identical_rows, int row_order /* 0 sorted, 1 interleaved, 2 streams */,
-                      bool deterministic, hipStream_t stream, unsigned side_by_side = 1 /* handles sharing the device */);
+                      bool deterministic, hipStream_t stream, unsigned side_by_side = 1 /* handles sharing the device */,
+                      bool locus_sets = false);
 
 // `gbrs compress`: equivalence classes of identical rows, in first-seen order.
 struct CompressResult {

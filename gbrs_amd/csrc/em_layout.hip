@@ -177,6 +177,126 @@ __global__ void row_start_kernel(uint64_t np, uint64_t nrows, const uint32_t *__
     row_orig[ridx[p]] = prow[p];
 }
 
+// ---- locus sets (em_layout.h) ---------------------------------------------------------------------
+constexpr uint32_t NO_SET = 0xFFFFFFFFu;
+constexpr uint32_t SET_MAX_LOCI = 1024;
+
+__device__ __forceinline__ uint64_t mix64(uint64_t h, uint64_t v) {
+    h = (h ^ v) * 0x9E3779B97F4A7C15ull;
+    return h ^ (h >> 29);
+}
+
+// flag[r] = 1 when row r has >= 2 (row, locus) pairs that all carry one mask; key[r] = hash of its locus list
+__global__ void set_candidate_kernel(uint64_t nrows, const uint32_t *__restrict__ rowstart, const uint32_t *__restrict__ ploc,
+                                     const uint32_t *__restrict__ pmask, uint64_t *__restrict__ key, uint32_t *__restrict__ flag) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrows) return;
+    const uint32_t b = rowstart[r], e = rowstart[r + 1];
+    bool ok = e - b >= 2 && e - b <= SET_MAX_LOCI;
+    uint64_t h = e - b;
+    if (ok) {
+        const uint32_t m0 = pmask[b];
+        for (uint32_t k = b; k < e; ++k) {
+            ok &= pmask[k] == m0;
+            h = mix64(h, ploc[k]);
+        }
+    }
+    flag[r] = ok ? 1u : 0u;
+    key[r] = h;
+}
+
+__global__ void set_compact_kernel(uint64_t nrows, const uint32_t *__restrict__ flag, const uint32_t *__restrict__ cidx,
+                                   const uint64_t *__restrict__ key, uint64_t *__restrict__ ckey, uint32_t *__restrict__ crow) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrows || !flag[r]) return;
+    ckey[cidx[r]] = key[r];
+    crow[cidx[r]] = (uint32_t)r;
+}
+
+// candidates sorted by hash: head[i] = 1 when candidate i's locus list differs from its predecessor's (exact comparison:
+// a hash collision can only split a set in two, never join two)
+__global__ void set_head_kernel(uint64_t nc, const uint64_t *__restrict__ skey, const uint32_t *__restrict__ srow,
+                                const uint32_t *__restrict__ rowstart, const uint32_t *__restrict__ ploc, uint32_t *__restrict__ head) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nc) return;
+    bool same = i > 0 && skey[i] == skey[i - 1];
+    if (same) {
+        const uint32_t a = srow[i], b = srow[i - 1];
+        const uint32_t a0 = rowstart[a], b0 = rowstart[b], n = rowstart[a + 1] - a0;
+        same = n == rowstart[b + 1] - b0;
+        for (uint32_t k = 0; same && k < n; ++k) same = ploc[a0 + k] == ploc[b0 + k];
+    }
+    head[i] = same ? 0u : 1u;
+}
+
+__global__ void set_assign_kernel(uint64_t nc, const uint32_t *__restrict__ head, const uint32_t *__restrict__ hincl,
+                                  const uint32_t *__restrict__ srow, const uint32_t *__restrict__ rowstart,
+                                  uint32_t *__restrict__ set_of_row, uint32_t *__restrict__ set_len, uint32_t *__restrict__ set_rep) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nc) return;
+    const uint32_t k = hincl[i] - 1, r = srow[i];
+    set_of_row[r] = k;
+    if (head[i]) {
+        set_len[k] = rowstart[r + 1] - rowstart[r];
+        set_rep[k] = r;
+    }
+}
+
+__global__ void set_members_kernel(uint32_t n_sets, const uint32_t *__restrict__ set_ptr, const uint32_t *__restrict__ set_rep,
+                                   const uint32_t *__restrict__ rowstart, const uint32_t *__restrict__ ploc,
+                                   uint32_t *__restrict__ members, uint64_t *__restrict__ lkeys) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_sets) return;
+    const uint32_t b = rowstart[set_rep[k]], o = set_ptr[k], n = set_ptr[k + 1] - o;
+    for (uint32_t j = 0; j < n; ++j) {
+        members[o + j] = ploc[b + j];
+        lkeys[o + j] = ((uint64_t)ploc[b + j] << 32) | k;      // (member locus, set): sorted later into locus -> sets
+    }
+}
+
+__global__ void set_row_len_kernel(uint64_t nrows, const uint32_t *__restrict__ rowstart, const uint32_t *__restrict__ set_of_row,
+                                   uint32_t *__restrict__ newlen) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrows) return;
+    newlen[r] = set_of_row[r] != NO_SET ? 1u : rowstart[r + 1] - rowstart[r];
+}
+
+__global__ void set_rewrite_kernel(uint64_t nrows, uint32_t L, const uint32_t *__restrict__ rowstart,
+                                   const uint32_t *__restrict__ set_of_row, const uint32_t *__restrict__ newstart,
+                                   const uint32_t *__restrict__ ploc, const uint32_t *__restrict__ pmask,
+                                   uint32_t *__restrict__ ploc2, uint32_t *__restrict__ pmask2) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrows) return;
+    const uint32_t b = rowstart[r], e = rowstart[r + 1], o = newstart[r], k = set_of_row[r];
+    if (k != NO_SET) {
+        ploc2[o] = L + k;
+        pmask2[o] = pmask[b];
+    } else {
+        for (uint32_t j = b; j < e; ++j) {
+            ploc2[o + (j - b)] = ploc[j];
+            pmask2[o + (j - b)] = pmask[j];
+        }
+    }
+}
+
+// ls_ptr[l] = first position of locus l in the sorted (locus << 32 | set) keys; ls_list = the keys' low halves
+__global__ void set_locus_ptr_kernel(uint32_t L, uint64_t n, const uint64_t *__restrict__ skeys, uint32_t *__restrict__ ls_ptr) {
+    const uint32_t l = blockIdx.x * blockDim.x + threadIdx.x;
+    if (l > L) return;
+    uint64_t lo = 0, hi = n;
+    const uint64_t want = (uint64_t)l << 32;
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi) >> 1;
+        if (skeys[mid] < want) lo = mid + 1; else hi = mid;
+    }
+    ls_ptr[l] = (uint32_t)lo;
+}
+
+__global__ void set_locus_list_kernel(uint64_t n, const uint64_t *__restrict__ skeys, uint32_t *__restrict__ ls_list) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) ls_list[i] = (uint32_t)skeys[i];
+}
+
 __device__ __forceinline__ uint32_t mix32(uint32_t h, uint32_t v) {
     h ^= v + 0x9e3779b9u + (h << 6) + (h >> 2);
     h *= 0x85ebca6bu;
@@ -829,9 +949,12 @@ int compress_device(CompressResult &out, uint64_t R, uint32_t L, uint32_t H, uin
     return GBRS_OK;
 }
 
-int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L, uint32_t H, uint64_t N,
+int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L_in, uint32_t H, uint64_t N,
                       const uint32_t *ent_row, const uint64_t *col_ptr, const double *count,
-                      bool merge, int row_order, bool deterministic, hipStream_t s, unsigned side_by_side) {
+                      bool merge, int row_order, bool deterministic, hipStream_t s, unsigned side_by_side, bool locus_sets) {
+    uint32_t L = L_in;                     // grows by the number of locus sets in step 3b
+    out.n_loci_ext = L_in;
+    out.n_sets = 0;
     const bool interleave = row_order == 1, streams = row_order == 2;
     if (H > 16) return fail(GBRS_ERR_INVALID, "the tiled layout packs the haplotype mask in 16 bits (H <= 16)");
     if (N >= 0xFFFFFFFFull || L >= (1u << 27))
@@ -922,6 +1045,80 @@ int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L, uint32_t H, uint6
     GBRS_HIP_CHECK(hipStreamSynchronize(s));
     rflag.release(); ridx.release(); prow.release();
     stg.mark("3 rows");
+    // 3b. locus sets: a row whose pairs all carry one mask becomes one pair on the id of its locus set (em_layout.h)
+    if (locus_sets && R1 > 0) {
+        DevBuf<uint64_t> key, ckey, skey2;
+        DevBuf<uint32_t> flag, cidx, crow, srow2;
+        GBRS_TRY(key.alloc(R1)); GBRS_TRY(flag.alloc(R1)); GBRS_TRY(cidx.alloc(R1));
+        hipLaunchKernelGGL(set_candidate_kernel, dim3(grid_for(R1)), dim3(256), 0, s, (uint64_t)R1, rowstart.p, ploc.p, pmask.p,
+                           key.p, flag.p);
+        GBRS_TRY(exclusive_scan(sc, flag.p, cidx.p, R1, s));
+        uint32_t C = 0;
+        GBRS_TRY(fetch_last_plus(cidx.p, flag.p, R1, C, s));
+        if (C > 0) {
+            GBRS_TRY(ckey.alloc(C)); GBRS_TRY(skey2.alloc(C)); GBRS_TRY(crow.alloc(C)); GBRS_TRY(srow2.alloc(C));
+            hipLaunchKernelGGL(set_compact_kernel, dim3(grid_for(R1)), dim3(256), 0, s, (uint64_t)R1, flag.p, cidx.p, key.p,
+                               ckey.p, crow.p);
+            GBRS_TRY(sort_pairs<uint64_t>(sc, ckey.p, skey2.p, crow.p, srow2.p, C, 64, s));
+            key.release(); ckey.release(); crow.release();
+            DevBuf<uint32_t> head2, hincl2, set_of_row;
+            GBRS_TRY(head2.alloc(C)); GBRS_TRY(hincl2.alloc(C)); GBRS_TRY(set_of_row.alloc(R1));
+            hipLaunchKernelGGL(set_head_kernel, dim3(grid_for(C)), dim3(256), 0, s, (uint64_t)C, skey2.p, srow2.p, rowstart.p,
+                               ploc.p, head2.p);
+            GBRS_TRY(inclusive_scan(sc, head2.p, hincl2.p, C, s));
+            uint32_t V = 0;
+            GBRS_HIP_CHECK(hipMemcpyAsync(&V, hincl2.p + C - 1, 4, hipMemcpyDeviceToHost, s));
+            GBRS_HIP_CHECK(hipStreamSynchronize(s));
+            if ((uint64_t)L_in + V >= (1u << 27))
+                return fail(GBRS_ERR_INVALID, "the tiled layout needs fewer than 2^27 loci and locus sets per handle");
+            DevBuf<uint32_t> set_len, set_rep;
+            GBRS_TRY(set_len.alloc(V)); GBRS_TRY(set_rep.alloc(V));
+            GBRS_HIP_CHECK(hipMemsetAsync(set_of_row.p, 0xFF, set_of_row.bytes(), s));
+            hipLaunchKernelGGL(set_assign_kernel, dim3(grid_for(C)), dim3(256), 0, s, (uint64_t)C, head2.p, hincl2.p, srow2.p,
+                               rowstart.p, set_of_row.p, set_len.p, set_rep.p);
+            GBRS_TRY(out.set_ptr.alloc((size_t)V + 1));
+            GBRS_TRY(exclusive_scan(sc, set_len.p, out.set_ptr.p, V, s));
+            uint32_t n_members = 0;
+            GBRS_TRY(fetch_last_plus(out.set_ptr.p, set_len.p, V, n_members, s));
+            GBRS_HIP_CHECK(hipMemcpyAsync(out.set_ptr.p + V, &n_members, 4, hipMemcpyHostToDevice, s));
+            GBRS_TRY(out.set_members.alloc(n_members));
+            DevBuf<uint64_t> lkeys, lkeys2;
+            GBRS_TRY(lkeys.alloc(n_members)); GBRS_TRY(lkeys2.alloc(n_members));
+            hipLaunchKernelGGL(set_members_kernel, dim3(grid_for(V)), dim3(256), 0, s, V, out.set_ptr.p, set_rep.p, rowstart.p,
+                               ploc.p, out.set_members.p, lkeys.p);
+            GBRS_TRY(sort_keys64(sc, lkeys.p, lkeys2.p, n_members, 64, s));
+            GBRS_TRY(out.ls_ptr.alloc((size_t)L_in + 1));
+            GBRS_TRY(out.ls_list.alloc(n_members));
+            hipLaunchKernelGGL(set_locus_ptr_kernel, dim3(grid_for((uint64_t)L_in + 1)), dim3(256), 0, s, L_in, (uint64_t)n_members,
+                               lkeys2.p, out.ls_ptr.p);
+            hipLaunchKernelGGL(set_locus_list_kernel, dim3(grid_for(n_members)), dim3(256), 0, s, (uint64_t)n_members, lkeys2.p,
+                               out.ls_list.p);
+            // the rows in their new form
+            DevBuf<uint32_t> newlen, rowstart2, ploc2, pmask2;
+            GBRS_TRY(newlen.alloc(R1)); GBRS_TRY(rowstart2.alloc((size_t)R1 + 1));
+            hipLaunchKernelGGL(set_row_len_kernel, dim3(grid_for(R1)), dim3(256), 0, s, (uint64_t)R1, rowstart.p, set_of_row.p,
+                               newlen.p);
+            GBRS_TRY(exclusive_scan(sc, newlen.p, rowstart2.p, R1, s));
+            uint32_t P2 = 0;
+            GBRS_TRY(fetch_last_plus(rowstart2.p, newlen.p, R1, P2, s));
+            GBRS_HIP_CHECK(hipMemcpyAsync(rowstart2.p + R1, &P2, 4, hipMemcpyHostToDevice, s));
+            GBRS_TRY(ploc2.alloc(P2)); GBRS_TRY(pmask2.alloc(P2));
+            hipLaunchKernelGGL(set_rewrite_kernel, dim3(grid_for(R1)), dim3(256), 0, s, (uint64_t)R1, L_in, rowstart.p,
+                               set_of_row.p, rowstart2.p, ploc.p, pmask.p, ploc2.p, pmask2.p);
+            GBRS_HIP_CHECK(hipStreamSynchronize(s));
+            GBRS_HIP_CHECK(hipGetLastError());
+            rowstart.swap(rowstart2); ploc.swap(ploc2); pmask.swap(pmask2);
+            out.n_sets = V;
+            out.n_pairs = P2;
+            L = L_in + V;
+            out.n_loci_ext = L;
+            GBRS_TRY(out.slot_ptr.alloc((size_t)L + 1));
+            GBRS_HIP_CHECK(hipMemsetAsync(out.slot_ptr.p, 0, out.slot_ptr.bytes(), s));
+            GBRS_TRY(out.locus_class.alloc(L));
+            GBRS_HIP_CHECK(hipMemsetAsync(out.locus_class.p, 0, out.locus_class.bytes(), s));
+        }
+        stg.mark("3b locus sets");
+    }
     // 4. order rows so that similar rows are adjacent
     DevBuf<uint64_t> rkey, skey;
     DevBuf<uint32_t> ident, srow;

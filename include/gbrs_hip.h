@@ -97,6 +97,13 @@ typedef struct gbrs_em gbrs_em_t;
  * shorter).  gbrs_em_info.retained_build_bytes reports what is held.  Without the flag create frees them in one pass
  * before it returns, so several live handles cost their layouts only. */
 #define GBRS_EM_ONE_SHOT 256u
+/* Locus sets off.  By default a read whose alignments to several loci all carry the same haplotype mask is stored as
+ * one word on the id of its locus SET: its denominator is sum_h m_h * (theta[l1,h] + theta[l2,h] + ...) and every
+ * member locus receives the same count/den, so the set behaves like one locus whose theta is the sum of its members'.
+ * After every E-step a locus adds the sums of the sets it belongs to (fixed order), after every M-step the sets' theta
+ * are re-summed.  Same arithmetic up to the association of those sums (agrees with the plain form to ~1e-15 relative);
+ * gbrs_em_info.num_locus_sets says how many sets the layout found.  The flag keeps one word per (read, locus) pair. */
+#define GBRS_EM_NO_LOCUS_SETS 512u
 
 /*
  * Replaces: AlignmentPropertyMatrix(h5file=...) as consumed by EMfactory.__init__
@@ -236,6 +243,7 @@ typedef struct gbrs_em_info {
                                    headers, dictionary, theta gather, slot stores [, row weights]  */
     uint64_t retained_build_bytes; /* device bytes of build temporaries the handle still holds
                                    (GBRS_EM_ONE_SHOT; 0 otherwise)                                */
+    uint64_t num_locus_sets;       /* distinct locus sets of the tile layout (GBRS_EM_NO_LOCUS_SETS: 0) */
 } gbrs_em_info_t;
 int gbrs_em_info(gbrs_em_t *em, gbrs_em_info_t *info);
 

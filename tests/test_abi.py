@@ -41,7 +41,7 @@ def test_struct_sizes(tmp_path):
     import shutil
     import subprocess
     from gbrs_amd import _lib
-    assert C.sizeof(_lib.EmInfo) == 8 * 8 + 4 * 4 + 7 * 8
+    assert C.sizeof(_lib.EmInfo) == 8 * 8 + 4 * 4 + 8 * 8
     assert C.sizeof(_lib.HmmInfo) == 2 * 8 + 4 * 8 + 2 * 4 + 8
     cc = shutil.which("gcc") or shutil.which("cc")
     if cc is None:

@@ -17,7 +17,8 @@ RTOL = 1e-9
 LAYOUTS = {"tiles": dict(), "tiles_merged": dict(merge_identical_rows=True), "csc": dict(csc_layout=True),
            "tiles_sorted": dict(extra_flags=16), "tiles_merged_interleaved": dict(merge_identical_rows=True, extra_flags=16),
            "tiles_deterministic": dict(deterministic=True),
-           "tiles_deterministic_merged": dict(deterministic=True, merge_identical_rows=True)}
+           "tiles_deterministic_merged": dict(deterministic=True, merge_identical_rows=True),
+           "tiles_no_locus_sets": dict(extra_flags=512)}
 
 
 def pack_mask(gtmask):
@@ -539,6 +540,82 @@ def _random_rows_problem(R, H, L, seed, min_loci, max_loci, with_count):
     count = rng.integers(1, 5, size=R).astype(np.float64) if with_count else None
     eff = np.tile(np.maximum(np.round(rng.lognormal(7.3, 0.6, size=L)) - 99.0, 1.0), (H, 1))
     return indptr, indices, count, np.ascontiguousarray(eff)
+
+
+def _shared_mask_rows_problem(R, H, L, seed, max_loci, with_count, n_lists=None):
+    """Rows whose alignments to several loci mostly share one haplotype mask (what a read that hits the same exon of a
+    gene's isoforms looks like): the layout stores such a row as one word on a locus SET.  The locus lists are drawn from
+    a pool so that sets repeat; the second half of the loci only ever occur inside multi-locus rows (no slot of their own)."""
+    rng = np.random.default_rng(seed)
+    n_lists = n_lists or max(R // 20, 4)
+    pool = []
+    for _ in range(n_lists):
+        k = int(rng.integers(1, max_loci + 1))
+        lo = rng.choice(L // 2, size=1) if k == 1 else rng.choice(L, size=k, replace=False)
+        pool.append(np.sort(lo))
+    which = rng.integers(0, n_lists, size=R)
+    nl = np.array([len(pool[w]) for w in which])
+    rows = np.repeat(np.arange(R, dtype=np.int64), nl)
+    loci = np.concatenate([pool[w] for w in which]).astype(np.int64)
+    row_mask = rng.integers(1, 1 << H, size=R, dtype=np.int64)
+    masks = np.repeat(row_mask, nl)
+    odd = rng.random(len(masks)) < 0.15                       # some rows keep a locus with a mask of its own
+    masks[odd] = rng.integers(1, 1 << H, size=int(odd.sum()), dtype=np.int64)
+    indptr, indices = [], []
+    for h in range(H):
+        sel = (masks >> h) & 1 == 1
+        order = np.lexsort((rows[sel], loci[sel]))
+        indices.append(rows[sel][order].astype(np.uint32))
+        indptr.append(np.searchsorted(loci[sel][order], np.arange(L + 1)).astype(np.uint32))
+    count = rng.integers(1, 5, size=R).astype(np.float64) if with_count else None
+    eff = np.tile(np.maximum(np.round(rng.lognormal(7.3, 0.6, size=L)) - 99.0, 1.0), (H, 1))
+    return indptr, indices, count, np.ascontiguousarray(eff)
+
+
+@pytest.mark.parametrize("R,H,L,hi,cnt,pc", [(6000, 8, 400, 5, False, 0.0),       # sets of 2-5 loci, many rows per set
+                                             (3000, 8, 300, 60, True, 0.0),       # sets larger than a row may have words (long rows collapse)
+                                             (4000, 16, 500, 6, False, 0.5),      # 16 haplotypes, pseudocount
+                                             (2500, 3, 200, 4, True, 0.0),        # generic haplotype count (thread-per-locus M-step)
+                                             (30000, 8, 20000, 3, False, 0.0)])   # many sets: dictionary cuts
+def test_em_locus_sets_vs_oracle(R, H, L, hi, cnt, pc):
+    """Rows with one mask over several loci become one word on a locus set (include/gbrs_hip.h, GBRS_EM_NO_LOCUS_SETS):
+    prepare, steps, the stopping rule and the expected counts against the oracle, for the plain, merged, deterministic
+    layouts and with the sets switched off; the building blocks of the sharded path (partial vector handed out and taken
+    back) give the same numbers."""
+    from gbrs_amd import _lib
+    from gbrs_amd.engine import EmEngine
+    from oracle.em_oracle import EMOracle
+    indptr, indices, count, eff = _shared_mask_rows_problem(R, H, L, 77 + R, hi, cnt)
+    o = EMOracle(R, L, H, indptr, indices, count)
+    o.prepare(pc, eff)
+    theta0 = o.theta.copy()
+    o.run(tol=0.0, max_iters=5)
+    for flags in (0, 1, 32, 512):                                # tiles, tiles + merge, deterministic tiles, no sets
+        eng = EmEngine.from_host(R, L, H, indptr, indices, count, eff, flags=flags)
+        inf = eng.info()
+        assert (inf.num_locus_sets > 0) == (flags != 512)
+        eng.prepare(pc)
+        close(eng.theta(), theta0)
+        n, hist = eng.run(model=4, tol=0.0, max_iters=5)
+        assert n == 5
+        np.testing.assert_allclose(hist, o.err_history, rtol=1e-7)
+        close(eng.theta(), o.theta)
+        close(eng.expected_counts(), o.expected_read_counts())
+        eng.set_theta(theta0)                                     # theta handed in: the sets' theta are re-summed
+        eng.step(5)
+        close(eng.theta(), o.theta)
+        eng.close()
+    if pc == 0.0:
+        eng = EmEngine.from_host(R, L, H, indptr, indices, count, eff)
+        eng.prepare_partial()
+        eng.finish_prepare(0.0)
+        close(eng.theta(), theta0)
+        for _ in range(5):
+            eng.estep_partial()
+            eng.finish_step(want_err=False)
+        close(eng.theta(), o.theta)
+        close(eng.expected_counts(), o.expected_read_counts())
+        eng.close()
 
 
 @pytest.mark.parametrize("R,H,L,lo,hi,cnt", [(4000, 8, 3000, 1, 12, False),      # cold tiles, rows up to 12 words
