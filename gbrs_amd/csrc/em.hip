@@ -553,55 +553,6 @@ int em_check_float(gbrs_em *em, EmScalars &host) {
 ErrArgs em_err_args(gbrs_em *em, double target_err);
 int em_flush_err(gbrs_em *em);
 
-// ---- locus sets (em_layout.h): ids [L, L + n_sets) of theta / acc stand for sets of loci -------------------------
-// after the gather of all L + n_sets ids: a real locus adds the sums of the sets it belongs to, in ascending set order
-__global__ void __launch_bounds__(256)
-fold_sets_kernel(uint32_t L, uint32_t H, const uint32_t *__restrict__ ls_ptr, const uint32_t *__restrict__ ls_list,
-                 double *__restrict__ acc, const EmScalars *__restrict__ sc, int honour_stop) {
-    if (honour_stop && sc->stop) return;
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (uint64_t)L * H) return;
-    const uint32_t l = (uint32_t)(i / H), h = (uint32_t)(i - (uint64_t)l * H);
-    const uint32_t k0 = ls_ptr[l], k1 = ls_ptr[l + 1];
-    if (k0 == k1) return;
-    double a = acc[i];
-    for (uint32_t k = k0; k < k1; ++k) a += acc[((size_t)L + ls_list[k]) * H + h];
-    acc[i] = a;
-}
-
-// after the M-step (and whenever theta is set): theta of a set = the sum of its members', in member order
-__global__ void __launch_bounds__(256)
-sets_theta_kernel(uint32_t L, uint32_t H, uint32_t n_sets, const uint32_t *__restrict__ set_ptr,
-                  const uint32_t *__restrict__ members, double *__restrict__ theta, const EmScalars *__restrict__ sc,
-                  int honour_stop) {
-    if (honour_stop && sc->stop) return;
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (uint64_t)n_sets * H) return;
-    const uint32_t k = (uint32_t)(i / H), h = (uint32_t)(i - (uint64_t)k * H);
-    double t = 0.0;
-    for (uint32_t j = set_ptr[k]; j < set_ptr[k + 1]; ++j) t += theta[(size_t)members[j] * H + h];
-    theta[((size_t)L + k) * H + h] = t;
-}
-
-// prepare(): theta = 1 for every locus (EMfactory.py:95), so a set's is the number of its members
-__global__ void __launch_bounds__(256)
-sets_ones_kernel(uint32_t L, uint32_t H, uint32_t n_sets, const uint32_t *__restrict__ set_ptr, double *__restrict__ theta) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= ((uint64_t)L + n_sets) * H) return;
-    const uint32_t l = (uint32_t)(i / H);
-    theta[i] = l < L ? 1.0 : (double)(set_ptr[l - L + 1] - set_ptr[l - L]);
-}
-
-int em_launch_sets_theta(gbrs_em *em, bool honour_stop) {
-    const TileLayout &tl = em->tl;
-    if (em->layout != 1 || tl.n_sets == 0) return GBRS_OK;
-    const uint64_t n = (uint64_t)tl.n_sets * em->H;
-    hipLaunchKernelGGL(sets_theta_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, em->stream, em->L, em->H, tl.n_sets,
-                       tl.set_ptr.p, tl.set_members.p, em->theta.p, em->scalars.p, honour_stop ? 1 : 0);
-    GBRS_HIP_CHECK(hipGetLastError());
-    return GBRS_OK;
-}
-
 template <int HT, bool ONES>
 int em_estep_tiles_h(gbrs_em *em) {
     const TileLayout &tl = em->tl;
@@ -612,20 +563,11 @@ int em_estep_tiles_h(gbrs_em *em) {
         em->err_pending = false;
         const dim3 grid((unsigned)tl.n_tiles + ea.n_err_blocks), block(TILE_THREADS);
         const double *ww = tl.weighted ? tl.word_weight.p : (const double *)nullptr;
-        // prepare() with locus sets: theta has been filled with ones and set sizes (sets_ones_kernel), the ordinary kernel
-        // reads it - the ONES form has the constant 1 built in
-        const bool ones_from_theta = ONES && tl.n_sets > 0;
+        const SetArgs sets{em->L, tl.n_sets ? tl.set_ptr.p : nullptr, tl.set_members.p, tl.dest_list.p};
 #define GBRS_LAUNCH_TILES(W, D)                                                                                        \
-        do {                                                                                                           \
-            if (ones_from_theta)                                                                                       \
-                hipLaunchKernelGGL((tile_estep_kernel<HT, W, false, D>), grid, block, 0, em->stream, em->H, tl.tiles.p, tl.words.p, \
-                                   tl.dict.p, ww, em->theta.p, tl.partials.p, tl.slot_dest.p, em->acc.p, em->scalars.p, \
-                                   (uint32_t)tl.n_tiles, ea);                                                          \
-            else                                                                                                       \
-                hipLaunchKernelGGL((tile_estep_kernel<HT, W, ONES, D>), grid, block, 0, em->stream, em->H, tl.tiles.p, tl.words.p, \
-                                   tl.dict.p, ww, em->theta.p, tl.partials.p, tl.slot_dest.p, em->acc.p, em->scalars.p, \
-                                   (uint32_t)tl.n_tiles, ea);                                                          \
-        } while (0)
+        hipLaunchKernelGGL((tile_estep_kernel<HT, W, ONES, D>), grid, block, 0, em->stream, em->H, tl.tiles.p, tl.words.p, \
+                           tl.dict.p, ww, em->theta.p, tl.partials.p, tl.slot_dest.p, em->acc.p, em->scalars.p,       \
+                           (uint32_t)tl.n_tiles, ea, sets)
         if (tl.deterministic) {           // fixed-order sums instead of LDS float atomics (GBRS_EM_DETERMINISTIC)
             if (tl.weighted) GBRS_LAUNCH_TILES(true, true); else GBRS_LAUNCH_TILES(false, true);
         } else {
@@ -640,12 +582,6 @@ int em_estep_tiles(gbrs_em *em, bool materialize, bool skip_gather = false) {
     if (ONES || !em->tl.n_tiles) GBRS_TRY(em_flush_err(em));   // prepare / no tile launch to ride on
 
     TileLayout &tl = em->tl;
-    const uint32_t Lx = tl.n_sets ? tl.n_loci_ext : em->L;     // real loci + locus sets
-    if (ONES && tl.n_sets) {
-        const uint64_t nx = (uint64_t)Lx * em->H;
-        hipLaunchKernelGGL(sets_ones_kernel, dim3((unsigned)((nx + 255) / 256)), dim3(256), 0, em->stream, em->L, em->H,
-                           tl.n_sets, tl.set_ptr.p, em->theta.p);
-    }
     switch (em->H) {
         case 1: GBRS_TRY((em_estep_tiles_h<1, ONES>(em))); break;
         case 2: GBRS_TRY((em_estep_tiles_h<2, ONES>(em))); break;
@@ -672,24 +608,18 @@ int em_estep_tiles(gbrs_em *em, bool materialize, bool skip_gather = false) {
     uint32_t HP = 1;
     while (HP < em->H) HP <<= 1;
     const bool pow2 = (em->H & (em->H - 1)) == 0;
-    // (with locus sets every element is rewritten in every step: the fold below adds in place)
-    const bool all = materialize || em->acc_external || !pow2 || tl.n_sets > 0;     // write every element of acc
-    const uint64_t elems = all ? (uint64_t)Lx * em->H : (uint64_t)tl.n_light * em->H;
+    const bool all = materialize || em->acc_external || !pow2;     // write every element of acc
+    const uint64_t elems = all ? (uint64_t)em->L * em->H : (uint64_t)tl.n_light * em->H;
     const unsigned light = (unsigned)((elems + 255) / 256);
     const unsigned heavy = (unsigned)((tl.n_heavy + 3) / 4);
     em->acc_needs_extra = !all && tl.n_long > 0;
     if (skip_gather) return GBRS_OK;           // the fused gather + M-step kernel follows (em_one_step)
     if (light + heavy > 0)
-        hipLaunchKernelGGL(gather_kernel, dim3(light + heavy), dim3(256), 0, em->stream, Lx, em->H,
+        hipLaunchKernelGGL(gather_kernel, dim3(light + heavy), dim3(256), 0, em->stream, em->L, em->H,
                            HP, light, heavy, (uint32_t)tl.n_heavy, all ? 1 : 0, (uint32_t)tl.n_light, tl.light_loci.p,
                            tl.slot_ptr.p, tl.heavy_loci.p, tl.locus_class.p, tl.partials.p,
                            (tl.n_long && all) ? tl.acc_extra.p : (const double *)nullptr, em->acc.p, em->scalars.p,
                            ONES ? 0 : 1);
-    if (tl.n_sets) {
-        const uint64_t nr = (uint64_t)em->L * em->H;
-        hipLaunchKernelGGL(fold_sets_kernel, dim3((unsigned)((nr + 255) / 256)), dim3(256), 0, em->stream, em->L, em->H,
-                           tl.ls_ptr.p, tl.ls_list.p, em->acc.p, em->scalars.p, ONES ? 0 : 1);
-    }
     GBRS_HIP_CHECK(hipGetLastError());
     return GBRS_OK;
 }
@@ -731,29 +661,6 @@ int em_estep(gbrs_em *em, bool materialize = false) {
 #endif
 constexpr int MSTEP_EPT = GBRS_MSTEP_EPT;       // elements per thread of the elementwise workgroups (measured 1, 2, 4, 8)
 constexpr int HEAVY_ROWS = 16;     // slot rows a thread of a heavy workgroup has in flight
-// Locus sets in the fused launch: what the sets a real locus belongs to add to its A (em_layout.h).  A set with one slot
-// has its sum in acc (stored by its tile), one with several is summed here in slot order - by every member locus again,
-// which is cheaper than a launch of its own; ascending set order, so the result does not depend on the launch shape.
-__device__ __forceinline__ double sets_contrib(uint32_t L, uint32_t H, uint32_t l, uint32_t h, const uint32_t *__restrict__ ls_ptr,
-                                               const uint32_t *__restrict__ ls_list, const uint8_t *__restrict__ locus_class,
-                                               const uint32_t *__restrict__ slot_ptr, const double *__restrict__ slot_sums,
-                                               const double *__restrict__ acc) {
-    double a = 0.0;
-    const uint32_t k0 = ls_ptr[l], k1 = ls_ptr[l + 1];
-    for (uint32_t k = k0; k < k1; ++k) {
-        const uint32_t v = L + ls_list[k];
-        const uint32_t cls = locus_class[v];
-        if (cls == 1) {
-            a += acc[(size_t)v * H + h];
-        } else if (cls >= 2) {
-            double sv = 0.0;
-            for (uint32_t q = slot_ptr[v]; q < slot_ptr[v + 1]; ++q) sv += slot_sums[(size_t)q * H + h];
-            a += sv;
-        }
-    }
-    return a;
-}
-
 __global__ void __launch_bounds__(RED_THREADS)
 mstep_gather_kernel(uint32_t L, uint32_t H, uint32_t HP, uint32_t heavy_blocks, uint32_t light_blocks, uint32_t n_light,
                     const uint32_t *__restrict__ heavy_range, const uint32_t *__restrict__ light_range,
@@ -762,8 +669,7 @@ mstep_gather_kernel(uint32_t L, uint32_t H, uint32_t HP, uint32_t heavy_blocks, 
                     const double *__restrict__ acc_extra, double *__restrict__ theta,
                     const double *__restrict__ eff_len, double *__restrict__ counts, double *__restrict__ tot_prev,
                     double *__restrict__ tot_new, double *__restrict__ msums, uint32_t cap,
-                    const EmScalars *__restrict__ sc, const uint32_t *__restrict__ ls_ptr /* nullable: no locus sets */,
-                    const uint32_t *__restrict__ ls_list, const uint32_t *__restrict__ slot_ptr) {
+                    const EmScalars *__restrict__ sc) {
     __shared__ double lds[16];
     __shared__ double heavy_part[RED_THREADS / 64][16];
     const int stop = sc->stop;          // scalar load, in flight beside the vector loads below; looked at before the stores
@@ -774,12 +680,9 @@ mstep_gather_kernel(uint32_t L, uint32_t H, uint32_t HP, uint32_t heavy_blocks, 
         const uint32_t l = heavy_range[3 * blockIdx.x], k0 = heavy_range[3 * blockIdx.x + 1], k1 = heavy_range[3 * blockIdx.x + 2];
         const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
         const uint32_t h = threadIdx.x & (HP - 1), sub = threadIdx.x / HP, nsub = blockDim.x / HP;
-        const bool real = l < L;                       // a locus set (id >= L) has no M-step: its members sum it themselves
-        const bool live = h < H && real;
+        const bool live = h < H;
         const size_t il = (size_t)l * H + (live ? h : 0);
-        const double t_old = real ? theta[il] : 0.0, ln = (eff_len && real) ? eff_len[il] : 1.0;
-        double ax = (acc_extra && real) ? acc_extra[il] : 0.0;
-        if (ls_ptr && live && threadIdx.x < HP) ax += sets_contrib(L, H, l, h, ls_ptr, ls_list, locus_class, slot_ptr, slot_sums, acc);
+        const double t_old = theta[il], ax = acc_extra ? acc_extra[il] : 0.0, ln = eff_len ? eff_len[il] : 1.0;
         double a = 0.0;
         for (uint32_t k = k0 + sub; k < k1; k += HEAVY_ROWS * nsub) {          // fixed order: rounds, then rows of a round
             double r[HEAVY_ROWS];
@@ -816,7 +719,7 @@ mstep_gather_kernel(uint32_t L, uint32_t H, uint32_t HP, uint32_t heavy_blocks, 
                 tp += __shfl_xor(tp, off, WAVE);
                 tq += __shfl_xor(tq, off, WAVE);
             }
-            if (lane == 0 && !stop && real) {
+            if (lane == 0 && !stop) {
                 tot_prev[l] = tp;
                 tot_new[l] = tq;
             }
@@ -824,14 +727,11 @@ mstep_gather_kernel(uint32_t L, uint32_t H, uint32_t HP, uint32_t heavy_blocks, 
     } else if (blockIdx.x < heavy_blocks + light_blocks) {
         // one thread per (light locus, haplotype): the locus's 2..HEAVY_SLOTS slot rows all at once, added in slot order
         const uint64_t i = (uint64_t)(blockIdx.x - heavy_blocks) * blockDim.x + threadIdx.x;
-        const bool in_list = i < (uint64_t)n_light * H;
-        const uint32_t li = in_list ? (uint32_t)(i / H) : 0, h = (uint32_t)(i & (H - 1));
+        const bool live = i < (uint64_t)n_light * H;
+        const uint32_t li = live ? (uint32_t)(i / H) : 0, h = (uint32_t)(i & (H - 1));
         const uint32_t l = light_range[3 * li], k0 = light_range[3 * li + 1], k1 = light_range[3 * li + 2];
-        const bool live = in_list && l < L;            // (a locus set: nothing to do here)
-        const size_t il = live ? (size_t)l * H + h : 0;
-        const double t_old = theta[il], ln = eff_len ? eff_len[il] : 1.0;
-        double ax = acc_extra ? acc_extra[il] : 0.0;
-        if (ls_ptr && live) ax += sets_contrib(L, H, l, h, ls_ptr, ls_list, locus_class, slot_ptr, slot_sums, acc);
+        const size_t il = (size_t)l * H + h;
+        const double t_old = theta[il], ax = acc_extra ? acc_extra[il] : 0.0, ln = eff_len ? eff_len[il] : 1.0;
         double r[HEAVY_SLOTS];
 #pragma unroll
         for (int m = 0; m < HEAVY_SLOTS; ++m) r[m] = k0 + m < k1 ? slot_sums[(size_t)(k0 + m) * H + h] : 0.0;
@@ -875,9 +775,6 @@ mstep_gather_kernel(uint32_t L, uint32_t H, uint32_t HP, uint32_t heavy_blocks, 
                 av[e] = acc[i];                           // one slot: stored by its tile; none: stays 0
                 if (acc_extra) av[e] += acc_extra[i];
                 if (eff_len) lv[e] = eff_len[i];
-                if (ls_ptr && cls[e] < 2)
-                    av[e] += sets_contrib(L, H, (uint32_t)(i / H), (uint32_t)(i & (H - 1)), ls_ptr, ls_list, locus_class, slot_ptr,
-                                          slot_sums, acc);
             }
         }
 #pragma unroll
@@ -987,8 +884,7 @@ int em_launch_mstep_gather(gbrs_em *em) {
                        tl.locus_class.p, tl.partials.p, em->acc.p,
                        tl.n_long ? tl.acc_extra.p : (const double *)nullptr, em->theta.p,
                        em->has_len ? em->eff_len.p : (const double *)nullptr, em->counts.p, em->tot_prev.p,
-                       em->tot_new.p, em->msums.p, em->msum_cap, em->scalars.p,
-                       tl.n_sets ? tl.ls_ptr.p : (const uint32_t *)nullptr, tl.ls_list.p, tl.slot_ptr.p);
+                       em->tot_new.p, em->msums.p, em->msum_cap, em->scalars.p);
     return GBRS_OK;
 }
 
@@ -996,7 +892,6 @@ int em_finish_step(gbrs_em *em, double target_err, bool defer = false, bool fuse
     GBRS_TRY(em_flush_err(em));
     if (fused) GBRS_TRY(em_launch_mstep_gather(em));
     else GBRS_TRY(em_launch_mstep<0>(em));
-    GBRS_TRY(em_launch_sets_theta(em, true));
     if (defer && em->layout == 1) {
         em->err_pending = true;
         em->err_pending_target = target_err;
@@ -1044,7 +939,6 @@ int em_finish_prepare(gbrs_em *em, double pseudocount) {
         hipLaunchKernelGGL(pseudo_scale_kernel, dim3(nb), dim3(RED_THREADS), 0, em->stream,
                            (uint64_t)em->L * em->H, nb, em->theta.p, em->partials.p, em->scalars.p);
     }
-    GBRS_TRY(em_launch_sets_theta(em, false));
     GBRS_HIP_CHECK(hipMemsetAsync(em->partials.p, 0, em->partials.bytes(), em->stream));
     // A of the loci without any slot must read 0 in the steps (the tile path then writes only the loci
     // it has rows for); prepare's full gather left the long rows' contribution there
@@ -1239,19 +1133,9 @@ int em_create_impl(uint64_t R, uint32_t L, uint32_t H, const uint32_t *const *in
                                    count ? em->count.p : nullptr, (flags & GBRS_EM_MERGE_IDENTICAL_ROWS) != 0,
                                    row_order, (flags & GBRS_EM_DETERMINISTIC) != 0,
                                    em->stream, (flags & GBRS_EM_SIDE_BY_SIDE) ? 2u : 1u,
-                                   (flags & GBRS_EM_NO_LOCUS_SETS) == 0));
+                                   (flags & GBRS_EM_NO_LOCUS_SETS) == 0 && !count &&
+                                       !(flags & GBRS_EM_MERGE_IDENTICAL_ROWS)));     // (weighted rows: their tiles are dictionary-bound)
         em->layout = 1;
-        if (em->tl.n_sets) {              // theta and A also hold the locus sets, behind the L real loci
-            const size_t LxH = (size_t)em->tl.n_loci_ext * H;
-            GBRS_TRY(em->theta.alloc(LxH));
-            GBRS_TRY(em->acc.alloc(LxH));
-            GBRS_HIP_CHECK(hipMemset(em->theta.p, 0, em->theta.bytes()));
-            GBRS_HIP_CHECK(hipMemset(em->acc.p, 0, em->acc.bytes()));
-            // the fused gather + M-step launch has workgroups for the sets with several slots too
-            em->msum_cap = (uint32_t)((LxH + RED_THREADS - 1) / RED_THREADS * 2 + em->tl.n_loci_ext + RED_BLOCKS);
-            GBRS_TRY(em->msums.alloc(2 * (size_t)em->msum_cap + ERR_BLOCKS));
-            GBRS_HIP_CHECK(hipMemset(em->msums.p, 0, em->msums.bytes()));
-        }
         stg.mark("build_tile_layout");
         // the CSC copy and the per-row denominators are only needed by layout 0 (and, until
         // gbrs_em_set_initial_values has run, when the caller announced stored values)
@@ -1380,8 +1264,7 @@ int em_prepare_partial(gbrs_em *em) {
     GBRS_TRY(select_device(em->device));
     GBRS_TRY(em_reset_scalars(em, false));
     if (em->has_init) {                       // stored alignment values: their normalised column sums
-        GBRS_HIP_CHECK(hipMemsetAsync(em->acc.p, 0, em->acc.bytes(), em->stream));        // (the locus sets' part stays 0)
-        GBRS_HIP_CHECK(hipMemcpyAsync(em->acc.p, em->acc_init.p, em->acc_init.bytes(), hipMemcpyDeviceToDevice, em->stream));
+        GBRS_HIP_CHECK(hipMemcpyAsync(em->acc.p, em->acc_init.p, em->acc.bytes(), hipMemcpyDeviceToDevice, em->stream));
         em->acc_needs_extra = false;
         return GBRS_OK;
     }
@@ -1606,7 +1489,6 @@ int gbrs_em_set_theta(gbrs_em_t *em, const double *theta) {
     GBRS_HIP_CHECK(hipMemcpyAsync(em->scratch_hl.p, theta, LH * sizeof(double), hipMemcpyHostToDevice, em->stream));
     hipLaunchKernelGGL(transpose_hl_to_lh, dim3(1024), dim3(256), 0, em->stream, em->L, em->H,
                        em->scratch_hl.p, em->theta.p);
-    GBRS_TRY(em_launch_sets_theta(em, false));
     GBRS_HIP_CHECK(hipStreamSynchronize(em->stream));
     em->prepared = true;
     return GBRS_OK;
@@ -1740,15 +1622,17 @@ int gbrs_em_info(gbrs_em_t *em, gbrs_em_info_t *info) {
         info->num_device_words = tl.n_batches * 64;
         // E-step: word stream, tile headers, dictionary, theta gather + partial store per slot,
         // [row weights]; gather: slot index + partials read back + acc store; M-step etc.: 5 H*L vectors
+        // rows = theta rows gathered and sum rows stored by the tiles: one per slot, one per (slot, member) for a locus set
+        const uint64_t rows = tl.n_dest_rows ? tl.n_dest_rows : tl.n_slots;
         info->bytes_per_iter = 4 * tl.n_batches * 64 + 16 * tl.n_tiles + 4 * tl.n_slots +
-                               8 * tl.n_slots * em->H * 3 + 4 * tl.n_slots + 4 * ((uint64_t)em->L + 1) +
+                               8 * rows * em->H * 3 + 4 * rows + 4 * ((uint64_t)em->L + 1) +
                                (tl.weighted ? 8 * tl.n_batches * 64 : 0) + 8 * HL * 6;
         info->num_heavy_loci = tl.n_heavy;
         info->num_light_loci = tl.n_light;
         // the E-step launch alone: words, tile headers, dictionary + slot destinations, theta gathered
         // once per slot, one partial-sum row stored per slot [, the per-word row weights]
-        info->estep_bytes = 4 * tl.n_batches * 64 + 16 * tl.n_tiles + 8 * tl.n_slots +
-                            8 * tl.n_slots * em->H * 2 + (tl.weighted ? 8 * tl.n_batches * 64 : 0);
+        info->estep_bytes = 4 * tl.n_batches * 64 + 16 * tl.n_tiles + 4 * tl.n_slots + 4 * rows +
+                            8 * rows * em->H * 2 + (tl.weighted ? 8 * tl.n_batches * 64 : 0);
     }
     info->last_estep_ms = em->last_estep_ms;
     info->last_step_ms = em->last_step_ms;

@@ -64,6 +64,7 @@ __host__ __device__ constexpr int lds_acc_doubles(bool weighted) { return lds_th
 // sums, so a tile may reference at most this many loci
 __host__ __device__ constexpr uint32_t det_dict_cap(int H, bool weighted) { return (lds_acc_doubles(weighted) / TILE_WAVES - 1) / H; }
 constexpr uint32_t SLOT_DIRECT = 0x80000000u;
+constexpr uint32_t SLOT_SET = 0x40000000u;    // slot_dest of a locus-set entry: offset of its destination list in dest_list
 constexpr int HEAVY_SLOTS = 16;                // loci with more slots get a whole wave in the gather (measured 1, 4, 16, 64)
 
 struct TileHdr {
@@ -71,6 +72,12 @@ struct TileHdr {
     uint32_t n_batches;
     uint32_t dict_base;    // first slot / dictionary entry of the tile
     uint32_t dict_count;   // D
+};
+
+// what the E-step kernel needs to know about locus sets (null set_ptr: the layout has none)
+struct SetArgs {
+    uint32_t n_loci;                 // ids below are loci, id - n_loci is a set
+    const uint32_t *set_ptr, *set_members, *dest_list;
 };
 
 struct TileLayout {
@@ -104,17 +111,18 @@ struct TileLayout {
     DevBuf<uint64_t> long_ptr;       // n_long + 1 offsets into long_loc / long_mask
     DevBuf<uint32_t> long_loc, long_mask;
     DevBuf<double> long_weight;      // n_long
-    DevBuf<double> acc_extra;        // Lx*H, global-atomic target of the long-row kernel
+    DevBuf<double> acc_extra;        // L*H, global-atomic target of the long-row kernel
     // Locus sets (GBRS_EM_NO_LOCUS_SETS switches them off).  A read whose alignments to several loci all carry the same
     // haplotype mask contributes  sum_h m_h * (theta[l1,h] + theta[l2,h] + ...)  to its denominator and the same v to every
     // one of those loci: the set {l1, l2, ...} behaves like one locus with theta = the sum of its members'.  The build
-    // gives every distinct such set an id n_loci + k ("virtual locus"), the read becomes ONE word on that id, and the
-    // layout (dictionaries, slots, gather) treats the n_loci_ext = n_loci + n_sets ids alike; after the gather a real
-    // locus adds the sums of the sets it belongs to (ls_ptr / ls_list, ascending: a fixed order), after the M-step the
-    // sets' theta are re-summed from their members (set_ptr / set_members).
-    uint32_t n_loci_ext = 0, n_sets = 0;
+    // gives every distinct such set an id n_loci + k, the read becomes ONE word on that id, and the tiles' dictionaries
+    // hold set ids beside locus ids.  Nothing outside the tiles sees a set: a tile's prologue sums the members' theta
+    // for a set entry (set_ptr / set_members), its epilogue stores a set entry's sums once per member - into a slot row
+    // of that member locus (dest_list), so the gather and the M-step add them up like any other slot of the locus.
+    uint32_t n_sets = 0;
+    uint64_t n_dest_rows = 0;                // rows of `partials` + direct stores: one per (slot, member locus)
     DevBuf<uint32_t> set_ptr, set_members;   // n_sets + 1 offsets; member loci of every set, ascending
-    DevBuf<uint32_t> ls_ptr, ls_list;        // n_loci + 1 offsets; the sets (as k = id - n_loci) a real locus belongs to
+    DevBuf<uint32_t> dest_list;              // per set slot: [n, dest_1 .. dest_n] at slot_dest[slot] & ~SLOT_SET
     // GBRS_EM_ONE_SHOT: the build temporaries stay allocated until the layout goes (common.h, DeferFrees): a
     // process that handles one sample and exits never pays for returning them.  Without the flag they are freed in
     // one pass when the build ends.

@@ -244,14 +244,11 @@ __global__ void set_assign_kernel(uint64_t nc, const uint32_t *__restrict__ head
 
 __global__ void set_members_kernel(uint32_t n_sets, const uint32_t *__restrict__ set_ptr, const uint32_t *__restrict__ set_rep,
                                    const uint32_t *__restrict__ rowstart, const uint32_t *__restrict__ ploc,
-                                   uint32_t *__restrict__ members, uint64_t *__restrict__ lkeys) {
+                                   uint32_t *__restrict__ members) {
     const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n_sets) return;
     const uint32_t b = rowstart[set_rep[k]], o = set_ptr[k], n = set_ptr[k + 1] - o;
-    for (uint32_t j = 0; j < n; ++j) {
-        members[o + j] = ploc[b + j];
-        lkeys[o + j] = ((uint64_t)ploc[b + j] << 32) | k;      // (member locus, set): sorted later into locus -> sets
-    }
+    for (uint32_t j = 0; j < n; ++j) members[o + j] = ploc[b + j];
 }
 
 __global__ void set_row_len_kernel(uint64_t nrows, const uint32_t *__restrict__ rowstart, const uint32_t *__restrict__ set_of_row,
@@ -277,24 +274,6 @@ __global__ void set_rewrite_kernel(uint64_t nrows, uint32_t L, const uint32_t *_
             pmask2[o + (j - b)] = pmask[j];
         }
     }
-}
-
-// ls_ptr[l] = first position of locus l in the sorted (locus << 32 | set) keys; ls_list = the keys' low halves
-__global__ void set_locus_ptr_kernel(uint32_t L, uint64_t n, const uint64_t *__restrict__ skeys, uint32_t *__restrict__ ls_ptr) {
-    const uint32_t l = blockIdx.x * blockDim.x + threadIdx.x;
-    if (l > L) return;
-    uint64_t lo = 0, hi = n;
-    const uint64_t want = (uint64_t)l << 32;
-    while (lo < hi) {
-        const uint64_t mid = (lo + hi) >> 1;
-        if (skeys[mid] < want) lo = mid + 1; else hi = mid;
-    }
-    ls_ptr[l] = (uint32_t)lo;
-}
-
-__global__ void set_locus_list_kernel(uint64_t n, const uint64_t *__restrict__ skeys, uint32_t *__restrict__ ls_list) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) ls_list[i] = (uint32_t)skeys[i];
 }
 
 __device__ __forceinline__ uint32_t mix32(uint32_t h, uint32_t v) {
@@ -580,6 +559,49 @@ __global__ void iota_kernel(uint64_t n, uint32_t *__restrict__ v) {
     if (i < n) v[i] = (uint32_t)i;
 }
 
+// destination entries of a slot: one for a locus, [header, one per member] for a locus set
+__global__ void dest_count_kernel(uint64_t ns, uint32_t L, const uint32_t *__restrict__ dict, const uint32_t *__restrict__ set_ptr,
+                                  uint32_t *__restrict__ cnt) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ns) return;
+    const uint32_t id = dict[i];
+    cnt[i] = id < L ? 1u : 1u + (set_ptr[id - L + 1] - set_ptr[id - L]);
+}
+
+// eloc / eidx: (locus, own index) of every entry; slot_dest of a locus slot = its entry (routed below), of a set slot
+// = SLOT_SET | offset of its header in dest_list, dest_list[header] = number of members
+__global__ void dest_emit_kernel(uint64_t ns, uint32_t L, const uint32_t *__restrict__ dict, const uint32_t *__restrict__ set_ptr,
+                                 const uint32_t *__restrict__ members, const uint32_t *__restrict__ eoff,
+                                 uint32_t *__restrict__ eloc, uint32_t *__restrict__ eidx, uint32_t *__restrict__ slot_dest,
+                                 uint32_t *__restrict__ dest_list) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ns) return;
+    const uint32_t id = dict[i], o = eoff[i];
+    if (id < L) {
+        eloc[o] = id;
+        eidx[o] = o;
+        slot_dest[i] = o;                    // provisional: the entry whose destination dest_route_kernel copies here
+    } else {
+        const uint32_t b = set_ptr[id - L], n = set_ptr[id - L + 1] - b;
+        eloc[o] = L;                         // header
+        eidx[o] = o;
+        dest_list[o] = n;
+        for (uint32_t j = 0; j < n; ++j) {
+            eloc[o + 1 + j] = members[b + j];
+            eidx[o + 1 + j] = o + 1 + j;
+        }
+        slot_dest[i] = SLOT_SET | o;
+    }
+}
+
+// a locus slot takes its destination out of dest_list (where locus_class_kernel left the destination of every entry)
+__global__ void dest_route_kernel(uint64_t ns, const uint32_t *__restrict__ dest_list, uint32_t *__restrict__ slot_dest) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ns) return;
+    const uint32_t d = slot_dest[i];
+    if (!(d & SLOT_SET)) slot_dest[i] = dest_list[d];
+}
+
 __global__ void slot_ptr_kernel(uint32_t L, uint64_t n_slots, const uint32_t *__restrict__ sorted_loc,
                                 uint32_t *__restrict__ slot_ptr) {
     const uint32_t l = blockIdx.x * blockDim.x + threadIdx.x;
@@ -601,6 +623,7 @@ __global__ void locus_class_kernel(uint32_t L, const uint32_t *__restrict__ slot
     // Destination of every (tile, dictionary entry) sum: straight into A for a locus that lives in one
     // tile; otherwise row k of `partials`, k = the entry's rank in the inverted index, so that the
     // slots of a locus are consecutive rows and the gather streams them without an indirection.
+    // (slot_list holds entry indices, slot_dest here is the per-entry destination array: dest_list)
     if (cnt == 1) slot_dest[slot_list[k0]] = SLOT_DIRECT | l;
     else
         for (uint32_t k = k0; k < k0 + cnt; ++k) slot_dest[slot_list[k]] = k;
@@ -953,8 +976,8 @@ int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L_in, uint32_t H, ui
                       const uint32_t *ent_row, const uint64_t *col_ptr, const double *count,
                       bool merge, int row_order, bool deterministic, hipStream_t s, unsigned side_by_side, bool locus_sets) {
     uint32_t L = L_in;                     // grows by the number of locus sets in step 3b
-    out.n_loci_ext = L_in;
     out.n_sets = 0;
+    out.n_dest_rows = 0;
     const bool interleave = row_order == 1, streams = row_order == 2;
     if (H > 16) return fail(GBRS_ERR_INVALID, "the tiled layout packs the haplotype mask in 16 bits (H <= 16)");
     if (N >= 0xFFFFFFFFull || L >= (1u << 27))
@@ -1082,17 +1105,8 @@ int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L_in, uint32_t H, ui
             GBRS_TRY(fetch_last_plus(out.set_ptr.p, set_len.p, V, n_members, s));
             GBRS_HIP_CHECK(hipMemcpyAsync(out.set_ptr.p + V, &n_members, 4, hipMemcpyHostToDevice, s));
             GBRS_TRY(out.set_members.alloc(n_members));
-            DevBuf<uint64_t> lkeys, lkeys2;
-            GBRS_TRY(lkeys.alloc(n_members)); GBRS_TRY(lkeys2.alloc(n_members));
             hipLaunchKernelGGL(set_members_kernel, dim3(grid_for(V)), dim3(256), 0, s, V, out.set_ptr.p, set_rep.p, rowstart.p,
-                               ploc.p, out.set_members.p, lkeys.p);
-            GBRS_TRY(sort_keys64(sc, lkeys.p, lkeys2.p, n_members, 64, s));
-            GBRS_TRY(out.ls_ptr.alloc((size_t)L_in + 1));
-            GBRS_TRY(out.ls_list.alloc(n_members));
-            hipLaunchKernelGGL(set_locus_ptr_kernel, dim3(grid_for((uint64_t)L_in + 1)), dim3(256), 0, s, L_in, (uint64_t)n_members,
-                               lkeys2.p, out.ls_ptr.p);
-            hipLaunchKernelGGL(set_locus_list_kernel, dim3(grid_for(n_members)), dim3(256), 0, s, (uint64_t)n_members, lkeys2.p,
-                               out.ls_list.p);
+                               ploc.p, out.set_members.p);
             // the rows in their new form
             DevBuf<uint32_t> newlen, rowstart2, ploc2, pmask2;
             GBRS_TRY(newlen.alloc(R1)); GBRS_TRY(rowstart2.alloc((size_t)R1 + 1));
@@ -1107,15 +1121,22 @@ int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L_in, uint32_t H, ui
                                set_of_row.p, rowstart2.p, ploc.p, pmask.p, ploc2.p, pmask2.p);
             GBRS_HIP_CHECK(hipStreamSynchronize(s));
             GBRS_HIP_CHECK(hipGetLastError());
-            rowstart.swap(rowstart2); ploc.swap(ploc2); pmask.swap(pmask2);
-            out.n_sets = V;
-            out.n_pairs = P2;
-            L = L_in + V;
-            out.n_loci_ext = L;
-            GBRS_TRY(out.slot_ptr.alloc((size_t)L + 1));
-            GBRS_HIP_CHECK(hipMemsetAsync(out.slot_ptr.p, 0, out.slot_ptr.bytes(), s));
-            GBRS_TRY(out.locus_class.alloc(L));
-            GBRS_HIP_CHECK(hipMemsetAsync(out.locus_class.p, 0, out.locus_class.bytes(), s));
+            // Worth it?  A set entry costs its tile a longer prologue and epilogue (its members' theta summed, its sums
+            // stored once per member), which pays when the words it saves are many and every dictionary entry serves many
+            // words.  Measured (profiles/r03_estep_experiments.txt item 8): C2, 23 % fewer words at 137 words per id:
+            // E-step -11 %; the 16-haplotype shard (same saving, 62 words per id) +8 %; multi-isoform reads (9 % fewer
+            // words) +8 %.  GBRS_TUNING_LOCUS_SETS=1 / 0 forces the choice.
+            bool use = (uint64_t)P2 * 100 <= (uint64_t)P * 85 && (uint64_t)P2 >= 100ull * ((uint64_t)L_in + V);
+            if (const char *env = std::getenv("GBRS_TUNING_LOCUS_SETS"); env) use = std::atoi(env) != 0;
+            if (use) {
+                rowstart.swap(rowstart2); ploc.swap(ploc2); pmask.swap(pmask2);
+                out.n_sets = V;
+                out.n_pairs = P2;
+                L = L_in + V;              // ids of the rows' pairs, the sort keys and the dictionaries from here on
+            } else {
+                out.set_ptr.release();
+                out.set_members.release();
+            }
         }
         stg.mark("3b locus sets");
     }
@@ -1174,7 +1195,7 @@ int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L_in, uint32_t H, ui
         GBRS_TRY(out.long_mask.alloc(tot));
         hipLaunchKernelGGL(long_copy_kernel, dim3((unsigned)n_long), dim3(64), 0, s, n_long, n_short, srow.p, rowstart.p,
                            ploc.p, pmask.p, out.long_ptr.p, out.long_loc.p, out.long_mask.p);
-        GBRS_TRY(out.acc_extra.alloc((size_t)L * H));
+        GBRS_TRY(out.acc_extra.alloc((size_t)L_in * H));
         GBRS_HIP_CHECK(hipStreamSynchronize(s));
     }
     srow.release(); row_orig.release();
@@ -1317,29 +1338,48 @@ int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L_in, uint32_t H, ui
         GBRS_HIP_CHECK(hipMemcpy(out.tiles.p, hdr.data(), T * sizeof(TileHdr), hipMemcpyHostToDevice));
     }
     stg.mark("10 words");
-    // 11. inverted index locus -> slots (ascending slot inside a locus: radix sort is stable)
-    GBRS_TRY(out.slot_list.alloc(std::max<uint32_t>(NS, 1)));
+    // 11. inverted index locus -> destination rows.  A slot (tile, dictionary entry) of a locus delivers one row of sums
+    // to that locus; the slot of a locus set delivers the same row to every member locus.  The rows are numbered by
+    // locus (ascending slot inside a locus: the radix sort is stable), so that the rows of a locus are consecutive in
+    // `partials` and the gather streams them without an indirection.
+    GBRS_TRY(out.slot_dest.alloc(std::max<uint32_t>(NS, 1)));
+    uint32_t NE = 0;
     if (NS) {
-        DevBuf<uint32_t> sid, sloc;
-        GBRS_TRY(sid.alloc(NS)); GBRS_TRY(sloc.alloc(NS));
-        hipLaunchKernelGGL(iota_kernel, dim3(grid_for(NS)), dim3(256), 0, s, (uint64_t)NS, sid.p);
-        GBRS_TRY(sort_pairs<uint32_t>(sc, out.dict.p, sloc.p, sid.p, out.slot_list.p, NS, bits_for(L - 1), s));
-        hipLaunchKernelGGL(slot_ptr_kernel, dim3(grid_for((uint64_t)L + 1)), dim3(256), 0, s, L, (uint64_t)NS, sloc.p,
+        DevBuf<uint32_t> ecnt, eoff;
+        GBRS_TRY(ecnt.alloc(NS)); GBRS_TRY(eoff.alloc(NS));
+        hipLaunchKernelGGL(dest_count_kernel, dim3(grid_for(NS)), dim3(256), 0, s, (uint64_t)NS, L_in, out.dict.p,
+                           out.n_sets ? out.set_ptr.p : (const uint32_t *)nullptr, ecnt.p);
+        GBRS_TRY(exclusive_scan(sc, ecnt.p, eoff.p, NS, s));
+        GBRS_TRY(fetch_last_plus(eoff.p, ecnt.p, NS, NE, s));
+        if (NE >= SLOT_SET) return fail(GBRS_ERR_INVALID, "the tiled layout needs fewer than 2^30 destination rows");
+        DevBuf<uint32_t> eloc, eidx, sloc;
+        GBRS_TRY(eloc.alloc(NE)); GBRS_TRY(eidx.alloc(NE)); GBRS_TRY(sloc.alloc(NE));
+        GBRS_TRY(out.slot_list.alloc(NE));
+        GBRS_TRY(out.dest_list.alloc(NE));
+        hipLaunchKernelGGL(dest_emit_kernel, dim3(grid_for(NS)), dim3(256), 0, s, (uint64_t)NS, L_in, out.dict.p,
+                           out.n_sets ? out.set_ptr.p : (const uint32_t *)nullptr, out.set_members.p, eoff.p, eloc.p, eidx.p,
+                           out.slot_dest.p, out.dest_list.p);
+        // (the header entry of a set slot carries locus id L_in: behind every real locus, never looked at)
+        GBRS_TRY(sort_pairs<uint32_t>(sc, eloc.p, sloc.p, eidx.p, out.slot_list.p, NE, bits_for(L_in), s));
+        hipLaunchKernelGGL(slot_ptr_kernel, dim3(grid_for((uint64_t)L_in + 1)), dim3(256), 0, s, L_in, (uint64_t)NE, sloc.p,
                            out.slot_ptr.p);
         GBRS_HIP_CHECK(hipStreamSynchronize(s));
+    } else {
+        GBRS_TRY(out.slot_list.alloc(1));
+        GBRS_TRY(out.dest_list.alloc(1));
     }
-    GBRS_TRY(out.partials.alloc(std::max<size_t>((size_t)NS * H, 1)));
-    GBRS_TRY(out.slot_dest.alloc(std::max<uint32_t>(NS, 1)));
-    if (NS) hipLaunchKernelGGL(iota_kernel, dim3(grid_for(NS)), dim3(256), 0, s, (uint64_t)NS, out.slot_dest.p);
-    hipLaunchKernelGGL(locus_class_kernel, dim3(grid_for(L)), dim3(256), 0, s, L, out.slot_ptr.p, out.slot_list.p,
-                       out.locus_class.p, out.slot_dest.p);
+    out.n_dest_rows = NE;
+    GBRS_TRY(out.partials.alloc(std::max<size_t>((size_t)NE * H, 1)));
+    hipLaunchKernelGGL(locus_class_kernel, dim3(grid_for(L_in)), dim3(256), 0, s, L_in, out.slot_ptr.p, out.slot_list.p,
+                       out.locus_class.p, out.dest_list.p);
+    if (NS) hipLaunchKernelGGL(dest_route_kernel, dim3(grid_for(NS)), dim3(256), 0, s, (uint64_t)NS, out.dest_list.p, out.slot_dest.p);
     stg.mark("11 inverted index");
     // 12. loci with many slots get a whole wave in the gather kernel
     {
-        std::vector<uint32_t> sp((size_t)L + 1), heavy, lightv;
+        std::vector<uint32_t> sp((size_t)L_in + 1), heavy, lightv;
         GBRS_HIP_CHECK(hipMemcpyAsync(sp.data(), out.slot_ptr.p, sp.size() * 4, hipMemcpyDeviceToHost, s));
         GBRS_HIP_CHECK(hipStreamSynchronize(s));
-        for (uint32_t l = 0; l < L; ++l)
+        for (uint32_t l = 0; l < L_in; ++l)
             if (sp[l + 1] - sp[l] > (uint32_t)HEAVY_SLOTS) heavy.push_back(l);
             else if (sp[l + 1] - sp[l] >= 2) lightv.push_back(l);
         out.n_heavy = heavy.size();

@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 def em_case(rng):
     from gbrs_amd.engine import EmEngine
     from oracle.em_oracle import EMOracle
-    from test_em_gpu import _random_rows_problem
+    from test_em_gpu import _random_rows_problem, _shared_mask_rows_problem
     H = int(rng.choice([1, 2, 3, 4, 8, 8, 8, 16]))
     L = int(rng.integers(5, 4000))
     R = int(rng.integers(1, 30000))
@@ -22,7 +22,14 @@ def em_case(rng):
     lo = min(lo, hi)
     cnt = bool(rng.integers(0, 2))
     seed = int(rng.integers(1, 1 << 30))
-    indptr, indices, count, eff = _random_rows_problem(R, H, L, seed, lo, hi, cnt)
+    # a third of the cases: rows that share one mask over their loci, with the locus sets of the layout forced on
+    shared = rng.random() < 0.35
+    os.environ["GBRS_TUNING_LOCUS_SETS"] = "1" if shared else "0"
+    if shared:
+        indptr, indices, count, eff = _shared_mask_rows_problem(R, H, max(L, 8), seed, max(hi, 2), cnt)
+        L = max(L, 8)
+    else:
+        indptr, indices, count, eff = _random_rows_problem(R, H, L, seed, lo, hi, cnt)
     pc = float(rng.choice([0.0, 0.0, 0.5]))
     tol = float(rng.choice([0.0, 1e-2, 1e-4]))
     iters = int(rng.integers(1, 9))
@@ -49,7 +56,7 @@ def em_case(rng):
         eng.step(n)
         np.testing.assert_allclose(eng.theta(), o.theta, rtol=1e-9, atol=1e-300)
         eng.close()
-    return f"EM R={R} H={H} L={L} rows {lo}-{hi} count={cnt} pc={pc} tol={tol} iters={o.num_iters}"
+    return f"EM R={R} H={H} L={L} rows {lo}-{hi} count={cnt} pc={pc} tol={tol} iters={o.num_iters} shared_masks={shared}"
 
 
 def hmm_case(rng):

@@ -195,8 +195,10 @@ def test_single_step_after_a_run_that_stopped():
         em.close()
 
 
-def test_em_c1_shape_vs_oracle():
-    """BASELINE config 1 (100k reads / 2 haplotypes / 5k isoforms) against the oracle."""
+def test_em_c1_shape_vs_oracle(monkeypatch):
+    """BASELINE config 1 (100k reads / 2 haplotypes / 5k isoforms) against the oracle (locus sets forced on: the build's
+    own rule only takes them for sample-sized inputs)."""
+    monkeypatch.setenv("GBRS_TUNING_LOCUS_SETS", "1")
     from gbrs_amd import synth
     from gbrs_amd.alignment import AlignmentPropertyMatrix
     from gbrs_amd.em import EMfactory
@@ -237,6 +239,7 @@ def test_em_tile_sizes_vs_oracle(tile_words, monkeypatch):
                                   indices=inc.indices, haplotype_names=inc.hap_names,
                                   locus_names=inc.locus_names)
     monkeypatch.setenv("GBRS_TUNING_TILE_WORDS", str(abs(tile_words)))
+    monkeypatch.setenv("GBRS_TUNING_LOCUS_SETS", "1" if tile_words % 128 == 0 else "0")
     if tile_words < 0:                                  # the tiles in locus order instead of largest first
         monkeypatch.setenv("GBRS_TUNING_TILE_ORDER", "0")
     for kw in (LAYOUTS["tiles"], LAYOUTS["tiles_merged"], LAYOUTS["tiles_deterministic"]):
@@ -577,7 +580,7 @@ def _shared_mask_rows_problem(R, H, L, seed, max_loci, with_count, n_lists=None)
                                              (4000, 16, 500, 6, False, 0.5),      # 16 haplotypes, pseudocount
                                              (2500, 3, 200, 4, True, 0.0),        # generic haplotype count (thread-per-locus M-step)
                                              (30000, 8, 20000, 3, False, 0.0)])   # many sets: dictionary cuts
-def test_em_locus_sets_vs_oracle(R, H, L, hi, cnt, pc):
+def test_em_locus_sets_vs_oracle(R, H, L, hi, cnt, pc, monkeypatch):
     """Rows with one mask over several loci become one word on a locus set (include/gbrs_hip.h, GBRS_EM_NO_LOCUS_SETS):
     prepare, steps, the stopping rule and the expected counts against the oracle, for the plain, merged, deterministic
     layouts and with the sets switched off; the building blocks of the sharded path (partial vector handed out and taken
@@ -585,6 +588,7 @@ def test_em_locus_sets_vs_oracle(R, H, L, hi, cnt, pc):
     from gbrs_amd import _lib
     from gbrs_amd.engine import EmEngine
     from oracle.em_oracle import EMOracle
+    monkeypatch.setenv("GBRS_TUNING_LOCUS_SETS", "1")            # (the build's own rule wants a sample-sized problem)
     indptr, indices, count, eff = _shared_mask_rows_problem(R, H, L, 77 + R, hi, cnt)
     o = EMOracle(R, L, H, indptr, indices, count)
     o.prepare(pc, eff)
@@ -593,7 +597,8 @@ def test_em_locus_sets_vs_oracle(R, H, L, hi, cnt, pc):
     for flags in (0, 1, 32, 512):                                # tiles, tiles + merge, deterministic tiles, no sets
         eng = EmEngine.from_host(R, L, H, indptr, indices, count, eff, flags=flags)
         inf = eng.info()
-        assert (inf.num_locus_sets > 0) == (flags != 512)
+        # weighted rows (counts given, or identical rows merged) keep one word per (read, locus) pair
+        assert (inf.num_locus_sets > 0) == (flags in (0, 32) and count is None)
         eng.prepare(pc)
         close(eng.theta(), theta0)
         n, hist = eng.run(model=4, tol=0.0, max_iters=5)
