@@ -681,7 +681,8 @@ def main():
                    "tiles": sum(int(i.num_tiles) for i in infos), "slots": sum(int(i.num_slots) for i in infos),
                    "heavy_loci": sum(int(i.num_heavy_loci) for i in infos),
                    "light_loci": sum(int(i.num_light_loci) for i in infos),
-                   "long_rows": sum(int(i.num_long_rows) for i in infos)},
+                   "long_rows": sum(int(i.num_long_rows) for i in infos),
+                   "locus_sets": sum(int(i.num_locus_sets) for i in infos)},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS if achieved else None,
                      "traffic": None, "kernel": "tile_estep_kernel (E-step)", "kernel_ms": em["estep_ms"],
@@ -692,7 +693,8 @@ def main():
                      "note": "achieved = E-step bytes (word stream, tile headers, dictionary, theta gather, slot "
                              "stores) / E-step launch time from HIP events on the library's stream; the device "
                              "format is a re-encoding of the CSC input (one 32-bit word per (read, locus) pair "
-                             "with the haplotype mask inside), so it moves fewer bytes than SURVEY 8d's B_iter "
+                             "with the haplotype mask inside; a read whose alignments share one mask is one word on its locus "
+                             "SET, config.locus_sets), so it moves fewer bytes than SURVEY 8d's B_iter "
                              "(algorithmic_bytes); words_per_read depends on the generator (<= 2 loci per read)",
                      "whole_step": {"bytes": moved, "priced_bytes": priced_step, "ms": ms_per_step,
                                     "achieved": priced_step / (ms_per_step * 1e-3) / 1e9,

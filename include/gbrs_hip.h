@@ -97,12 +97,15 @@ typedef struct gbrs_em gbrs_em_t;
  * shorter).  gbrs_em_info.retained_build_bytes reports what is held.  Without the flag create frees them in one pass
  * before it returns, so several live handles cost their layouts only. */
 #define GBRS_EM_ONE_SHOT 256u
-/* Locus sets off.  By default a read whose alignments to several loci all carry the same haplotype mask is stored as
- * one word on the id of its locus SET: its denominator is sum_h m_h * (theta[l1,h] + theta[l2,h] + ...) and every
+/* Locus sets off.  By default a read whose alignments to several loci all carry the same haplotype mask may be stored
+ * as one word on the id of its locus SET: its denominator is sum_h m_h * (theta[l1,h] + theta[l2,h] + ...) and every
  * member locus receives the same count/den, so the set behaves like one locus whose theta is the sum of its members'.
- * After every E-step a locus adds the sums of the sets it belongs to (fixed order), after every M-step the sets' theta
- * are re-summed.  Same arithmetic up to the association of those sums (agrees with the plain form to ~1e-15 relative);
- * gbrs_em_info.num_locus_sets says how many sets the layout found.  The flag keeps one word per (read, locus) pair. */
+ * The sets exist inside the tiles only (a tile sums the members' theta for a set entry and stores the entry's sums once
+ * per member locus); theta, the expected counts and the M-step are per locus as before.  Same arithmetic up to the
+ * association of those sums (agrees with the plain form to ~1e-15 relative).  The layout takes the sets when they
+ * remove >= 15 % of the words and leave >= 100 words per id, and never for weighted rows (count given or identical rows
+ * merged); gbrs_em_info.num_locus_sets says how many it found (0: not taken).  The flag keeps one word per
+ * (read, locus) pair whatever the sample. */
 #define GBRS_EM_NO_LOCUS_SETS 512u
 
 /*
