@@ -94,6 +94,18 @@ struct DevBuf {
     }
 };
 
+// roctx ranges around the library's calls (rocprofv3 --marker-trace), when GBRS_ROCTX=1: the marker library is
+// looked up at run time (librocprofiler-sdk-roctx.so, else libroctx64.so); without the variable or the library the
+// ranges cost one predictable branch.
+void roctx_push(const char *name);
+void roctx_pop();
+struct RoctxRange {
+    explicit RoctxRange(const char *name) { roctx_push(name); }
+    ~RoctxRange() { roctx_pop(); }
+    RoctxRange(const RoctxRange &) = delete;
+    RoctxRange &operator=(const RoctxRange &) = delete;
+};
+
 // Wall-clock checkpoints of the one-off build steps, printed to stderr when GBRS_TUNING_BUILD_TIMES=1.
 struct StageTimer {
     bool on;

@@ -2,9 +2,40 @@
 #include "common.h"
 
 #include <cstdlib>
+#include <dlfcn.h>
 #include <vector>
 
 namespace gbrs {
+
+namespace {
+struct Roctx {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+    Roctx() {
+        const char *e = std::getenv("GBRS_ROCTX");
+        if (!e || !std::atoi(e)) return;
+        for (const char *lib : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+            if (void *h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL)) {
+                push = reinterpret_cast<int (*)(const char *)>(dlsym(h, "roctxRangePushA"));
+                pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+                if (push && pop) return;
+                push = nullptr;
+                pop = nullptr;
+            }
+        }
+    }
+};
+const Roctx &roctx() {
+    static const Roctx r;
+    return r;
+}
+}  // namespace
+void roctx_push(const char *name) {
+    if (roctx().push) (void)roctx().push(name);
+}
+void roctx_pop() {
+    if (roctx().pop) (void)roctx().pop();
+}
 
 static thread_local char g_err[1024] = "";
 

@@ -1058,6 +1058,7 @@ int check_row_ids(uint64_t n, const uint32_t *ent_row, uint64_t R, hipStream_t s
 int em_create_impl(uint64_t R, uint32_t L, uint32_t H, const uint32_t *const *indptr,
                    const uint32_t *const *indices, const double *count, const double *eff_len,
                    const uint32_t *allowed, int device, uint32_t flags, bool on_device, gbrs_em_t **out) {
+    RoctxRange roctx_range("gbrs_em_create");
     if (!out) return fail(GBRS_ERR_INVALID, "out is NULL");
     *out = nullptr;
     if (H < 1 || H > 32 || L < 1 || R < 1 || R > 0xFFFFFFFFull)
@@ -1170,6 +1171,7 @@ extern "C" {
 int gbrs_compress_create(uint64_t R, uint32_t L, uint32_t H, const uint32_t *const *indptr,
                          const uint32_t *const *indices, const double *count, int device,
                          gbrs_compress_t **out, uint64_t *num_ecs, uint64_t *nnz_per_hap) {
+    RoctxRange roctx_range("gbrs_compress_create");
     if (!out) return fail(GBRS_ERR_INVALID, "out is NULL");
     *out = nullptr;
     if (H < 1 || H > 16 || L < 1 || R < 1 || R > 0xFFFFFFFFull || !indptr || !indices)
@@ -1352,6 +1354,7 @@ int gbrs_em_finish_prepare(gbrs_em_t *em, double pseudocount) {
 }
 
 int gbrs_em_prepare(gbrs_em_t *em, double pseudocount) {
+    RoctxRange roctx_range("gbrs_em_prepare");
     if (!em) return fail(GBRS_ERR_INVALID, "handle is NULL");
     GBRS_TRY(em_prepare_partial(em));
     return gbrs_em_finish_prepare(em, pseudocount);
@@ -1383,6 +1386,7 @@ int gbrs_em_finish_step(gbrs_em_t *em, double *err_sum_out) {
 }
 
 int gbrs_em_step(gbrs_em_t *em, int n_iters, double *err_sum_out) {
+    RoctxRange roctx_range("gbrs_em_step");
     if (!em) return fail(GBRS_ERR_INVALID, "handle is NULL");
     if (!em->prepared) return fail(GBRS_ERR_STATE, "prepare() has not been called");
     GBRS_TRY(select_device(em->device));
@@ -1420,6 +1424,7 @@ int gbrs_em_step(gbrs_em_t *em, int n_iters, double *err_sum_out) {
 
 int gbrs_em_run(gbrs_em_t *em, int model, double tol, int max_iters, int *n_iters_out,
                 double *err_hist, int err_hist_cap, double *elapsed_s) {
+    RoctxRange roctx_range("gbrs_em_run");
     if (!em) return fail(GBRS_ERR_INVALID, "handle is NULL");
     if (model < 1 || model > 4)
         return fail(GBRS_ERR_INVALID, "The read normalization model should be 1, 2, 3, or 4.");
@@ -1671,6 +1676,7 @@ int gbrs_counts_create(uint64_t R, uint32_t L, uint32_t H, const uint32_t *const
 
 int gbrs_counts_get(gbrs_counts_t *c, const int32_t *locus_group, uint32_t num_out_loci, double *aln_counts,
                     double *allele_unique, double *locus_unique) {
+    RoctxRange roctx_range("gbrs_counts_get");
     if (!c) return fail(GBRS_ERR_INVALID, "handle is NULL");
     const uint32_t L = c->L, H = c->H;
     const uint32_t Lout = locus_group ? num_out_loci : L;

@@ -2710,6 +2710,7 @@ int gbrs_hmm_create(int num_haps, int n_chrom, const int32_t *n_genes, const int
 int gbrs_hmm_set_expression(gbrs_hmm_t *h, int n_samples, const double *const *expr,
                             const double *const *avecs, const uint8_t *const *has_avec,
                             double expr_threshold, double sigma) {
+    RoctxRange roctx_range("gbrs_hmm_set_expression");
     if (!h || !expr || n_samples < 1 || (avecs == nullptr) != (has_avec == nullptr))
         return fail(GBRS_ERR_INVALID, "bad argument");
     GBRS_TRY(select_device(h->device));
@@ -2786,6 +2787,7 @@ int gbrs_hmm_set_eprob(gbrs_hmm_t *h, int n_samples, const double *const *eprob)
 }
 
 int gbrs_hmm_run(gbrs_hmm_t *h) {
+    RoctxRange roctx_range("gbrs_hmm_run");
     if (!h) return fail(GBRS_ERR_INVALID, "handle is NULL");
     if (!h->have_eprob) return fail(GBRS_ERR_STATE, "no expression / emission data set");
     GBRS_TRY(select_device(h->device));
