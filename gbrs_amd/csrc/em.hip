@@ -570,6 +570,13 @@ int em_estep_tiles_h(gbrs_em *em) {
                            (uint32_t)tl.n_tiles, ea, sets)
         if (tl.deterministic) {           // fixed-order sums instead of LDS float atomics (GBRS_EM_DETERMINISTIC)
             if (tl.weighted) GBRS_LAUNCH_TILES(true, true); else GBRS_LAUNCH_TILES(false, true);
+#if !defined(GBRS_NO_ONEWORD)
+        } else if (HT == 8 && !tl.weighted && tl.all_one_word) {
+            // no row of the layout has more than one word (single-locus reads, or locus sets): no row sums at all
+            hipLaunchKernelGGL((tile_estep_kernel<HT == 8 ? 8 : 1, false, ONES, false, HT == 8>), grid, block, 0, em->stream, em->H,
+                               tl.tiles.p, tl.words.p, tl.dict.p, ww, em->theta.p, tl.partials.p, tl.slot_dest.p, em->acc.p,
+                               em->scalars.p, (uint32_t)tl.n_tiles, ea, sets);
+#endif
         } else {
             if (tl.weighted) GBRS_LAUNCH_TILES(true, false); else GBRS_LAUNCH_TILES(false, false);
         }

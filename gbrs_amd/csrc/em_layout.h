@@ -90,6 +90,7 @@ struct TileLayout {
     uint32_t d_max = 0;          // dictionary capacity used when cutting tiles
     bool weighted = false;       // per-row weights present (count given or rows merged)
     bool deterministic = false;  // dictionaries capped at det_dict_cap(H): one private sum copy per wavefront
+    bool all_one_word = false;   // every row of the layout is a single word (and there are no long rows)
 
     DevBuf<uint32_t> words;          // n_batches * 64
     DevBuf<TileHdr> tiles;           // n_tiles

@@ -1178,6 +1178,7 @@ int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L_in, uint32_t H, ui
     }
     skey.release();
     out.n_rows = M;
+    out.all_one_word = false;
     stg.mark("5 merge");
     // 6. long rows keep their pair form
     if (n_long) {
@@ -1214,6 +1215,7 @@ int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L_in, uint32_t H, ui
     {
         uint32_t total_words = 0;
         GBRS_TRY(fetch_last_plus(wordoff.p, npm.p, M, total_words, s));
+        out.all_one_word = total_words == M && n_long == 0;
         int dev = 0, n_cu = 0;
         GBRS_HIP_CHECK(hipGetDevice(&dev));
         GBRS_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev));
