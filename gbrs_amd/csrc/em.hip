@@ -563,7 +563,7 @@ int em_estep_tiles_h(gbrs_em *em) {
         em->err_pending = false;
         const dim3 grid((unsigned)tl.n_tiles + ea.n_err_blocks), block(TILE_THREADS);
         const double *ww = tl.weighted ? tl.word_weight.p : (const double *)nullptr;
-        const SetArgs sets{em->L, tl.n_sets ? tl.set_ptr.p : nullptr, tl.set_members.p, tl.dest_list.p};
+        const SetArgs sets{em->L, tl.n_sets ? tl.set_ptr.p : nullptr, tl.set_members.p, tl.dest_list.p, tl.dict_b.p, tl.dest_b.p};
 #define GBRS_LAUNCH_TILES(W, D)                                                                                        \
         hipLaunchKernelGGL((tile_estep_kernel<HT, W, ONES, D>), grid, block, 0, em->stream, em->H, tl.tiles.p, tl.words.p, \
                            tl.dict.p, ww, em->theta.p, tl.partials.p, tl.slot_dest.p, em->acc.p, em->scalars.p,       \

@@ -65,6 +65,10 @@ __host__ __device__ constexpr int lds_acc_doubles(bool weighted) { return lds_th
 __host__ __device__ constexpr uint32_t det_dict_cap(int H, bool weighted) { return (lds_acc_doubles(weighted) / TILE_WAVES - 1) / H; }
 constexpr uint32_t SLOT_DIRECT = 0x80000000u;
 constexpr uint32_t SLOT_SET = 0x40000000u;    // slot_dest of a locus-set entry: offset of its destination list in dest_list
+constexpr uint32_t SLOT_PAIR = 0x20000000u;   // slot_dest of a two-member set: first destination here, second in dest_b
+// dictionary entries as the E-step kernel reads them (the build works on plain ids and encodes them at the end):
+// a locus id; DICT_PAIR | first member of a two-member set (second member in dict_b); DICT_SET | set index (set_ptr)
+constexpr uint32_t DICT_PAIR = 0x80000000u, DICT_SET = 0x40000000u;
 constexpr int HEAVY_SLOTS = 16;                // loci with more slots get a whole wave in the gather (measured 1, 4, 16, 64)
 
 struct TileHdr {
@@ -76,8 +80,9 @@ struct TileHdr {
 
 // what the E-step kernel needs to know about locus sets (null set_ptr: the layout has none)
 struct SetArgs {
-    uint32_t n_loci;                 // ids below are loci, id - n_loci is a set
+    uint32_t n_loci;                 // number of loci (the encoded dictionary does not need it; kept for checks)
     const uint32_t *set_ptr, *set_members, *dest_list;
+    const uint32_t *dict_b, *dest_b; // per slot: second member / second destination of a two-member set
 };
 
 struct TileLayout {
@@ -124,6 +129,7 @@ struct TileLayout {
     uint64_t n_dest_rows = 0;                // rows of `partials` + direct stores: one per (slot, member locus)
     DevBuf<uint32_t> set_ptr, set_members;   // n_sets + 1 offsets; member loci of every set, ascending
     DevBuf<uint32_t> dest_list;              // per set slot: [n, dest_1 .. dest_n] at slot_dest[slot] & ~SLOT_SET
+    DevBuf<uint32_t> dict_b, dest_b;         // n_slots: second member / second destination of the two-member sets
     // GBRS_EM_ONE_SHOT: the build temporaries stay allocated until the layout goes (common.h, DeferFrees): a
     // process that handles one sample and exits never pays for returning them.  Without the flag they are freed in
     // one pass when the build ends.

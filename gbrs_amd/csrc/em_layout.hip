@@ -602,6 +602,30 @@ __global__ void dest_route_kernel(uint64_t ns, const uint32_t *__restrict__ dest
     if (!(d & SLOT_SET)) slot_dest[i] = dest_list[d];
 }
 
+// Last step of the build: the dictionary and the destinations in the form the E-step kernel reads (em_layout.h) - a
+// two-member set carries its members and its two destinations in place (one round trip less in the tile's prologue and
+// epilogue than the general set's lists), a larger set its index.
+__global__ void encode_sets_kernel(uint64_t ns, uint32_t L, const uint32_t *__restrict__ set_ptr, const uint32_t *__restrict__ members,
+                                   const uint32_t *__restrict__ dest_list, uint32_t *__restrict__ dict, uint32_t *__restrict__ dict_b,
+                                   uint32_t *__restrict__ slot_dest, uint32_t *__restrict__ dest_b) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ns) return;
+    const uint32_t id = dict[i];
+    dict_b[i] = 0;
+    dest_b[i] = 0;
+    if (id < L) return;
+    const uint32_t k = id - L, b = set_ptr[k], n = set_ptr[k + 1] - b;
+    if (n == 2) {
+        const uint32_t off = slot_dest[i] & ~SLOT_SET;
+        dict[i] = DICT_PAIR | members[b];
+        dict_b[i] = members[b + 1];
+        slot_dest[i] = SLOT_PAIR | dest_list[off + 1];      // (a destination is a row < 2^29 or SLOT_DIRECT | locus < 2^27)
+        dest_b[i] = dest_list[off + 2];
+    } else {
+        dict[i] = DICT_SET | k;
+    }
+}
+
 __global__ void slot_ptr_kernel(uint32_t L, uint64_t n_slots, const uint32_t *__restrict__ sorted_loc,
                                 uint32_t *__restrict__ slot_ptr) {
     const uint32_t l = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1375,6 +1399,13 @@ int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L_in, uint32_t H, ui
     hipLaunchKernelGGL(locus_class_kernel, dim3(grid_for(L_in)), dim3(256), 0, s, L_in, out.slot_ptr.p, out.slot_list.p,
                        out.locus_class.p, out.dest_list.p);
     if (NS) hipLaunchKernelGGL(dest_route_kernel, dim3(grid_for(NS)), dim3(256), 0, s, (uint64_t)NS, out.dest_list.p, out.slot_dest.p);
+    if (NE >= SLOT_PAIR) return fail(GBRS_ERR_INVALID, "the tiled layout needs fewer than 2^29 destination rows");
+    if (out.n_sets && NS) {
+        GBRS_TRY(out.dict_b.alloc(NS));
+        GBRS_TRY(out.dest_b.alloc(NS));
+        hipLaunchKernelGGL(encode_sets_kernel, dim3(grid_for(NS)), dim3(256), 0, s, (uint64_t)NS, L_in, out.set_ptr.p,
+                           out.set_members.p, out.dest_list.p, out.dict.p, out.dict_b.p, out.slot_dest.p, out.dest_b.p);
+    }
     stg.mark("11 inverted index");
     // 12. loci with many slots get a whole wave in the gather kernel
     {
