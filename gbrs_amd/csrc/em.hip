@@ -492,6 +492,7 @@ struct gbrs_em {
     bool has_init = false, keep_csc = false;
     bool stopped = false;          // the device's stop flag is set: every step kernel is a no-op until it is cleared
     DevBuf<double> theta, acc, counts;             // L*H locus-major
+    bool counts_stale = false;                     // the fused M-step ran since `counts` was written (em_refresh_counts)
     DevBuf<double> tot_prev, tot_new;              // L
     DevBuf<double> partials;                       // 3 * RED_BLOCKS (pseudocount reductions)
     DevBuf<double> msums;                          // M-step block sums [2][msum_cap] + ERR_BLOCKS error partials
@@ -716,10 +717,7 @@ mstep_gather_kernel(uint32_t L, uint32_t H, uint32_t HP, uint32_t heavy_blocks, 
                 t = t_old;
                 const double c = t * (a + ax);
                 tn = eff_len ? c / ln : c;
-                if (!stop) {
-                    counts[il] = c;
-                    theta[il] = tn;
-                }
+                if (!stop) theta[il] = tn;             // (the expected counts are theta' * len: made when asked for)
             }
             double tp = t, tq = tn;                       // lanes 0 .. H-1 hold the locus, the others 0
             for (uint32_t off = 1; off < HP; off <<= 1) {
@@ -749,10 +747,7 @@ mstep_gather_kernel(uint32_t L, uint32_t H, uint32_t HP, uint32_t heavy_blocks, 
             t = t_old;
             const double c = t * a;
             tn = eff_len ? c / ln : c;
-            if (!stop) {
-                counts[il] = c;
-                theta[il] = tn;
-            }
+            if (!stop) theta[il] = tn;
         }
         double tp = t, tq = tn;                           // the H lanes of a locus are adjacent
         for (uint32_t off = 1; off < H; off <<= 1) {
@@ -794,10 +789,7 @@ mstep_gather_kernel(uint32_t L, uint32_t H, uint32_t HP, uint32_t heavy_blocks, 
                 te = tv[e];
                 const double c = te * av[e];
                 tne = eff_len ? c / lv[e] : c;
-                if (!stop) {
-                    counts[i] = c;
-                    theta[i] = tne;
-                }
+                if (!stop) theta[i] = tne;
             }
             double tp = te, tq = tne;                     // the H lanes of a locus are adjacent, same class
             for (uint32_t off = 1; off < H; off <<= 1) {
@@ -839,6 +831,25 @@ int em_launch_mstep(gbrs_em *em) {
     hipLaunchKernelGGL(mstep_elem_kernel<MODE>, dim3(nb), dim3(RED_THREADS), 0, em->stream, em->L, em->H, em->theta.p,
                        em->acc.p, em->acc_needs_extra ? em->tl.acc_extra.p : (const double *)nullptr, len,
                        em->counts.p, em->tot_prev.p, em->tot_new.p, em->msums.p, em->msum_cap, em->scalars.p);
+    return GBRS_OK;
+}
+
+// The expected read counts theta * A of the last iteration (EMfactory.py:302: the last E-step's posterior summed over the
+// reads) equal theta' * len, theta' being what that iteration's M-step left: the fused gather + M-step launch does not
+// store them (7.7 of its ~55 MB per iteration at C2), they are made from theta when somebody asks (one more rounding:
+// within 2 ulp of the product the unfused kernels store).
+__global__ void __launch_bounds__(256)
+counts_from_theta_kernel(uint64_t n, const double *__restrict__ theta, const double *__restrict__ eff_len, double *__restrict__ counts) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) counts[i] = eff_len ? theta[i] * eff_len[i] : theta[i];
+}
+int em_refresh_counts(gbrs_em *em) {
+    if (!em->counts_stale) return GBRS_OK;
+    const uint64_t n = (uint64_t)em->L * em->H;
+    hipLaunchKernelGGL(counts_from_theta_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, em->stream, n, em->theta.p,
+                       em->has_len ? em->eff_len.p : (const double *)nullptr, em->counts.p);
+    GBRS_HIP_CHECK(hipGetLastError());
+    em->counts_stale = false;
     return GBRS_OK;
 }
 
@@ -899,6 +910,7 @@ int em_finish_step(gbrs_em *em, double target_err, bool defer = false, bool fuse
     GBRS_TRY(em_flush_err(em));
     if (fused) GBRS_TRY(em_launch_mstep_gather(em));
     else GBRS_TRY(em_launch_mstep<0>(em));
+    em->counts_stale = fused;
     if (defer && em->layout == 1) {
         em->err_pending = true;
         em->err_pending_target = target_err;
@@ -939,6 +951,7 @@ int em_read_times(gbrs_em *em) {
 
 int em_finish_prepare(gbrs_em *em, double pseudocount) {
     GBRS_TRY(em_launch_mstep<1>(em));
+    em->counts_stale = false;
     const int nb = em->red_blocks();
     if (pseudocount > 0.0) {
         hipLaunchKernelGGL(pseudo_add_kernel, dim3(nb), dim3(RED_THREADS), 0, em->stream, em->L,
@@ -1486,6 +1499,7 @@ int gbrs_em_get(gbrs_em_t *em, double *theta, double *expected_counts) {
     for (int which = 0; which < 2; ++which) {
         double *dst = which == 0 ? theta : expected_counts;
         if (!dst) continue;
+        if (which == 1) GBRS_TRY(em_refresh_counts(em));
         hipLaunchKernelGGL(transpose_lh_to_hl, dim3(1024), dim3(256), 0, em->stream, em->L, em->H,
                            which == 0 ? em->theta.p : em->counts.p, em->scratch_hl.p);
         GBRS_HIP_CHECK(hipMemcpyAsync(dst, em->scratch_hl.p, LH * sizeof(double), hipMemcpyDeviceToHost, em->stream));
@@ -1498,6 +1512,9 @@ int gbrs_em_set_theta(gbrs_em_t *em, const double *theta) {
     if (!em || !theta) return fail(GBRS_ERR_INVALID, "NULL argument");
     GBRS_TRY(select_device(em->device));
     const size_t LH = (size_t)em->L * em->H;
+    // the expected counts stay those of the last iteration (the reports rescale theta to TPM in place and then ask for
+    // the counts, EMfactory.py:352-354 before :302): made from the theta about to be replaced, if not stored yet
+    GBRS_TRY(em_refresh_counts(em));
     GBRS_HIP_CHECK(hipMemcpyAsync(em->scratch_hl.p, theta, LH * sizeof(double), hipMemcpyHostToDevice, em->stream));
     hipLaunchKernelGGL(transpose_hl_to_lh, dim3(1024), dim3(256), 0, em->stream, em->L, em->H,
                        em->scratch_hl.p, em->theta.p);
@@ -1525,6 +1542,7 @@ int gbrs_em_group_sums(gbrs_em_t *em, int64_t G, const int64_t *group_ptr, const
     GBRS_HIP_CHECK(hipMemcpyAsync(d_ptr.p, group_ptr, (G + 1) * sizeof(int64_t), hipMemcpyHostToDevice, em->stream));
     if (nm) GBRS_HIP_CHECK(hipMemcpyAsync(d_mem.p, members, nm * sizeof(int64_t), hipMemcpyHostToDevice, em->stream));
     const int64_t total = G * (int64_t)em->H;
+    if (which != 0) GBRS_TRY(em_refresh_counts(em));
     hipLaunchKernelGGL(group_sum_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, em->stream,
                        em->H, G, d_ptr.p, d_mem.p, which == 0 ? em->theta.p : em->counts.p, d_out.p);
     GBRS_HIP_CHECK(hipMemcpyAsync(out, d_out.p, (size_t)G * em->H * sizeof(double), hipMemcpyDeviceToHost, em->stream));
