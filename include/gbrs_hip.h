@@ -179,7 +179,10 @@ int gbrs_em_run(gbrs_em_t *em, int model, double tol, int max_iters,
                 int *n_iters_out, double *err_hist, int err_hist_cap, double *elapsed_s);
 
 /* theta (H x L) = EMfactory.allelic_expression; expected_counts (H x L) = probability.sum(READ)
- * of the last E-step (EMfactory.py:302).  Either pointer may be NULL. */
+ * of the last E-step (EMfactory.py:302), i.e. theta_before * A of the last iteration - on the single-GPU path formed
+ * as theta * effective_length from the theta that iteration's M-step left (the same number up to two roundings), when
+ * this call or gbrs_em_group_sums asks for it.  They stay those of the last iteration when gbrs_em_set_theta replaces
+ * theta afterwards (the reports rescale theta to TPM first).  Either pointer may be NULL. */
 int gbrs_em_get(gbrs_em_t *em, double *theta, double *expected_counts);
 
 /* Overwrite theta (H x L), e.g. to resume from a checkpoint. */
