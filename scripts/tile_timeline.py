@@ -33,11 +33,14 @@ eng.step(1)
 torch.cuda.synchronize()
 fn(C.c_void_p(0))
 a = buf.cpu().numpy().reshape(-1, 8)[:n_tiles].astype(np.int64)
-t0, t1, t2, t3, hw, xcc, nb = (a[:, k] for k in (0, 1, 2, 3, 4, 5, 6))
+t0, t1, t2, t3, hw, xcc5, t6, t7 = (a[:, k] for k in (0, 1, 2, 3, 4, 5, 6, 7))
+xcc, nb = xcc5 & 0xff, xcc5 >> 8
 base = t0.min()
-t0, t1, t2, t3 = (t - base for t in (t0, t1, t2, t3))
+t0, t1, t2, t3, t6, t7 = (t - base for t in (t0, t1, t2, t3, t6, t7))
 span = t3.max()
 print(f"tiles {n_tiles}  launch span {span * 10 / 1000:.1f} us (first start -> last end)")
+print(f"prologue in parts (us, thread 0): start -> sums zeroed {np.mean(t7 - t0) / 100:.2f}, -> theta gathered {np.mean(t6 - t7) / 100:.2f}, "
+      f"-> barrier passed {np.mean(t1 - t6) / 100:.2f}")
 print(f"per tile (us): prologue {np.mean(t1 - t0) / 100:.2f}  loop {np.mean(t2 - t1) / 100:.2f}  epilogue {np.mean(t3 - t2) / 100:.2f}  "
       f"total {np.mean(t3 - t0) / 100:.2f}   largest tile {np.max(t3 - t0) / 100:.2f}, batches {nb.max()}")
 cu = ((hw >> 8) & 0xf) | (((hw >> 13) & 0x7) << 4) | ((xcc & 0xf) << 8)       # CU_ID, SE_ID, XCC
