@@ -1150,7 +1150,8 @@ int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L_in, uint32_t H, ui
             // words.  Measured (profiles/r03_estep_experiments.txt item 8): C2, 23 % fewer words at 137 words per id:
             // E-step -11 %; the 16-haplotype shard (same saving, 62 words per id) +8 %; multi-isoform reads (9 % fewer
             // words) +8 %.  GBRS_TUNING_LOCUS_SETS=1 / 0 forces the choice.
-            bool use = (uint64_t)P2 * 100 <= (uint64_t)P * 85 && (uint64_t)P2 >= 100ull * ((uint64_t)L_in + V);
+            // (and no more sets than twice the loci: many thin sets fill the tiles' dictionaries, item 16 of the same file)
+            bool use = (uint64_t)P2 * 100 <= (uint64_t)P * 85 && (uint64_t)P2 >= 100ull * ((uint64_t)L_in + V) && (uint64_t)V <= 2ull * L_in;
             if (const char *env = std::getenv("GBRS_TUNING_LOCUS_SETS"); env) use = std::atoi(env) != 0;
             if (use) {
                 rowstart.swap(rowstart2); ploc.swap(ploc2); pmask.swap(pmask2);
