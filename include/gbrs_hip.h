@@ -103,8 +103,8 @@ typedef struct gbrs_em gbrs_em_t;
  * The sets exist inside the tiles only (a tile sums the members' theta for a set entry and stores the entry's sums once
  * per member locus); theta, the expected counts and the M-step are per locus as before.  Same arithmetic up to the
  * association of those sums (agrees with the plain form to ~1e-15 relative).  The layout takes the sets when they
- * remove >= 15 % of the words and leave >= 100 words per id, and never for weighted rows (count given or identical rows
- * merged); gbrs_em_info.num_locus_sets says how many it found (0: not taken).  The flag keeps one word per
+ * remove >= 15 % of the words, leave >= 100 words per id and number at most twice the loci, and never for weighted rows
+ * (count given or identical rows merged); gbrs_em_info.num_locus_sets says how many it found (0: not taken).  The flag keeps one word per
  * (read, locus) pair whatever the sample. */
 #define GBRS_EM_NO_LOCUS_SETS 512u
 
