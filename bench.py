@@ -567,6 +567,9 @@ def self_launch(args):
 
 def main():
     args = parse()
+    if os.environ.get("GBRS_BENCH_WATCHDOG"):        # rehearsals: where is every rank after N seconds without finishing?
+        import faulthandler
+        faulthandler.dump_traceback_later(int(os.environ["GBRS_BENCH_WATCHDOG"]), repeat=True, file=sys.stderr)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         self_launch(args)                             # never returns
     world = int(os.environ.get("WORLD_SIZE", "1"))
