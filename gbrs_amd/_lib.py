@@ -148,7 +148,7 @@ def load():
         fn.argtypes = args
     lib.gbrs_em_stream.restype = vp
     lib.gbrs_em_stream.argtypes = [vp]
-    if lib.gbrs_abi_version() != 3:
+    if lib.gbrs_abi_version() != 4:
         raise ImportError("libgbrs_hip.so ABI version mismatch")
     _lib = lib
     return lib
@@ -162,8 +162,8 @@ def _host_signatures():
         "gbrs_decode_chunks": [C.c_char_p, i64, vp, vp, vp, vp, u64, u32, u64, i32, i32, vp, i32],
         "gbrs_inflate_backend": [],
         "gbrs_zip_directory": [vp, u64, u64, vp, vp, vp, vp, vp, vp, u64, C.POINTER(u64), C.POINTER(u64)],
-        "gbrs_npz_stack": [vp, u64, i64, vp, vp, vp, vp, vp, u64, u64, vp, vp, i32],
-        "gbrs_zip_read_members": [vp, u64, i64, vp, vp, vp, vp, vp, i32],
+        "gbrs_npz_stack": [vp, u64, i64, vp, vp, vp, vp, vp, vp, u64, u64, vp, vp, i32],
+        "gbrs_zip_read_members": [vp, u64, i64, vp, vp, vp, vp, vp, vp, i32],
         "gbrs_parse_number_table": [C.c_char_p, i64, i64, i32, vp],
         "gbrs_parse_length_table": [C.c_char_p, i64, C.c_char_p, vp, i64, C.c_char_p, vp, i32, dbl, vp],
         "gbrs_parse_genotype_table": [C.c_char_p, i64, C.c_char_p, vp, i64, C.c_char_p, vp, i32, vp, vp, i32, vp,

@@ -154,7 +154,11 @@ __device__ __forceinline__ void err_finish_body(const ErrArgs &ea, unsigned bid)
     __shared__ double lds[16];
     __shared__ double s_sums[2];
     __shared__ int s_last;
-    if (sc->stop) return;
+    // (one read of the flag per workgroup: a partner handle's pair_err_kernel may raise it while this pass is running)
+    if (threadIdx.x == 0) s_last = sc->stop;
+    __syncthreads();
+    if (s_last) return;
+    __syncthreads();                                            // s_last is written again below
     double a = reduce_partials(partials, nblocks, lds);
     double b = reduce_partials(partials + ea.cap, nblocks, lds);
     if (threadIdx.x == 0) {
@@ -1384,6 +1388,9 @@ int gbrs_em_estep_partial(gbrs_em_t *em, void **partial_dev, uint64_t *n_elems) 
     if (!em) return fail(GBRS_ERR_INVALID, "handle is NULL");
     if (!em->prepared) return fail(GBRS_ERR_STATE, "prepare() has not been called");
     GBRS_TRY(select_device(em->device));
+    // a run that met its stopping rule (gbrs_em_run, or the pair's rule: gbrs_em_pair_check) left the device's stop flag
+    // set, which turns every step kernel into a no-op; a step asked for by hand is applied anyway, as in gbrs_em_step
+    if (em->stopped) GBRS_TRY(em_reset_scalars(em, true));
     em->acc_external = true;
     GBRS_TRY(em_estep<false>(em, true));
     if (partial_dev) *partial_dev = em->acc.p;
@@ -1662,7 +1669,9 @@ int gbrs_em_info(gbrs_em_t *em, gbrs_em_info_t *info) {
         // the E-step launch alone: words, tile headers, dictionary + slot destinations, theta gathered
         // once per slot, one partial-sum row stored per slot [, the per-word row weights]
         info->estep_bytes = 4 * tl.n_batches * 64 + 16 * tl.n_tiles + 4 * tl.n_slots + 4 * rows +
-                            8 * rows * em->H * 2 + (tl.weighted ? 8 * tl.n_batches * 64 : 0);
+                            8 * rows * em->H * 2 + (tl.weighted ? 8 * tl.n_batches * 64 : 0) +
+                            (tl.n_sets ? 8 * tl.n_slots : 0);       // dict_b / dest_b beside the dictionary
+        if (tl.n_sets) info->bytes_per_iter += 8 * tl.n_slots;
     }
     info->last_estep_ms = em->last_estep_ms;
     info->last_step_ms = em->last_step_ms;

@@ -1116,9 +1116,11 @@ int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L_in, uint32_t H, ui
             uint32_t V = 0;
             GBRS_HIP_CHECK(hipMemcpyAsync(&V, hincl2.p + C - 1, 4, hipMemcpyDeviceToHost, s));
             GBRS_HIP_CHECK(hipStreamSynchronize(s));
-            if ((uint64_t)L_in + V >= (1u << 27))
-                return fail(GBRS_ERR_INVALID, "the tiled layout needs fewer than 2^27 loci and locus sets per handle");
+            // (ids of loci and sets share the 27 bits of a row key: a sample with that many distinct sets keeps its plain rows)
+            const bool ids_fit = (uint64_t)L_in + V < (1u << 27);
+            if (!ids_fit) V = 0;
             DevBuf<uint32_t> set_len, set_rep;
+            if (ids_fit) {
             GBRS_TRY(set_len.alloc(V)); GBRS_TRY(set_rep.alloc(V));
             GBRS_HIP_CHECK(hipMemsetAsync(set_of_row.p, 0xFF, set_of_row.bytes(), s));
             hipLaunchKernelGGL(set_assign_kernel, dim3(grid_for(C)), dim3(256), 0, s, (uint64_t)C, head2.p, hincl2.p, srow2.p,
@@ -1162,6 +1164,7 @@ int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L_in, uint32_t H, ui
                 out.set_ptr.release();
                 out.set_members.release();
             }
+            }   // ids_fit
         }
         stg.mark("3b locus sets");
     }
@@ -1370,7 +1373,7 @@ int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L_in, uint32_t H, ui
     // locus (ascending slot inside a locus: the radix sort is stable), so that the rows of a locus are consecutive in
     // `partials` and the gather streams them without an indirection.
     GBRS_TRY(out.slot_dest.alloc(std::max<uint32_t>(NS, 1)));
-    uint32_t NE = 0;
+    uint32_t NE = 0, n_rows_real = 0;
     if (NS) {
         DevBuf<uint32_t> ecnt, eoff;
         GBRS_TRY(ecnt.alloc(NS)); GBRS_TRY(eoff.alloc(NS));
@@ -1378,7 +1381,8 @@ int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L_in, uint32_t H, ui
                            out.n_sets ? out.set_ptr.p : (const uint32_t *)nullptr, ecnt.p);
         GBRS_TRY(exclusive_scan(sc, ecnt.p, eoff.p, NS, s));
         GBRS_TRY(fetch_last_plus(eoff.p, ecnt.p, NS, NE, s));
-        if (NE >= SLOT_SET) return fail(GBRS_ERR_INVALID, "the tiled layout needs fewer than 2^30 destination rows");
+        // (SLOT_PAIR is the lowest flag bit of a destination: checked here, before anything is sized by NE or indexed with it)
+        if (NE >= SLOT_PAIR) return fail(GBRS_ERR_INVALID, "the tiled layout needs fewer than 2^29 destination rows");
         DevBuf<uint32_t> eloc, eidx, sloc;
         GBRS_TRY(eloc.alloc(NE)); GBRS_TRY(eidx.alloc(NE)); GBRS_TRY(sloc.alloc(NE));
         GBRS_TRY(out.slot_list.alloc(NE));
@@ -1390,17 +1394,18 @@ int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L_in, uint32_t H, ui
         GBRS_TRY(sort_pairs<uint32_t>(sc, eloc.p, sloc.p, eidx.p, out.slot_list.p, NE, bits_for(L_in), s));
         hipLaunchKernelGGL(slot_ptr_kernel, dim3(grid_for((uint64_t)L_in + 1)), dim3(256), 0, s, L_in, (uint64_t)NE, sloc.p,
                            out.slot_ptr.p);
+        // the rows that receive sums: the entries of real loci (a set slot's header entry sorts behind them)
+        GBRS_HIP_CHECK(hipMemcpyAsync(&n_rows_real, out.slot_ptr.p + L_in, 4, hipMemcpyDeviceToHost, s));
         GBRS_HIP_CHECK(hipStreamSynchronize(s));
     } else {
         GBRS_TRY(out.slot_list.alloc(1));
         GBRS_TRY(out.dest_list.alloc(1));
     }
-    out.n_dest_rows = NE;
-    GBRS_TRY(out.partials.alloc(std::max<size_t>((size_t)NE * H, 1)));
+    out.n_dest_rows = n_rows_real;
+    GBRS_TRY(out.partials.alloc(std::max<size_t>((size_t)n_rows_real * H, 1)));
     hipLaunchKernelGGL(locus_class_kernel, dim3(grid_for(L_in)), dim3(256), 0, s, L_in, out.slot_ptr.p, out.slot_list.p,
                        out.locus_class.p, out.dest_list.p);
     if (NS) hipLaunchKernelGGL(dest_route_kernel, dim3(grid_for(NS)), dim3(256), 0, s, (uint64_t)NS, out.dest_list.p, out.slot_dest.p);
-    if (NE >= SLOT_PAIR) return fail(GBRS_ERR_INVALID, "the tiled layout needs fewer than 2^29 destination rows");
     if (out.n_sets && NS) {
         GBRS_TRY(out.dict_b.alloc(NS));
         GBRS_TRY(out.dest_b.alloc(NS));

@@ -25,6 +25,7 @@ namespace gbrs { int fail(int status, const char *fmt, ...); }
 #include <unistd.h>
 
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <charconv>
 #include <cmath>
@@ -114,6 +115,8 @@ struct ZStream {
 typedef int (*z_init2_fn)(ZStream *, int, const char *, int);
 typedef int (*z_inflate_fn)(ZStream *, int);
 typedef int (*z_end_fn)(ZStream *);
+typedef uint32_t (*ld_crc32_fn)(uint32_t, const void *, size_t);
+typedef unsigned long (*z_crc32_fn)(unsigned long, const unsigned char *, unsigned int);
 
 struct Inflaters {
     uncompress_fn z_uncompress = nullptr;
@@ -124,6 +127,8 @@ struct Inflaters {
     z_init2_fn z_init2 = nullptr;
     z_inflate_fn z_inflate = nullptr;
     z_end_fn z_end = nullptr;
+    ld_crc32_fn ld_crc32 = nullptr;               // libdeflate_crc32: carry-less multiply, several GB/s per core
+    z_crc32_fn z_crc32 = nullptr;
     Inflaters() {
         // libdeflate (about three times zlib's inflate speed) when the machine has it, zlib otherwise;
         // both are looked up at run time so the library has no link-time dependency on either
@@ -135,6 +140,7 @@ struct Inflaters {
                 ld_free = (ld_free_fn)dlsym(h, "libdeflate_free_decompressor");
                 ld_inflate = (ld_inflate_fn)dlsym(h, "libdeflate_zlib_decompress");
                 ld_inflate_raw = (ld_inflate_fn)dlsym(h, "libdeflate_deflate_decompress");
+                ld_crc32 = (ld_crc32_fn)dlsym(h, "libdeflate_crc32");
                 if (ld_alloc && ld_free && ld_inflate && ld_inflate_raw) break;
                 ld_alloc = nullptr; ld_free = nullptr; ld_inflate = nullptr; ld_inflate_raw = nullptr;
             }
@@ -146,6 +152,7 @@ struct Inflaters {
                 z_init2 = (z_init2_fn)dlsym(h, "inflateInit2_");
                 z_inflate = (z_inflate_fn)dlsym(h, "inflate");
                 z_end = (z_end_fn)dlsym(h, "inflateEnd");
+                z_crc32 = (z_crc32_fn)dlsym(h, "crc32");
                 if (z_uncompress) break;
             }
     }
@@ -175,6 +182,34 @@ static bool inflate_raw(const Inflaters &inf, void *ld, const unsigned char *in,
         return ok;
     }
     return false;
+}
+
+// CRC-32 of a zip member's plain bytes (what numpy.load / zipfile check on every access and report as BadZipFile:
+// the reference inherits that): libdeflate's when the machine has it, zlib's otherwise, a table walk as the last resort
+static uint32_t member_crc32(const Inflaters &inf, const unsigned char *p, size_t n) {
+    if (inf.ld_crc32) return inf.ld_crc32(0, p, n);
+    if (inf.z_crc32) {
+        unsigned long c = 0;
+        while (n) {
+            const unsigned int part = (unsigned int)std::min<size_t>(n, 1u << 30);
+            c = inf.z_crc32(c, p, part);
+            p += part;
+            n -= part;
+        }
+        return (uint32_t)c;
+    }
+    static const std::array<uint32_t, 256> table = [] {
+        std::array<uint32_t, 256> t{};
+        for (uint32_t i = 0; i < 256; ++i) {
+            uint32_t c = i;
+            for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            t[i] = c;
+        }
+        return t;
+    }();
+    uint32_t c = 0xFFFFFFFFu;
+    for (size_t i = 0; i < n; ++i) c = table[(c ^ p[i]) & 0xFFu] ^ (c >> 8);
+    return c ^ 0xFFFFFFFFu;
 }
 
 static uint16_t rd16(const unsigned char *p) { return (uint16_t)(p[0] | (p[1] << 8)); }
@@ -350,7 +385,7 @@ int gbrs_zip_directory(const uint8_t *buf, uint64_t len, uint64_t cap, uint16_t 
 }
 
 int gbrs_zip_read_members(const uint8_t *buf, uint64_t len, int64_t n, const uint64_t *header_off, const uint16_t *method,
-                          const uint64_t *csize, const uint64_t *usize, uint8_t *const *out, int32_t threads) {
+                          const uint64_t *csize, const uint64_t *usize, const uint32_t *crc32, uint8_t *const *out, int32_t threads) {
     using gbrs::fail;
     using gbrs::rd16; using gbrs::rd32;
     if (!buf || n < 0 || (n && (!header_off || !method || !csize || !usize || !out))) return fail(GBRS_ERR_INVALID, "bad argument");
@@ -383,6 +418,8 @@ int gbrs_zip_read_members(const uint8_t *buf, uint64_t len, int64_t n, const uin
                 failed = 3;
                 break;
             }
+            // checked on the thread that has just produced the bytes (still in its cache)
+            if (crc32 && gbrs::member_crc32(inf, out[k], usize[k]) != crc32[k]) { failed = 4; break; }
         }
         if (ld) inf.ld_free(ld);
     };
@@ -395,12 +432,13 @@ int gbrs_zip_read_members(const uint8_t *buf, uint64_t len, int64_t n, const uin
     if (failed.load() == 1) return fail(GBRS_ERR_INVALID, "bad local header in the zip file");
     if (failed.load() == 2) return fail(GBRS_ERR_INVALID, "a member does not inflate to its recorded size");
     if (failed.load() == 3) return fail(GBRS_ERR_UNSUPPORTED, "compression method other than stored / deflate");
+    if (failed.load() == 4) return fail(GBRS_ERR_INVALID, "a member fails its CRC-32");
     return GBRS_OK;
 }
 
 int gbrs_npz_stack(const uint8_t *buf, uint64_t len, int64_t n, const uint64_t *header_off, const uint16_t *method,
-                   const uint64_t *csize, const uint64_t *usize, const uint8_t *npy_header, uint64_t npy_header_len,
-                   uint64_t item_bytes, uint8_t *out, uint8_t *needs_fallback, int32_t threads) {
+                   const uint64_t *csize, const uint64_t *usize, const uint32_t *crc32, const uint8_t *npy_header,
+                   uint64_t npy_header_len, uint64_t item_bytes, uint8_t *out, uint8_t *needs_fallback, int32_t threads) {
     using gbrs::fail;
     using gbrs::rd16; using gbrs::rd32;
     if (!buf || n < 0 || (n && (!header_off || !method || !csize || !usize || !out || !needs_fallback)) || !npy_header)
@@ -437,6 +475,7 @@ int gbrs_npz_stack(const uint8_t *buf, uint64_t len, int64_t n, const uint64_t *
                     continue;
                 }
                 if (std::memcmp(img, npy_header, npy_header_len) != 0) continue;
+                if (crc32 && gbrs::member_crc32(inf, img, usize[k]) != crc32[k]) continue;   // the caller's reader reports it by name
                 std::memcpy(out + (size_t)k * item_bytes, img + npy_header_len, item_bytes);
                 needs_fallback[k] = 0;
             }

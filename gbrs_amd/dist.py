@@ -176,6 +176,13 @@ class PipelinedShardedEM:
         """k EM iterations (no error report)."""
         if k <= 0:
             return
+        # A run() that met its stopping rule left the engines stopped (every later step a no-op, so that theta stays the
+        # stopping iteration's).  A step asked for by hand is applied anyway, as EMfactory.update_allelic_expression is
+        # (EMfactory.py:214-232 knows no stopping rule): HIP engines clear their device flag in gbrs_em_estep_partial,
+        # engines that carry the flag on the host (tests/cpu_engine.py) get it cleared here.
+        for e in self.eng:
+            if getattr(e, 'stopped', False) is True:
+                e.stopped = False
         pend = [self.start(*e.estep_partial()) for e in self.eng]
         for _ in range(k - 1):
             for i, e in enumerate(self.eng):

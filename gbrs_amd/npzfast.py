@@ -36,10 +36,12 @@ class _Member:
 
 
 # CRC-32 of the members (numpy.load checks every member on every access and raises BadZipFile: the reference inherits
-# that).  Here: always for a member read on its own when it is deflated or small; for the bulk paths (the transition
-# tables inflated on all cores, the per-gene blocks copied by gbrs_npz_stack) and large stored members only with
-# GBRS_VERIFY_CRC=1 - a pass over 0.4 GB of tables is 0.2-0.4 s, the whole of `gbrs reconstruct`'s file handling.
-VERIFY_ALL = os.environ.get('GBRS_VERIFY_CRC', '0') not in ('', '0')
+# that).  Here: every member is checked once when it is read - the bulk paths (the transition tables inflated on all
+# cores, the per-gene blocks copied by gbrs_npz_stack) check on the native thread that has just produced the bytes
+# (libdeflate's / zlib's crc32, 0.4 GB of tables in ~15 ms spread over the cores); a mismatch sends the member to the
+# one-at-a-time reader, which raises BadZipFile with the member's name.  GBRS_VERIFY_CRC=0 switches the checks of the bulk
+# paths and of large stored members off (a member read on its own is always checked when it is deflated or small).
+VERIFY_ALL = os.environ.get('GBRS_VERIFY_CRC', '1') not in ('', '0')
 STORED_CHECK_MAX = 4 << 20
 
 
@@ -146,7 +148,7 @@ class FastNpz:
         labels = text.split('\n')[:-1]
         if len(labels) != count:
             return None
-        self._native = (method, csize, usize, hoff)          # arrays for stack()
+        self._native = (method, csize, usize, hoff, crc)     # arrays for stack() / read_many()
         crcs = crc.tolist()
         return [_Member(labels[k], int(method[k]), int(csize[k]), int(usize[k]), int(hoff[k]), crcs[k]) for k in range(count)]
 
@@ -242,20 +244,17 @@ class FastNpz:
             from . import _lib
             lib = _lib.load()
             which = np.fromiter((self._index[n] for n in names), dtype=np.int64, count=len(names))
-            m_all, c_all, u_all, h_all = self._native
-            method, csize, usize, hoff = (np.ascontiguousarray(a[which]) for a in (m_all, c_all, u_all, h_all))
+            m_all, c_all, u_all, h_all, crc_all = self._native
+            method, csize, usize, hoff, crc = (np.ascontiguousarray(a[which]) for a in (m_all, c_all, u_all, h_all, crc_all))
             if not np.isin(method, (0, 8)).all():
                 return None
             images = [np.empty(int(u), dtype=np.uint8) for u in usize]
             ptrs = (C.c_void_p * len(names))(*[im.ctypes.data for im in images])
             view = np.frombuffer(self._mm, dtype=np.uint8)
+            # (a member that fails its CRC-32 makes the call decline: the caller's one-at-a-time path then names it)
             if lib.gbrs_zip_read_members(_lib.ptr(view), view.size, len(names), _lib.ptr(hoff), _lib.ptr(method),
-                                         _lib.ptr(csize), _lib.ptr(usize), ptrs, 0):
+                                         _lib.ptr(csize), _lib.ptr(usize), _lib.ptr(crc) if VERIFY_ALL else None, ptrs, 0):
                 return None
-            if VERIFY_ALL:
-                from concurrent.futures import ThreadPoolExecutor
-                with ThreadPoolExecutor(max_workers=min(16, len(names))) as pool:      # zlib.crc32 drops the GIL
-                    list(pool.map(lambda t: _check_crc(self._info[t[0]], t[1], self.path), zip(names, images)))
             out = []
             for im in images:
                 dt, shape, doff = self._npy_header(im)
@@ -317,7 +316,8 @@ class FastNpz:
         _, _, doff = self._npy_header(image)
         header = np.frombuffer(bytes(image[:doff]), dtype=np.uint8)
         which = np.fromiter((self._index[n] for n in names), dtype=np.int64, count=len(names))
-        m_all, c_all, u_all, h_all = self._native
+        m_all, c_all, u_all, h_all, crc_all = self._native
+        crc_k = np.ascontiguousarray(crc_all[which])
         method_k = np.ascontiguousarray(m_all[which])
         csize_k = np.ascontiguousarray(c_all[which])
         usize_k = np.ascontiguousarray(u_all[which])
@@ -326,7 +326,8 @@ class FastNpz:
         view = np.frombuffer(self._mm, dtype=np.uint8)
         flat = out.reshape(len(names), -1).view(np.uint8)
         status = _lib.load().gbrs_npz_stack(_lib.ptr(view), view.size, len(names), _lib.ptr(hoff_k), _lib.ptr(method_k),
-                                            _lib.ptr(csize_k), _lib.ptr(usize_k), _lib.ptr(header), header.size,
+                                            _lib.ptr(csize_k), _lib.ptr(usize_k), _lib.ptr(crc_k) if VERIFY_ALL else None,
+                                            _lib.ptr(header), header.size,
                                             out[0].nbytes, _lib.ptr(flat), _lib.ptr(fallback), 0)
         if status:
             return False

@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import logging
 import os
+import re
 import time
 
 import numpy as np
@@ -32,6 +33,9 @@ def _default_support_file(given, default_name, what_is_lost):
     return path
 
 
+_TWO_TABS_ON_A_LINE = re.compile(r'\t[^\t\n]*\t')
+
+
 def read_genotype_table(genotype_file):
     """(gene ids, diplotype strings) of a `genotypes.tsv` in file order, one pair per line (a gene listed twice
     appears twice): `#Gene_ID<TAB>Diplotype` header, then `<gene><TAB><call>[<TAB>...]` lines.  Only the comment
@@ -47,7 +51,10 @@ def read_genotype_table(genotype_file):
         return [], []
     n_lines = body.count('\n') + (0 if body.endswith('\n') else 1)
     # the plain form - exactly two tab-separated fields per line, no other white space - splits in one pass
-    if body.count('\t') == n_lines and not (' ' in body or '\r' in body or '\n\n' in body or body.startswith('\n')):
+    # (as many tabs as lines AND no line with two of them = exactly one tab on every line: a line with two tabs beside one
+    # with none would otherwise pair the fields up wrongly, where the reference raises on the one-field line, `g, gt = item[:2]`)
+    if body.count('\t') == n_lines and not (' ' in body or '\r' in body or '\n\n' in body or body.startswith('\n')) \
+            and _TWO_TABS_ON_A_LINE.search(body) is None:
         tokens = body.replace('\n', '\t').split('\t')
         if not body.endswith('\n'):
             tokens.append('')

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GBRS_ABI_VERSION 3
+#define GBRS_ABI_VERSION 4
 
 enum gbrs_status {
     GBRS_OK = 0,
@@ -442,16 +442,19 @@ int gbrs_zip_directory(const uint8_t *buf, uint64_t len, uint64_t cap, uint16_t 
                        uint64_t *usize, uint64_t *header_off, uint32_t *crc32 /* nullable: the members' CRC-32 */,
                        char *names, uint64_t names_cap, uint64_t *n_members, uint64_t *names_len);
 /* n members' plain contents (their .npy images), member k into out[k] (usize[k] bytes, caller allocated), copied or
- * inflated on `threads` threads (0 = all cores), largest member first. */
+ * inflated on `threads` threads (0 = all cores), largest member first.  crc32 (nullable): the members' CRC-32 from the
+ * central directory, checked on the thread that produced the bytes - numpy.load / zipfile check every member and raise
+ * BadZipFile (the reference inherits that at gbrs_utils.py:420-441); a mismatch returns GBRS_ERR_INVALID. */
 int gbrs_zip_read_members(const uint8_t *buf, uint64_t len, int64_t n, const uint64_t *header_off, const uint16_t *method,
-                          const uint64_t *csize, const uint64_t *usize, uint8_t *const *out, int32_t threads);
+                          const uint64_t *csize, const uint64_t *usize, const uint32_t *crc32, uint8_t *const *out,
+                          int32_t threads);
 /* n equally shaped .npy members (the per-gene 8 x 8 blocks) -> out[k * item_bytes ...], on `threads` threads
  * (0 = all cores): a member whose .npy image is exactly npy_header followed by item_bytes of data is copied
- * (stored) or inflated (raw deflate) into place; any other member gets needs_fallback[k] = 1 and is left to the
- * caller. */
+ * (stored) or inflated (raw deflate) into place; any other member - and, with crc32 given, one that fails its CRC-32 -
+ * gets needs_fallback[k] = 1 and is left to the caller. */
 int gbrs_npz_stack(const uint8_t *buf, uint64_t len, int64_t n, const uint64_t *header_off, const uint16_t *method,
-                   const uint64_t *csize, const uint64_t *usize, const uint8_t *npy_header, uint64_t npy_header_len,
-                   uint64_t item_bytes, uint8_t *out, uint8_t *needs_fallback, int32_t threads);
+                   const uint64_t *csize, const uint64_t *usize, const uint32_t *crc32, const uint8_t *npy_header,
+                   uint64_t npy_header_len, uint64_t item_bytes, uint8_t *out, uint8_t *needs_fallback, int32_t threads);
 
 #ifdef __cplusplus
 }

@@ -220,40 +220,68 @@ int main(int argc, char **argv) {
                                  &count, &nbytes) == 0);
         CHECK(std::strncmp(names.data(), "gene0000.npy\ngene0001.npy\n", 26) == 0 && ho[7] == offs[7] && us[7] == 192 && method[7] == 0);
         std::vector<unsigned char> out(n * item, 0), fb(n, 9);
-        CHECK(gbrs_npz_stack(zip.data(), zip.size(), n, ho.data(), method.data(), cs.data(), us.data(),
+        CHECK(gbrs_npz_stack(zip.data(), zip.size(), n, ho.data(), method.data(), cs.data(), us.data(), nullptr,
                              (const uint8_t *)npy_header.data(), npy_header.size(), item, out.data(), fb.data(), 3) == 0);
         for (int k = 0; k < n; ++k) CHECK(fb[k] == 0 && out[k * item + 5] == (unsigned char)(k + 5));
         {
             std::vector<std::vector<unsigned char>> imgs(n, std::vector<unsigned char>(192));
             std::vector<uint8_t *> ptrs(n);
             for (int k = 0; k < n; ++k) ptrs[k] = imgs[k].data();
-            CHECK(gbrs_zip_read_members(zip.data(), zip.size(), n, ho.data(), method.data(), cs.data(), us.data(), ptrs.data(), 3) == 0);
+            CHECK(gbrs_zip_read_members(zip.data(), zip.size(), n, ho.data(), method.data(), cs.data(), us.data(), nullptr, ptrs.data(), 3) == 0);
             for (int k = 0; k < n; ++k) CHECK(std::memcmp(imgs[k].data(), npy_header.data(), 128) == 0 && imgs[k][128 + 9] == (unsigned char)(k + 9));
             method[2] = 8;                                            // not a deflate stream
-            CHECK(gbrs_zip_read_members(zip.data(), zip.size(), n, ho.data(), method.data(), cs.data(), us.data(), ptrs.data(), 2) < 0);
+            CHECK(gbrs_zip_read_members(zip.data(), zip.size(), n, ho.data(), method.data(), cs.data(), us.data(), nullptr, ptrs.data(), 2) < 0);
             method[2] = 12;
-            CHECK(gbrs_zip_read_members(zip.data(), zip.size(), n, ho.data(), method.data(), cs.data(), us.data(), ptrs.data(), 2) < 0);
+            CHECK(gbrs_zip_read_members(zip.data(), zip.size(), n, ho.data(), method.data(), cs.data(), us.data(), nullptr, ptrs.data(), 2) < 0);
             method[2] = 0;
             ho[1] = zip.size() - 3;
-            CHECK(gbrs_zip_read_members(zip.data(), zip.size(), n, ho.data(), method.data(), cs.data(), us.data(), ptrs.data(), 2) < 0);
+            CHECK(gbrs_zip_read_members(zip.data(), zip.size(), n, ho.data(), method.data(), cs.data(), us.data(), nullptr, ptrs.data(), 2) < 0);
             ho[1] = offs[1];
+        }
+        {
+            // CRC-32 of the members (what numpy.load checks on every access): a right table passes, a wrong entry sends the
+            // member to the caller (stack) / fails the call (read_members)
+            auto crc_of = [](const unsigned char *p, size_t nb) {
+                uint32_t c = 0xFFFFFFFFu;
+                for (size_t i = 0; i < nb; ++i) {
+                    c ^= p[i];
+                    for (int b = 0; b < 8; ++b) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+                }
+                return c ^ 0xFFFFFFFFu;
+            };
+            std::vector<uint32_t> crcs(n);
+            std::vector<std::vector<unsigned char>> imgs(n, std::vector<unsigned char>(192));
+            std::vector<uint8_t *> ptrs(n);
+            for (int k = 0; k < n; ++k) {
+                ptrs[k] = imgs[k].data();
+                crcs[k] = crc_of(zip.data() + offs[k] + 30 + 12, 192);
+            }
+            CHECK(gbrs_zip_read_members(zip.data(), zip.size(), n, ho.data(), method.data(), cs.data(), us.data(), crcs.data(), ptrs.data(), 3) == 0);
+            CHECK(gbrs_npz_stack(zip.data(), zip.size(), n, ho.data(), method.data(), cs.data(), us.data(), crcs.data(),
+                                 (const uint8_t *)npy_header.data(), npy_header.size(), item, out.data(), fb.data(), 3) == 0);
+            for (int k = 0; k < n; ++k) CHECK(fb[k] == 0);
+            crcs[11] ^= 0x00100000u;
+            CHECK(gbrs_zip_read_members(zip.data(), zip.size(), n, ho.data(), method.data(), cs.data(), us.data(), crcs.data(), ptrs.data(), 3) < 0);
+            CHECK(gbrs_npz_stack(zip.data(), zip.size(), n, ho.data(), method.data(), cs.data(), us.data(), crcs.data(),
+                                 (const uint8_t *)npy_header.data(), npy_header.size(), item, out.data(), fb.data(), 3) == 0);
+            for (int k = 0; k < n; ++k) CHECK(fb[k] == (k == 11 ? 1 : 0));
         }
         std::string other = npy_header;
         other[20] = 'x';                                              // another header: every member goes to the caller
-        CHECK(gbrs_npz_stack(zip.data(), zip.size(), n, ho.data(), method.data(), cs.data(), us.data(), (const uint8_t *)other.data(),
+        CHECK(gbrs_npz_stack(zip.data(), zip.size(), n, ho.data(), method.data(), cs.data(), us.data(), nullptr, (const uint8_t *)other.data(),
                              other.size(), item, out.data(), fb.data(), 1) == 0);
         for (int k = 0; k < n; ++k) CHECK(fb[k] == 1);
         method[3] = 8;                                                // claims deflate: the bytes are no deflate stream
-        CHECK(gbrs_npz_stack(zip.data(), zip.size(), n, ho.data(), method.data(), cs.data(), us.data(),
+        CHECK(gbrs_npz_stack(zip.data(), zip.size(), n, ho.data(), method.data(), cs.data(), us.data(), nullptr,
                              (const uint8_t *)npy_header.data(), npy_header.size(), item, out.data(), fb.data(), 2) == 0);
         CHECK(fb[3] == 1 && fb[4] == 0);
         method[3] = 0;
         ho[5] = zip.size() + 77;                                      // offsets outside the image are errors, not reads
-        CHECK(gbrs_npz_stack(zip.data(), zip.size(), n, ho.data(), method.data(), cs.data(), us.data(),
+        CHECK(gbrs_npz_stack(zip.data(), zip.size(), n, ho.data(), method.data(), cs.data(), us.data(), nullptr,
                              (const uint8_t *)npy_header.data(), npy_header.size(), item, out.data(), fb.data(), 2) < 0);
         ho[5] = offs[5];
         cs[6] = zip.size();
-        CHECK(gbrs_npz_stack(zip.data(), zip.size(), n, ho.data(), method.data(), cs.data(), us.data(),
+        CHECK(gbrs_npz_stack(zip.data(), zip.size(), n, ho.data(), method.data(), cs.data(), us.data(), nullptr,
                              (const uint8_t *)npy_header.data(), npy_header.size(), item, out.data(), fb.data(), 2) < 0);
         // every truncation of the tail, and random byte damage anywhere: any status, no out-of-bounds access
         for (size_t cut = 1; cut < 200 && cut < zip.size(); ++cut) {
@@ -269,7 +297,7 @@ int main(int argc, char **argv) {
             std::vector<uint32_t> crcs(n);
             if (gbrs_zip_directory(t.data(), t.size(), n, m2.data(), c2.data(), u2.data(), h2.data(), crcs.data(), names.data(), names.size(),
                                    &count, &nbytes) == 0 && count == (uint64_t)n)
-                (void)gbrs_npz_stack(t.data(), t.size(), n, h2.data(), m2.data(), c2.data(), u2.data(),
+                (void)gbrs_npz_stack(t.data(), t.size(), n, h2.data(), m2.data(), c2.data(), u2.data(), (trial & 1) ? crcs.data() : nullptr,
                                      (const uint8_t *)npy_header.data(), npy_header.size(), item, out.data(), fb.data(), 2);
         }
         CHECK(gbrs_zip_directory(zip.data(), 10, 0, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, &count, &nbytes) < 0);
@@ -280,13 +308,13 @@ int main(int argc, char **argv) {
             for (int k = 0; k < n; ++k) ptrs[k] = imgs[k].data();
             for (uint64_t huge : {(uint64_t)~0ull, (uint64_t)(~0ull - 29), (uint64_t)(~0ull - 100), (uint64_t)1 << 63}) {
                 ho[4] = huge;
-                CHECK(gbrs_zip_read_members(zip.data(), zip.size(), n, ho.data(), method.data(), cs.data(), us.data(), ptrs.data(), 2) < 0);
-                CHECK(gbrs_npz_stack(zip.data(), zip.size(), n, ho.data(), method.data(), cs.data(), us.data(),
+                CHECK(gbrs_zip_read_members(zip.data(), zip.size(), n, ho.data(), method.data(), cs.data(), us.data(), nullptr, ptrs.data(), 2) < 0);
+                CHECK(gbrs_npz_stack(zip.data(), zip.size(), n, ho.data(), method.data(), cs.data(), us.data(), nullptr,
                                      (const uint8_t *)npy_header.data(), npy_header.size(), item, out.data(), fb.data(), 2) < 0);
                 ho[4] = offs[4];
                 cs[4] = huge;
-                CHECK(gbrs_zip_read_members(zip.data(), zip.size(), n, ho.data(), method.data(), cs.data(), us.data(), ptrs.data(), 2) < 0);
-                CHECK(gbrs_npz_stack(zip.data(), zip.size(), n, ho.data(), method.data(), cs.data(), us.data(),
+                CHECK(gbrs_zip_read_members(zip.data(), zip.size(), n, ho.data(), method.data(), cs.data(), us.data(), nullptr, ptrs.data(), 2) < 0);
+                CHECK(gbrs_npz_stack(zip.data(), zip.size(), n, ho.data(), method.data(), cs.data(), us.data(), nullptr,
                                      (const uint8_t *)npy_header.data(), npy_header.size(), item, out.data(), fb.data(), 2) < 0);
                 cs[4] = us[4];
             }

@@ -18,7 +18,7 @@ def test_header_symbols_exported(hip_lib):
     for n in names:
         assert hasattr(hip_lib, n), f"{n} declared in gbrs_hip.h but not exported"
     assert sorted(_lib.EXPORTS) == names
-    assert hip_lib.gbrs_abi_version() == 3
+    assert hip_lib.gbrs_abi_version() == 4
 
 
 def test_header_constants_match_python_mirror():

@@ -113,8 +113,10 @@ def _pipelined_worker(rank, world, port, path, out_dir):
     theta_fixed = drv.theta()
     drv.prepare(0.0)                           # and again under the driver's own stopping rule
     n = drv.run(model=4, tol=float(g["tol"]), max_iters=int(g["max_iters"]), check_every=4)
-    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), theta=theta_fixed, theta_run=drv.theta(), n=n, l_split=l_split,
-             err=np.array(drv.err_history))
+    theta_run = drv.theta()
+    drv.step(1)                                # a step by hand after a run that stopped is applied, not swallowed
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), theta=theta_fixed, theta_run=theta_run, n=n, l_split=l_split,
+             err=np.array(drv.err_history), theta_plus1=drv.theta(), n_plus1=drv.num_iters)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -137,6 +139,16 @@ def test_two_rank_pipelined_halves_match_reference(tmp_path, name):
     np.testing.assert_allclose(a["err"], g["err_history"], rtol=1e-7)
     np.testing.assert_allclose(a["theta"], g["theta_final"], rtol=1e-9, atol=1e-300)
     np.testing.assert_allclose(a["theta_run"], g["theta_final"], rtol=1e-9, atol=1e-300)   # theta after run(): not a step further
+    # run() -> step(1): one more iteration of the oracle from the final state
+    from oracle.em_oracle import EMOracle
+    R, L, H, indptr, indices, count, eff_len, groups, gtmask = em_case_inputs(g)
+    o = EMOracle(R, L, H, indptr, indices, count)
+    o.prepare(0.0, eff_len)
+    for _ in range(int(g["num_iters"]) + 1):
+        o.em_step()
+    assert int(a["n_plus1"]) == int(g["num_iters"]) + 1
+    np.testing.assert_allclose(a["theta_plus1"], o.theta, rtol=1e-9, atol=1e-300)
+    assert not np.allclose(a["theta_plus1"], a["theta_run"], rtol=1e-12, atol=0)
 
 
 def test_split_at_locus_partitions_entries():

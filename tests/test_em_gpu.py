@@ -18,7 +18,19 @@ LAYOUTS = {"tiles": dict(), "tiles_merged": dict(merge_identical_rows=True), "cs
            "tiles_sorted": dict(extra_flags=16), "tiles_merged_interleaved": dict(merge_identical_rows=True, extra_flags=16),
            "tiles_deterministic": dict(deterministic=True),
            "tiles_deterministic_merged": dict(deterministic=True, merge_identical_rows=True),
-           "tiles_no_locus_sets": dict(extra_flags=512)}
+           "tiles_no_locus_sets": dict(extra_flags=512),
+           # the layout the headline number runs on: the build's own rule (>= 100 words per id) declines the sets on
+           # inputs of this size, GBRS_TUNING_LOCUS_SETS=1 forces them (see the fixture below)
+           "tiles_locus_sets_forced": dict()}
+
+
+@pytest.fixture(autouse=True)
+def _forced_locus_sets(request, monkeypatch):
+    """Layout "tiles_locus_sets_forced": every unweighted tile layout built inside the test takes the locus sets."""
+    cs = getattr(request.node, "callspec", None)
+    if cs is not None and cs.params.get("layout") == "tiles_locus_sets_forced":
+        monkeypatch.setenv("GBRS_TUNING_LOCUS_SETS", "1")
+    yield
 
 
 def pack_mask(gtmask):
@@ -50,6 +62,20 @@ def make_factory(g, layout="tiles", mask_on="device"):
     return em
 
 
+def _rows_with_one_mask_over_several_loci(g):
+    """Number of reads of an em_*.npz fixture that align to more than one locus with the same haplotype mask at each
+    (after the fixture's `-G` mask): the reads a locus set replaces by one word."""
+    R, L, H, indptr, indices, count, eff_len, groups, gtmask = em_case_inputs(g)
+    m = np.zeros((R, L), dtype=np.int64)
+    for h in range(H):
+        col = np.repeat(np.arange(L), np.diff(indptr[h].astype(np.int64)))
+        keep = np.ones(len(col), dtype=bool) if gtmask is None else gtmask[h, col] != 0
+        m[indices[h].astype(np.int64)[keep], col[keep]] |= 1 << h
+    nl = (m != 0).sum(axis=1)
+    same = (np.where(m != 0, m, m.max(axis=1, keepdims=True)) == m.max(axis=1, keepdims=True)).all(axis=1)
+    return int(((nl > 1) & same).sum())
+
+
 def close(a, b, rtol=RTOL):
     np.testing.assert_allclose(a, b, rtol=rtol, atol=1e-300)
 
@@ -63,6 +89,11 @@ def test_em_matches_reference_golden(path, layout):
     expect_layout = 0 if (layout == "csc" or int(g["num_haps"]) > 16) else 1
     em.prepare(pseudocount=pc)
     assert em.info().layout == expect_layout
+    if layout == "tiles_locus_sets_forced" and expect_layout == 1 and not bool(g["has_count"]):
+        # unweighted rows (the build never takes sets for weighted ones): the sets must really be there whenever some
+        # read aligns to several loci under one mask
+        multi = _rows_with_one_mask_over_several_loci(g)
+        assert (em.info().num_locus_sets > 0) == (multi > 0), (em.info().num_locus_sets, multi)
     close(em.allelic_expression, g["theta0"])
     # fixed iteration counts: tol=0 never stops early
     done = 0
@@ -442,12 +473,44 @@ def _sharded_worker(rank, world, port, path, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_rank_sharded_hip_engines(tmp_path):
+def _synth16_case(tmp_path):
+    """A 16-haplotype sample without row weights in the goldens' file format (the reference fixtures hold 16 haplotypes
+    only with `count`): configs[4]'s kernel instance (tile_estep_kernel<16, false, ...>) under the multi-rank drivers.
+    Expected values from the oracle - itself pinned bit-for-bit to the reference on the goldens."""
+    from gbrs_amd import synth
+    from oracle.em_oracle import EMOracle
+    inc = synth.make_em_problem(R=6000, H=16, L=150, seed=41)
+    eff = inc.effective_length(100)
+    o = EMOracle(inc.num_rows, inc.num_loci, 16, inc.indptr, inc.indices, None)
+    o.prepare(0.0, eff)
+    n = o.run(tol=1e-3, max_iters=40)
+    gp = np.concatenate(([0], np.cumsum([len(m) for m in inc.groups])))
+    d = dict(num_haps=16, num_loci=inc.num_loci, num_rows=inc.num_rows, has_count=False, has_len=True, has_mask=False,
+             eff_len=eff, group_ptr=gp, group_members=np.concatenate([np.asarray(m) for m in inc.groups]),
+             pseudocount=0.0, tol=1e-3, max_iters=40, num_iters=n, theta_final=o.theta, err_history=np.asarray(o.err_history))
+    for h in range(16):
+        d[f"indptr{h}"], d[f"indices{h}"] = inc.indptr[h], inc.indices[h]
+    path = str(tmp_path / "em_synth16.npz")
+    np.savez(path, **d)
+    return path
+
+
+def _two_rank_case(name, tmp_path):
+    if name == "synth16_unweighted":
+        return _synth16_case(tmp_path)
+    return [p for p in golden_files("em") if p.endswith(f"em_{name}.npz")][0]
+
+
+TWO_RANK_CASES = ["h8_count_len", "h8_len", "h16_len", "synth16_unweighted"]
+
+
+@pytest.mark.parametrize("name", TWO_RANK_CASES)
+def test_two_rank_sharded_hip_engines(tmp_path, name):
     """Rows sharded over two processes driving HIP engines (same GPU, gloo all-reduce through host
     copies): identical on both ranks and equal to the unsharded reference."""
     import socket
     import torch.multiprocessing as mp
-    path = [p for p in golden_files("em") if p.endswith("em_h8_count_len.npz")][0]
+    path = _two_rank_case(name, tmp_path)
     g = load_golden(path)
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     mp.spawn(_sharded_worker, args=(2, port, path, str(tmp_path)), nprocs=2, join=True)
@@ -498,21 +561,24 @@ def _pipelined_worker(rank, world, port, path, out_dir):
     # and read every 8: iterations enqueued past the stopping one must be no-ops
     drv.prepare(0.0)
     n = drv.run(model=4, tol=float(g["tol"]), max_iters=int(g["max_iters"]), check_every=8)
-    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), theta=theta_fixed, l_split=l_split, n=n, theta_run=drv.theta(),
-             err=np.array(drv.err_history))
+    theta_run = drv.theta()
+    drv.step(1)          # by hand, after a run that stopped through the device flags: applied, not swallowed
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), theta=theta_fixed, l_split=l_split, n=n, theta_run=theta_run,
+             err=np.array(drv.err_history), theta_plus1=drv.theta(), n_plus1=drv.num_iters)
     for e in engs:
         e.close()
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_two_rank_pipelined_hip_engines(tmp_path):
+@pytest.mark.parametrize("name", TWO_RANK_CASES)
+def test_two_rank_pipelined_hip_engines(tmp_path, name):
     """Rows sharded over two processes, loci cut at a gene boundary into two HIP engines per process whose
     (gloo) all-reduces are started asynchronously and interleaved with the other half's E-step: after
-    the reference's number of iterations theta is the reference's."""
+    the reference's number of iterations theta is the reference's; 8 and 16 haplotypes, with and without row weights."""
     import socket
     import torch.multiprocessing as mp
-    path = [p for p in golden_files("em") if p.endswith("em_h8_count_len.npz")][0]
+    path = _two_rank_case(name, tmp_path)
     g = load_golden(path)
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     mp.spawn(_pipelined_worker, args=(2, port, path, str(tmp_path)), nprocs=2, join=True)
@@ -524,6 +590,16 @@ def test_two_rank_pipelined_hip_engines(tmp_path):
     np.testing.assert_allclose(a["err"], g["err_history"], rtol=1e-7)
     np.testing.assert_array_equal(a["theta_run"], b["theta_run"])
     close(a["theta_run"], g["theta_final"])
+    # run() -> step(1): the oracle one iteration past the stopping one
+    from oracle.em_oracle import EMOracle
+    R, L, H, indptr, indices, count, eff_len, groups, gtmask = em_case_inputs(g)
+    o = EMOracle(R, L, H, indptr, indices, count)
+    o.prepare(0.0, eff_len)
+    for _ in range(int(g["num_iters"]) + 1):
+        o.em_step()
+    assert int(a["n_plus1"]) == int(g["num_iters"]) + 1
+    close(a["theta_plus1"], o.theta)
+    assert not np.allclose(a["theta_plus1"], a["theta_run"], rtol=1e-12, atol=0)
 
 
 def _random_rows_problem(R, H, L, seed, min_loci, max_loci, with_count):

@@ -210,6 +210,12 @@ def test_genotype_table_forms(tmp_path):
     assert genotype_mask_from_file(apm, str(bad)) is None
     with pytest.raises(ValueError):
         read_genotype_table(str(bad))
+    # as many tabs as lines, but two on the first line and none on the second: the reference raises on the one-field
+    # line (`g, gt = item[:2]`); the one-pass splitter must not pair the fields up across lines
+    bad.write_text("G0000000\tAB\tG0000001\nCD\n")
+    assert genotype_mask_from_file(apm, str(bad)) is None
+    with pytest.raises(ValueError):
+        read_genotype_table(str(bad))
     for text in ("G0000000\tAZ\n", "nope\tAB\n", "G0000000\tABCDEFGHA\n", "G0000000\tA\xc3\xa9\n"):
         bad.write_text(text)
         assert genotype_mask_from_file(apm, str(bad)) is None        # left to the line-by-line path and its errors

@@ -109,7 +109,7 @@ def test_damaged_files_fall_back_or_fail_cleanly(tmp_path):
 
 def test_bit_rot_is_reported_like_numpy_load(tmp_path, monkeypatch):
     """A member whose payload no longer matches its CRC-32 raises BadZipFile when read on its own (numpy.load's
-    behaviour, which the reference inherits); the bulk paths check under GBRS_VERIFY_CRC=1."""
+    behaviour, which the reference inherits), on its own and through the bulk paths (read_many, stack)."""
     import zipfile
     from gbrs_amd import npzfast
     rng = np.random.default_rng(3)
@@ -132,11 +132,31 @@ def test_bit_rot_is_reported_like_numpy_load(tmp_path, monkeypatch):
         assert z["g006"].flags.writeable and z["g006"].flags.aligned
         with pytest.raises((zipfile.BadZipFile, zlib_error())):
             z["g007"]
-        monkeypatch.setattr(npzfast, "VERIFY_ALL", True)
+        # the bulk paths check by default (on the native threads that produce the bytes); GBRS_VERIFY_CRC=0 opts out
+        assert npzfast.VERIFY_ALL
         with pytest.raises((zipfile.BadZipFile, zlib_error())):
             z.read_many(list(arrays))
-        monkeypatch.setattr(npzfast, "VERIFY_ALL", False)
+        genes = [f"g{k:03d}" for k in range(20)]
+        with pytest.raises((zipfile.BadZipFile, zlib_error())):
+            z.stack(genes, (8, 8))
+        np.testing.assert_array_equal(z.stack(genes[:7], (8, 8)), np.stack([arrays[n] for n in genes[:7]]))
         z.close()
+    # damage in a LARGE deflated member: only the bulk path's own check can see it
+    p = tmp_path / "tables.npz"
+    big = {f"c{k}": rng.random(300_000) for k in range(6)}
+    np.savez_compressed(p, **big)
+    z = npzfast.FastNpz(str(p))
+    zi = z._info["c3"]
+    _, off, csize = z._payload(zi)
+    z.close()
+    raw = bytearray(p.read_bytes())
+    raw[off + csize // 2] ^= 0x01
+    bad = tmp_path / "bad_tables.npz"
+    bad.write_bytes(bytes(raw))
+    z = npzfast.FastNpz(str(bad))
+    with pytest.raises((zipfile.BadZipFile, zlib_error())):
+        z.read_many(list(big))
+    z.close()
 
 
 def zlib_error():
