@@ -10,7 +10,9 @@ DO-shaped sample of BASELINE.json configs[1]: 40M reads x 8 haplotypes x 120k is
 (SURVEY.md §8d generator), resident in HBM before the timed region.  With N > 1 every rank holds
 its own 40M-read shard of a pooled sample (reads sharded, weak scaling) and the ranks exchange
 the H*L expected-count vector with one RCCL all-reduce per iteration; the value
-reported is shard-iterations/s summed over ranks.
+reported is shard-iterations/s summed over ranks.  The N > 1 line also carries `replicas` (configs[3] as
+SURVEY §8e reads it: one independent sample per GPU, samples/s, no collective), `time_to_solution` through the
+same multi-rank driver, and `hmm` (every rank its own samples, aggregate genes/s, no collective).
 
 The same line carries `roofline` (E-step kernel, HIP-event time measured in the library on its
 own stream), `cpu_baseline` (the numpy oracle, 1 core, bounded sample) and an `hmm` object with
@@ -48,6 +50,8 @@ def parse():
     ap.add_argument("--no-hmm", action="store_true")
     ap.add_argument("--no-merged-line", action="store_true")
     ap.add_argument("--no-check", action="store_true", help="skip the post-run tiles-vs-CSC theta comparison")
+    ap.add_argument("--no-solve", action="store_true", help="skip the time-to-solution measurements (tol = 1e-4)")
+    ap.add_argument("--no-replicas", action="store_true", help="N > 1: skip the one-sample-per-GPU replica measurement (configs[3])")
     ap.add_argument("--from-host", action="store_true", help="also time gbrs_em_create from host (numpy) arrays: PCIe copy + layout build")
     ap.add_argument("--cpu-rows", type=int, default=2_000_000, help="rows of the one-core baseline when it cannot run at full size")
     ap.add_argument("--cpu-iters", type=int, default=60, help="oracle iterations timed for cpu_baseline (stops at 25 s)")
@@ -190,6 +194,28 @@ def em_bench(args, rank, world, torch, dist, keep_host=False):
         n_it, hist = eng.run(model=4, tol=1e-4, max_iters=999)
         res["solve"] = dict(iterations=n_it, ms=(time.perf_counter() - t1) * 1e3,
                             final_err_sum=float(hist[-1]) if n_it else None)
+    if use_dist and world > 1 and not args.no_solve:
+        # N > 1 on one engine per GPU: gbrs_amd.dist.ShardedEM with the all-reduce in line on the engine's stream
+        from gbrs_amd.dist import ShardedEM
+
+        _views = {}
+
+        def _ar(ptr, n):
+            if ptr not in _views:
+                _views[ptr] = torch.as_tensor(DevArray(ptr, n), device=dev)
+            dist.all_reduce(_views[ptr])
+        drv = ShardedEM(eng, _ar)
+        drv.prepare(0.0)
+        barrier()
+        t1 = time.perf_counter()
+        n_it = drv.run(model=4, tol=1e-4, max_iters=999)
+        barrier()
+        ms = (time.perf_counter() - t1) * 1e3
+        tt = torch.tensor([ms], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        res["solve"] = dict(iterations=n_it, ms=float(tt.item()), final_err_sum=drv.err_history[-1] if n_it else None,
+                            path="ShardedEM.run (one engine per rank, err_sum read back every iteration)",
+                            rows_in_the_pool=args.rows * world)
     if world == 1:
         res["estep_ms"] = inf.last_estep_ms
         res["step_ms"] = inf.last_step_ms
@@ -347,6 +373,23 @@ def em_bench_pipelined(args, rank, world, torch, dist, state):
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     check = em_state_check(torch, [e.expected_counts() for e in engs], float(args.rows) * world)
+    # time to solution through the same two-engine loop: prepare, then the reference's stopping rule (EMfactory.py:266-278)
+    # over both locus ranges on the device (gbrs_em_pair_check), looked at every 8 iterations; max over ranks
+    solve = None
+    if not args.no_solve:
+        drv.prepare(0.0)
+        barrier()
+        t1 = time.perf_counter()
+        n_it = drv.run(model=4, tol=1e-4, max_iters=999)
+        barrier()
+        ms = (time.perf_counter() - t1) * 1e3
+        if world > 1:
+            tt = torch.tensor([ms], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            ms = float(tt.item())
+        solve = dict(iterations=n_it, ms=ms, final_err_sum=drv.err_history[-1] if drv.err_history else None,
+                     path="PipelinedShardedEM.run (two engines per rank, pair stopping rule on the device)",
+                     rows_in_the_pool=args.rows * world)
     # per-launch E-step time of the two halves: local steps without the collective
     estep_ms = step_ms = 0.0
     infos = []
@@ -360,7 +403,7 @@ def em_bench_pipelined(args, rank, world, torch, dist, state):
         e.close()
     return dict(dt=dt, t_gen=state["t_gen"], t_create=state["t_create"], t_create_host=None, N=state["N"],
                 info=infos[0], infos=infos, estep_ms=estep_ms, step_ms=step_ms, l_split=state["l_split"],
-                check=check)
+                check=check, **({"solve": solve} if solve else {}))
 
 
 def em_state_check(torch, counts_list, expect_total):
@@ -375,6 +418,101 @@ def em_state_check(torch, counts_list, expect_total):
         out["expected"] = float(expect_total)
         out["rel_err"] = abs(tot - expect_total) / max(expect_total, 1.0)
         out["ok"] = bool(ok and out["rel_err"] < 1e-9)
+    return out
+
+
+def max_over_ranks(x, torch, dist, world, dev):
+    if world == 1:
+        return float(x)
+    t = torch.tensor([float(x)], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def gather_over_ranks(x, torch, dist, world, dev):
+    if world == 1:
+        return [float(x)]
+    t = torch.zeros(world, dtype=torch.float64, device=dev)
+    t[dist.get_rank()] = float(x)
+    dist.all_reduce(t)
+    return [float(v) for v in t.tolist()]
+
+
+def replica_bench(args, rank, world, torch, dist):
+    """BASELINE.json configs[3] read as SURVEY 8(e) reads it: N samples, one per GPU, every rank solves ITS OWN sample
+    (independent theta: replicas only, no collective on the data path) - layout build from the CSC arrays in HBM,
+    prepare, then EMfactory.run's loop with the reference's default stopping rule (tol = 1e-4).  Reported as samples/s:
+    N samples / the slowest rank's time, the region bracketed by barriers."""
+    from gbrs_amd import synth, synth_torch
+    from gbrs_amd.engine import EmEngine
+    dev = f"cuda:{torch.cuda.current_device()}"
+    # a sample of its own per rank: its own abundances, gene sizes and reads (seed offset 1000 * (rank + 1))
+    seed = synth.SEED_BASE_EM + 1 + 1000 * (rank + 1)
+    prob = synth_torch.make_em_problem_device(args.rows, args.haps, args.loci, seed, dev, row_seed=seed,
+                                              variant=args.variant)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+
+    def one_sample():
+        t0 = time.perf_counter()
+        eng = EmEngine.from_device(prob["R"], prob["L"], prob["H"], [t.data_ptr() for t in prob["indptr"]],
+                                   [t.data_ptr() for t in prob["indices"]], None, prob["eff_len"].data_ptr(),
+                                   device=torch.cuda.current_device(), flags=args.flags)
+        t1 = time.perf_counter()
+        eng.prepare(0.0)
+        n_it, hist = eng.run(model=4, tol=1e-4, max_iters=999)
+        t2 = time.perf_counter()
+        tot = float(eng.expected_counts().sum())
+        eng.close()
+        return t1 - t0, t2 - t1, n_it, tot
+
+    one_sample()                                   # untimed: code objects, allocator pools, clocks
+    barrier()
+    t0 = time.perf_counter()
+    t_create, t_solve, n_it, tot = one_sample()
+    barrier()
+    dt = max_over_ranks(time.perf_counter() - t0, torch, dist, world, dev)
+    solve_max = max_over_ranks(t_solve, torch, dist, world, dev)
+    create_max = max_over_ranks(t_create, torch, dist, world, dev)
+    iters = gather_over_ranks(n_it, torch, dist, world, dev)
+    mass = gather_over_ranks(abs(tot - args.rows) / args.rows, torch, dist, world, dev)
+    del prob
+    torch.cuda.empty_cache()
+    return dict(metric="samples/s: one sample per GPU, layout build from arrays in HBM + prepare + run(tol=1e-4); no collective",
+                value=world / dt, unit="samples/s", n_gpus=world, seconds=dt, scaling="weak",
+                em_only=dict(value=world / solve_max, unit="samples/s", seconds=solve_max,
+                             note="prepare + EMfactory.run loop alone (the slowest rank), layout already built"),
+                layout_build_seconds=create_max, iterations_per_rank=[int(v) for v in iters],
+                mass_conservation_rel_err_per_rank=mass,
+                workload=f"R={args.rows} reads x H={args.haps} x L={args.loci} isoforms per sample, a different sample "
+                         f"(abundances, gene sizes, reads) on every rank")
+
+
+def hmm_bench_ranks(args, rank, world, torch, dist):
+    """N > 1: the HMM is independent per (sample, chromosome) (gbrs_utils.py:498-599) - replicas only, no collective.
+    Every rank runs its own samples through the same pass as the N = 1 line (one sample: the CLI's shape; a batch that
+    fills the chip); genes/s = all ranks' gene x sample units / the slowest rank's pass time."""
+    dev = f"cuda:{torch.cuda.current_device()}"
+    out = None
+    for key, ns in (("single", 1), ("batched_large", args.hmm_batch_large)):
+        if ns <= 0 or (key == "batched_large" and args.hmm_haps != 8):
+            continue
+        if world > 1:
+            dist.barrier()
+        b = hmm_bench(args, torch, ns=ns, with_cpu=False, sample_seed=1 + rank)
+        ms = max_over_ranks(b["ms_per_pass"], torch, dist, world, dev)
+        wall = max_over_ranks(b["wall_clock"]["ms_per_pass"], torch, dist, world, dev)
+        units = b["genes"] * ns * world
+        rec = dict(value=units / (ms * 1e-3), unit="genes/s", n_gpus=world, samples_per_gpu=ns, ms_per_pass_slowest_rank=ms,
+                   wall_clock=dict(value=units / (wall * 1e-3), unit="genes/s", ms_per_pass_slowest_rank=wall),
+                   per_gpu_roofline_frac=b["roofline"]["frac"] * b["ms_per_pass"] / ms, genes=b["genes"], states=b["states"])
+        if key == "single":
+            out = dict(metric=b["metric"] + "; one process per GPU, no collective", scaling="weak", **rec)
+        else:
+            out["batched_large"] = rec
     return out
 
 
@@ -436,7 +574,7 @@ def em_cpu_baseline(args, host=None):
                        f"rule); host has {os.cpu_count()} cores, reference is single-threaded")
 
 
-def hmm_bench(args, torch, ns=None, with_cpu=True):
+def hmm_bench(args, torch, ns=None, with_cpu=True, sample_seed=1):
     import numpy as np
     from gbrs_amd import synth
     from gbrs_amd.hmm import DiplotypeHMM
@@ -446,11 +584,13 @@ def hmm_bench(args, torch, ns=None, with_cpu=True):
     ns = args.hmm_samples if ns is None else ns
     hmm = DiplotypeHMM(HH, chroms, [len(prob.gene_ids[c]) for c in chroms], [prob.tprob[c] for c in chroms],
                        device=torch.cuda.current_device())
-    rng = np.random.default_rng(1)
+    rng = np.random.default_rng(sample_seed)
     ex, av, ha = [], [], []
     for c in chroms:
         ids = prob.gene_ids[c]
         e = np.array([prob.expr[g] for g in ids])
+        if sample_seed != 1:                       # another rank's sample: its own expression values
+            e = rng.gamma(1.0, 5.0, size=e.shape) * (rng.random(e.shape) < 0.5)
         if ns > 1:
             e = np.stack([e] + [rng.gamma(1.0, 5.0, size=e.shape) * (rng.random(e.shape) < 0.5)
                                 for _ in range(ns - 1)])
@@ -661,18 +801,27 @@ def main():
     priced_step = min(algo, moved)
     achieved = priced_estep / estep_s / 1e9 if estep_s > 0 else None
     useful_flop = 4.0 * em["N"]                         # per stored entry: one FMA into den, one into A
+    def short(n):
+        return f"{n / 1e6:g}M" if n >= 1_000_000 and n % 100_000 == 0 else (f"{n / 1e3:g}k" if n >= 1000 and n % 100 == 0 else str(n))
+    is_c2 = (args.rows, args.haps, args.loci) == (40_000_000, 8, 120_000)
+    is_c5_shard = (args.rows, args.haps, args.loci) == (25_000_000, 16, 200_000)
+    cfg_name = "configs[1]: single DO sample" if is_c2 and world == 1 else \
+        ("configs[3]-shaped pool: one shard per GPU" if is_c2 else
+         ("configs[4]: one GPU's shard of the 200M-read x 16-haplotype sample" if is_c5_shard else "custom shape"))
     line = {
-        "metric": "EM iterations/s (EMASE Model 4, 40M reads x 8 haplotypes x 120k isoforms per GPU)",
+        "metric": f"EM iterations/s (EMASE Model 4, {short(args.rows)} reads x {args.haps} haplotypes x "
+                  f"{short(args.loci)} isoforms per GPU)",
         "value": value, "unit": "iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "path": path, "rccl_ranks": world if ((world > 1 or args.rccl_selftest) and args.backend == "nccl") else 0,
         "backend": args.backend if world > 1 else None,
         "config": {"workload": ("" if args.variant == "survey" else f"[{args.variant} reads, not the headline] ") +
-                               f"configs[1]: single DO sample, R={args.rows} reads x H={args.haps} x "
+                               f"{cfg_name}, R={args.rows} reads x H={args.haps} x "
                                f"L={args.loci} isoforms, N={em['N']} alignment entries, quantify Model 4, "
-                               f"tol=0 fixed iterations" + (", rows sharded one 40M-read shard per GPU + "
-                               "RCCL all-reduce of the H*L vector per iteration" if world > 1 else "")
+                               f"tol=0 fixed iterations" + (f", rows sharded: one {short(args.rows)}-read shard of a "
+                               f"{short(args.rows * world)}-read pool per GPU + {'RCCL' if args.backend == 'nccl' else args.backend} "
+                               "all-reduce of the H*L vector per iteration" if world > 1 else "")
                                + (f"; loci cut at gene boundary {em['l_split']} into two engines per GPU, the "
                                   "all-reduce of one range overlapped with the E-step of the other"
                                   if "l_split" in em else ""),
@@ -729,16 +878,27 @@ def main():
         if key in pt and path == "single-engine":
             line["roofline"]["traffic"] = pt[key]["bytes_per_launch"]
             line["roofline"]["traffic_source"] = pt[key]["source"]
+            # traffic and the counter-derived fields below come from the committed rocprofv3 --pmc passes of this same
+            # command (a counter run cannot share a process with the timed region), not from this run
+            line["roofline"]["measured_in_run"] = {"achieved": True, "kernel_ms": True, "traffic": False, "pmc_fields": False}
             for k in ("valu_insts_per_launch", "valu_util", "shader_clock_mhz", "lds_bank_conflict_cycles",
                       "lds_idx_active_cycles", "lds_util", "valu_insts_per_word", "pmc_round"):
                 if k in pt[key]:
                     line["roofline"][k] = pt[key][k]
     except (OSError, ValueError):
         pass
+    if world > 1:
+        # the rest of BASELINE.json's metric at N > 1 (every rank takes part: the timings are max-over-ranks)
+        if not args.no_replicas and not args.merge:
+            line["replicas"] = replica_bench(args, rank, world, torch, dist)
+        if not args.no_hmm:
+            line["hmm"] = hmm_bench_ranks(args, rank, world, torch, dist)
     if rank == 0:
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = em_cpu_baseline(args, em.pop("host", None))
-            line["speedup_vs_cpu"] = (value / world) / line["cpu_baseline"]["value"]
+            line["speedup_vs_cpu"] = value / line["cpu_baseline"]["value"]
+        elif world > 1:
+            line["cpu_baseline"] = None        # rank 0 at N = 1 only (the driver's N = 1 run carries it)
         if not args.merge and not args.no_merged_line and world == 1:
             import copy
             a2 = copy.copy(args)
