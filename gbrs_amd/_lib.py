@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgbrs_hip.so")
+# GBRS_TUNING_LIB: a variant build of the same library (scripts/build_variant.sh), for A/B runs of kernel experiments
+LIB_PATH = os.environ.get("GBRS_TUNING_LIB") or os.path.join(_HERE, "libgbrs_hip.so")
 
 # names every build must export (checked by tests/test_abi.py against include/gbrs_hip.h)
 EXPORTS = [

@@ -480,6 +480,7 @@ struct gbrs_em {
     uint32_t flags = 0;
 
     int layout = 0;               // 0 = csc-direct, 1 = packed row tiles
+    uint32_t persist_groups = 0;  // > 0: the E-step of a step runs on this many persistent workgroups (em_tiles.inc)
     bool acc_needs_extra = false; // last E-step left the long-row sums in tl.acc_extra for the M-step to add
     bool acc_external = false;    // the caller all-reduces acc (sharded): always materialise all of it
     TileLayout tl;
@@ -573,7 +574,20 @@ int em_estep_tiles_h(gbrs_em *em) {
         hipLaunchKernelGGL((tile_estep_kernel<HT, W, ONES, D>), grid, block, 0, em->stream, em->H, tl.tiles.p, tl.words.p, \
                            tl.dict.p, ww, em->theta.p, tl.partials.p, tl.slot_dest.p, em->acc.p, em->scalars.p,       \
                            (uint32_t)tl.n_tiles, ea, sets)
-        if (tl.deterministic) {           // fixed-order sums instead of LDS float atomics (GBRS_EM_DETERMINISTIC)
+        if (!ONES && !tl.deterministic && em->persist_groups > 0 && HT > 0 && HT <= 8) {
+            // persistent workgroups (em_tiles.inc): as many as the chip holds at once, each walking several tiles with the
+            // next tile's header, dictionary and theta fetched under the current tile's batch loop
+            const uint32_t G = std::min<uint32_t>(em->persist_groups, (uint32_t)tl.n_tiles);
+            const dim3 pgrid(G + ea.n_err_blocks);
+#define GBRS_LAUNCH_PERSISTENT(HH, W, OW)                                                                              \
+            hipLaunchKernelGGL((tile_estep_persistent_kernel<HH, W, OW>), pgrid, block, 0, em->stream, em->H, tl.tiles.p,  \
+                               tl.words.p, tl.dict.p, ww, em->theta.p, tl.partials.p, tl.slot_dest.p,                  \
+                               (int64_t)(em->acc.p - tl.partials.p), em->scalars.p, (uint32_t)tl.n_tiles, G, ea, sets)
+            if (HT == 8 && !tl.weighted && tl.all_one_word) GBRS_LAUNCH_PERSISTENT(HT == 8 ? 8 : 1, false, HT == 8);
+            else if (tl.weighted) GBRS_LAUNCH_PERSISTENT(HT, true, false);
+            else GBRS_LAUNCH_PERSISTENT(HT, false, false);
+#undef GBRS_LAUNCH_PERSISTENT
+        } else if (tl.deterministic) {           // fixed-order sums instead of LDS float atomics (GBRS_EM_DETERMINISTIC)
             if (tl.weighted) GBRS_LAUNCH_TILES(true, true); else GBRS_LAUNCH_TILES(false, true);
 #if !defined(GBRS_NO_ONEWORD)
         } else if (HT == 8 && !tl.weighted && tl.all_one_word) {
@@ -1161,6 +1175,20 @@ int em_create_impl(uint64_t R, uint32_t L, uint32_t H, const uint32_t *const *in
                                    (flags & GBRS_EM_NO_LOCUS_SETS) == 0 && !count &&
                                        !(flags & GBRS_EM_MERGE_IDENTICAL_ROWS)));     // (weighted rows: their tiles are dictionary-bound)
         em->layout = 1;
+        {
+            // persistent E-step workgroups: one per place the chip has for them (tile_estep_kernel's launch bounds: 3 per CU
+            // for unweighted rows of <= 8 haplotypes, else 2), shared between handles that run side by side
+            // GBRS_TUNING_PERSISTENT=1 switches them on: built, parity-green and measured in round 4 - 8-10 % SLOWER than one
+            // workgroup per tile on the C2 sample (profiles/r04_estep_experiments.txt), so off by default
+            const char *env = std::getenv("GBRS_TUNING_PERSISTENT");
+            int n_cu = 0;
+            GBRS_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device));
+            const unsigned per_cu = (em->tl.weighted || H > 8) ? 2u : 3u;
+            const unsigned share = (flags & GBRS_EM_SIDE_BY_SIDE) ? 2u : 1u;
+            unsigned groups = per_cu * (unsigned)std::max(n_cu, 1) / share;
+            if (const char *g = std::getenv("GBRS_TUNING_PERSISTENT_GROUPS"); g && std::atoi(g) > 0) groups = (unsigned)std::atoi(g);
+            em->persist_groups = (env && std::atoi(env) != 0) ? std::max(groups, 1u) : 0u;
+        }
         stg.mark("build_tile_layout");
         // the CSC copy and the per-row denominators are only needed by layout 0 (and, until
         // gbrs_em_set_initial_values has run, when the caller announced stored values)

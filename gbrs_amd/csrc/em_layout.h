@@ -150,7 +150,7 @@ int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L, uint32_t H, uint6
                       const uint32_t *ent_row, const uint64_t *col_ptr, const double *count,
                       bool merge_identical_rows, int row_order /* 0 sorted, 1 interleaved, 2 streams */,
                       bool deterministic, hipStream_t stream, unsigned side_by_side = 1 /* handles sharing the device */,
-                      bool locus_sets = false);
+                      bool locus_sets = false, uint32_t dict_cap = 0 /* > 0: at most this many loci per tile dictionary */);
 
 // `gbrs compress`: equivalence classes of identical rows, in first-seen order.
 struct CompressResult {

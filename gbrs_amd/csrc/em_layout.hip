@@ -998,7 +998,8 @@ int compress_device(CompressResult &out, uint64_t R, uint32_t L, uint32_t H, uin
 
 int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L_in, uint32_t H, uint64_t N,
                       const uint32_t *ent_row, const uint64_t *col_ptr, const double *count,
-                      bool merge, int row_order, bool deterministic, hipStream_t s, unsigned side_by_side, bool locus_sets) {
+                      bool merge, int row_order, bool deterministic, hipStream_t s, unsigned side_by_side, bool locus_sets,
+                      uint32_t dict_cap) {
     uint32_t L = L_in;                     // grows by the number of locus sets in step 3b
     out.n_sets = 0;
     out.n_dest_rows = 0;
@@ -1023,6 +1024,9 @@ int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L_in, uint32_t H, ui
     out.d_max = std::min<uint32_t>(1024, lds_theta_doubles(merge || count != nullptr) / H);
     out.deterministic = deterministic;
     if (deterministic) out.d_max = std::min<uint32_t>(out.d_max, det_dict_cap(H, merge || count != nullptr));
+    if (dict_cap) out.d_max = std::min<uint32_t>(out.d_max, std::max<uint32_t>(dict_cap, (uint32_t)max_row_words(H) + 1));
+    if (const char *env = std::getenv("GBRS_TUNING_DICT_CAP"); env && std::atoi(env) > max_row_words(H))
+        out.d_max = std::min<uint32_t>(out.d_max, (uint32_t)std::atoi(env));
     if (out.d_max <= (uint32_t)max_row_words(H))
         return fail(GBRS_ERR_UNSUPPORTED, "the deterministic tile layout has no room for a row's loci at H = %u", H);
     const uint32_t dseg = out.d_max - max_row_words(H);

@@ -21,15 +21,31 @@ LAYOUTS = {"tiles": dict(), "tiles_merged": dict(merge_identical_rows=True), "cs
            "tiles_no_locus_sets": dict(extra_flags=512),
            # the layout the headline number runs on: the build's own rule (>= 100 words per id) declines the sets on
            # inputs of this size, GBRS_TUNING_LOCUS_SETS=1 forces them (see the fixture below)
-           "tiles_locus_sets_forced": dict()}
+           "tiles_locus_sets_forced": dict(),
+           # round 4: the E-step on persistent workgroups (GBRS_TUNING_PERSISTENT=1; built, measured, not the default).  A golden
+           # has a handful of tiles, so every workgroup would get one (the path with nothing to prefetch); 128-word tiles on
+           # two (three) workgroups make each walk many tiles, with the next tile's dictionary and theta fetched under the
+           # batch loop - plain loci, and locus sets
+           "tiles_persistent_walk": dict(),
+           "tiles_persistent_walk_sets": dict(),
+           "tiles_persistent_walk_merged": dict(merge_identical_rows=True),
+           "tiles_persistent_one_tile_each": dict()}
+LAYOUT_ENV = {"tiles_locus_sets_forced": {"GBRS_TUNING_LOCUS_SETS": "1"},
+              "tiles_persistent_walk": {"GBRS_TUNING_PERSISTENT": "1", "GBRS_TUNING_PERSISTENT_GROUPS": "2", "GBRS_TUNING_TILE_WORDS": "128"},
+              "tiles_persistent_walk_sets": {"GBRS_TUNING_PERSISTENT": "1", "GBRS_TUNING_PERSISTENT_GROUPS": "3",
+                                             "GBRS_TUNING_TILE_WORDS": "128", "GBRS_TUNING_LOCUS_SETS": "1"},
+              "tiles_persistent_walk_merged": {"GBRS_TUNING_PERSISTENT": "1", "GBRS_TUNING_PERSISTENT_GROUPS": "2",
+                                               "GBRS_TUNING_TILE_WORDS": "64"},
+              "tiles_persistent_one_tile_each": {"GBRS_TUNING_PERSISTENT": "1"}}
 
 
 @pytest.fixture(autouse=True)
-def _forced_locus_sets(request, monkeypatch):
-    """Layout "tiles_locus_sets_forced": every unweighted tile layout built inside the test takes the locus sets."""
+def _layout_environment(request, monkeypatch):
+    """Tuning switches a layout name stands for (read by the library when a handle is created)."""
     cs = getattr(request.node, "callspec", None)
-    if cs is not None and cs.params.get("layout") == "tiles_locus_sets_forced":
-        monkeypatch.setenv("GBRS_TUNING_LOCUS_SETS", "1")
+    if cs is not None:
+        for k, v in LAYOUT_ENV.get(cs.params.get("layout"), {}).items():
+            monkeypatch.setenv(k, v)
     yield
 
 
@@ -89,7 +105,11 @@ def test_em_matches_reference_golden(path, layout):
     expect_layout = 0 if (layout == "csc" or int(g["num_haps"]) > 16) else 1
     em.prepare(pseudocount=pc)
     assert em.info().layout == expect_layout
-    if layout == "tiles_locus_sets_forced" and expect_layout == 1 and not bool(g["has_count"]):
+    if layout.startswith("tiles_persistent_walk") and expect_layout == 1:
+        # every workgroup really walks several tiles (the one-haplotype golden's rows merge into a single tile)
+        if int(g["num_haps"]) > 1:
+            assert em.info().num_tiles >= (2 if "merged" in layout else 4), em.info().num_tiles
+    if layout in ("tiles_locus_sets_forced", "tiles_persistent_walk_sets") and expect_layout == 1 and not bool(g["has_count"]):
         # unweighted rows (the build never takes sets for weighted ones): the sets must really be there whenever some
         # read aligns to several loci under one mask
         multi = _rows_with_one_mask_over_several_loci(g)
