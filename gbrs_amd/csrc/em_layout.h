@@ -28,8 +28,10 @@ namespace gbrs {
 constexpr int TILE_THREADS = GBRS_TILE_THREADS;   // 8 waves per workgroup
 constexpr int TILE_WAVES = TILE_THREADS / 64;
 #ifndef GBRS_TILE_CAP
-#define GBRS_TILE_CAP 16384                    // capacity of the per-tile dictionary sort (words incl. padding)
-#endif
+#define GBRS_TILE_CAP 32768                    // most words (incl. padding) a tile may hold.  Round 4: the dictionaries come from one
+#endif                                         // global sort (the per-tile LDS sort of rounds 1-3 held 16,384), so the cap is a choice:
+                                               // C2, same box: 16,320 words 0.0751-0.0753 ms, 20,800: 0.0745-0.0747, 26,048: 0.0730-0.0735,
+                                               // 32,704: 0.0729-0.0742, 52,096 (one round): 0.0749-0.0750, 65,472: 0.0747-0.0749
 // Unpadded words per tile.  Larger tiles spread the tile prologue / epilogue (dictionary, theta gather, flush of the
 // sums) over more words, but a launch needs several rounds of tiles on the chip's resident workgroups to hide
 // its tail.  Measured on the C2 sample (52.4 M words; profiles/r02_estep_experiments.txt items 10, 12, 13): in locus

@@ -457,74 +457,40 @@ __global__ void tile_pad_kernel(uint64_t n_tiles, int streams, const uint32_t *_
     nbatch[t] = (off + 63u) >> 6;
 }
 
-// one workgroup per tile: sorted unique loci of the tile -> tmpdict[t * dcap ...], dcount[t]
-constexpr int SORT_CAP = GBRS_TILE_CAP;
-__global__ void __launch_bounds__(512)
-tile_dict_kernel(uint32_t dcap, const uint32_t *__restrict__ tile_row, const uint32_t *__restrict__ hrow,
-                 const uint32_t *__restrict__ rowstart, const uint32_t *__restrict__ ploc,
-                 const uint32_t *__restrict__ wordoff, uint32_t *__restrict__ tmpdict,
-                 uint32_t *__restrict__ dcount, BuildFlags *flags) {
-    __shared__ uint32_t a[SORT_CAP];
-    const uint32_t t = blockIdx.x;
-    const uint32_t m0 = tile_row[t], m1 = tile_row[t + 1];
-    const uint32_t w0 = wordoff[m0];
-    for (int i = threadIdx.x; i < SORT_CAP; i += blockDim.x) a[i] = 0xFFFFFFFFu;
-    __syncthreads();
-    for (uint32_t m = m0 + threadIdx.x; m < m1; m += blockDim.x) {
-        const uint32_t r = hrow[m], p0 = rowstart[r], cnt = rowstart[r + 1] - p0;
-        const uint32_t o = wordoff[m] - w0;
-        for (uint32_t j = 0; j < cnt; ++j)
-            if (o + j < SORT_CAP) a[o + j] = ploc[p0 + j]; else flags->dict_overflow = 1;
-    }
-    __syncthreads();
-    // bitonic sort of SORT_CAP keys in LDS
-    for (int k = 2; k <= SORT_CAP; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = threadIdx.x; i < SORT_CAP; i += blockDim.x) {
-                const int ixj = i ^ j;
-                if (ixj > i) {
-                    const uint32_t x = a[i], y = a[ixj];
-                    const bool up = (i & k) == 0;
-                    if ((x > y) == up) { a[i] = y; a[ixj] = x; }
-                }
-            }
-            __syncthreads();
-        }
-    }
-    // unique (order preserved by giving each thread a contiguous chunk)
-    const int per = SORT_CAP / 512;
-    const int lo = threadIdx.x * per;
-    int mine = 0;
-    for (int i = lo; i < lo + per; ++i)
-        mine += (a[i] != 0xFFFFFFFFu) && (i == 0 || a[i] != a[i - 1]);
-    __shared__ uint32_t s_scan[512];
-    s_scan[threadIdx.x] = mine;
-    __syncthreads();
-    for (int off = 1; off < 512; off <<= 1) {
-        uint32_t v = threadIdx.x >= off ? s_scan[threadIdx.x - off] : 0;
-        __syncthreads();
-        s_scan[threadIdx.x] += v;
-        __syncthreads();
-    }
-    uint32_t pos = s_scan[threadIdx.x] - mine;
-    for (int i = lo; i < lo + per; ++i) {
-        if ((a[i] != 0xFFFFFFFFu) && (i == 0 || a[i] != a[i - 1])) {
-            if (pos < dcap) tmpdict[(uint64_t)t * dcap + pos] = a[i]; else flags->dict_overflow = 1;
-            ++pos;
-        }
-    }
-    if (threadIdx.x == 511) dcount[t] = s_scan[511];
+// Per-tile dictionaries = the distinct loci (and locus sets) of a tile's rows, ascending.  Built from ONE radix sort of
+// (tile, id) keys over all the pairs of the layout (round 4; before: a bitonic sort per tile in LDS, which capped a tile at
+// 16,384 words - and the E-step likes its tiles as large as one round of the chip's workgroups allows).
+__global__ void tile_pair_keys_kernel(uint64_t m_rows, const uint32_t *__restrict__ tincl, const uint32_t *__restrict__ hrow,
+                                      const uint32_t *__restrict__ rowstart, const uint32_t *__restrict__ ploc,
+                                      const uint32_t *__restrict__ wordoff, uint64_t *__restrict__ keys) {
+    const uint64_t m = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m >= m_rows) return;
+    const uint64_t t = tincl[m] - 1;
+    const uint32_t r = hrow[m], p0 = rowstart[r], cnt = rowstart[r + 1] - p0, o = wordoff[m];
+    for (uint32_t j = 0; j < cnt; ++j) keys[o + j] = (t << 32) | ploc[p0 + j];
 }
 
-__global__ void tile_hdr_kernel(uint64_t n_tiles, uint32_t dcap, const uint32_t *__restrict__ batch_base,
+__global__ void dict_flag_kernel(uint64_t n, const uint64_t *__restrict__ skeys, uint32_t *__restrict__ flag) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) flag[i] = (i == 0 || skeys[i] != skeys[i - 1]) ? 1u : 0u;
+}
+
+__global__ void dict_emit_kernel(uint64_t n, const uint64_t *__restrict__ skeys, const uint32_t *__restrict__ flag,
+                                 const uint32_t *__restrict__ pos, uint32_t *__restrict__ dict, uint32_t *__restrict__ dict_base) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !flag[i]) return;
+    dict[pos[i]] = (uint32_t)skeys[i];
+    if (i == 0 || (skeys[i] >> 32) != (skeys[i - 1] >> 32)) dict_base[skeys[i] >> 32] = pos[i];
+}
+
+__global__ void tile_hdr_kernel(uint64_t n_tiles, uint32_t dcap, uint32_t n_slots, const uint32_t *__restrict__ batch_base,
                                 const uint32_t *__restrict__ nbatch, const uint32_t *__restrict__ dict_base,
-                                const uint32_t *__restrict__ dcount, const uint32_t *__restrict__ tmpdict,
-                                TileHdr *__restrict__ hdr, uint32_t *__restrict__ dict) {
-    const uint32_t t = blockIdx.x;
+                                TileHdr *__restrict__ hdr, BuildFlags *flags) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_tiles) return;
-    const uint32_t d = dcount[t], db = dict_base[t];
-    if (threadIdx.x == 0) hdr[t] = TileHdr{batch_base[t], nbatch[t], db, d};
-    for (uint32_t j = threadIdx.x; j < d; j += blockDim.x) dict[db + j] = tmpdict[(uint64_t)t * dcap + j];
+    const uint32_t db = dict_base[t], d = (t + 1 < n_tiles ? dict_base[t + 1] : n_slots) - db;
+    if (d > dcap) flags->dict_overflow = 1;
+    hdr[t] = TileHdr{batch_base[t], nbatch[t], db, d};
 }
 
 // one thread per (merged) row: emit its words at the padded position
@@ -1254,7 +1220,9 @@ int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L_in, uint32_t H, ui
         // (handles that run side by side - the locus ranges of one sample, GBRS_EM_SIDE_BY_SIDE - fill the rounds together)
         const unsigned per_cu = (out.weighted || H > 8) ? 2u : 3u;      // resident E-step workgroups per CU (tile_estep_kernel's launch bounds)
         const uint64_t fit = (uint64_t)total_words * side_by_side / ((uint64_t)TILE_ROUNDS_MIN * per_cu * (uint64_t)std::max(n_cu, 1));
-        tile_words = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(fit, TILE_WORDS), TILE_WORDS_MAX) & ~63u;
+        // (weighted rows - merged reads, EC counts - stay at 16,320: the merged C2 sample reads 0.0345 ms there, 0.0357 at 20,900)
+        const uint64_t cap = out.weighted ? std::min<uint64_t>(TILE_WORDS_MAX, 16320) : (uint64_t)TILE_WORDS_MAX;
+        tile_words = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(fit, TILE_WORDS), cap) & ~63u;
         if (const char *env = std::getenv("GBRS_TUNING_TILE_WORDS"); env && std::atoi(env) >= 64)
             tile_words = (uint32_t)std::min(std::atoi(env), GBRS_TILE_CAP - 64);
     }
@@ -1327,22 +1295,33 @@ int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L_in, uint32_t H, ui
     GBRS_TRY(fetch_last_plus(batch_base.p, nbatch.p, T, NB, s));
     out.n_batches = NB;
     stg.mark("8 padding");
-    // 9. per-tile dictionaries
+    // 9. per-tile dictionaries: one sort of (tile, id) keys over all the pairs (see tile_pair_keys_kernel)
     const uint32_t dcap = out.d_max;
-    DevBuf<uint32_t> tmpdict, dcount, dict_base;
-    GBRS_TRY(tmpdict.alloc((size_t)T * dcap)); GBRS_TRY(dcount.alloc(T)); GBRS_TRY(dict_base.alloc(T));
-    hipLaunchKernelGGL(tile_dict_kernel, dim3((unsigned)T), dim3(512), 0, s, dcap, tile_row.p, hrow.p, rowstart.p, ploc.p,
-                       wordoff.p, tmpdict.p, dcount.p, d_flags.p);
-    GBRS_TRY(exclusive_scan(sc, dcount.p, dict_base.p, T, s));
     uint32_t NS = 0;
-    GBRS_TRY(fetch_last_plus(dict_base.p, dcount.p, T, NS, s));
-    GBRS_TRY(read_flags());
-    if (hf.dict_overflow) return fail(GBRS_ERR_INVALID, "internal error: a tile dictionary overflowed its capacity");
-    out.n_slots = NS;
-    GBRS_TRY(out.tiles.alloc(T));
-    GBRS_TRY(out.dict.alloc(std::max<uint32_t>(NS, 1)));
-    hipLaunchKernelGGL(tile_hdr_kernel, dim3((unsigned)T), dim3(64), 0, s, T, dcap, batch_base.p, nbatch.p, dict_base.p,
-                       dcount.p, tmpdict.p, out.tiles.p, out.dict.p);
+    DevBuf<uint32_t> dict_base;
+    GBRS_TRY(dict_base.alloc(T));
+    {
+        uint32_t W = 0;
+        GBRS_TRY(fetch_last_plus(wordoff.p, npm.p, M, W, s));
+        DevBuf<uint64_t> dkey, dkey2;
+        DevBuf<uint32_t> dflag, dpos;
+        GBRS_TRY(dkey.alloc(W)); GBRS_TRY(dkey2.alloc(W)); GBRS_TRY(dflag.alloc(W)); GBRS_TRY(dpos.alloc(W));
+        hipLaunchKernelGGL(tile_pair_keys_kernel, dim3(grid_for(M)), dim3(256), 0, s, M, tincl.p, hrow.p, rowstart.p, ploc.p,
+                           wordoff.p, dkey.p);
+        GBRS_TRY(sort_keys64(sc, dkey.p, dkey2.p, W, 32 + bits_for(T), s));
+        hipLaunchKernelGGL(dict_flag_kernel, dim3(grid_for(W)), dim3(256), 0, s, (uint64_t)W, dkey2.p, dflag.p);
+        GBRS_TRY(exclusive_scan(sc, dflag.p, dpos.p, W, s));
+        GBRS_TRY(fetch_last_plus(dpos.p, dflag.p, W, NS, s));
+        out.n_slots = NS;
+        GBRS_TRY(out.tiles.alloc(T));
+        GBRS_TRY(out.dict.alloc(std::max<uint32_t>(NS, 1)));
+        hipLaunchKernelGGL(dict_emit_kernel, dim3(grid_for(W)), dim3(256), 0, s, (uint64_t)W, dkey2.p, dflag.p, dpos.p, out.dict.p,
+                           dict_base.p);
+        hipLaunchKernelGGL(tile_hdr_kernel, dim3(grid_for(T)), dim3(256), 0, s, T, dcap, NS, batch_base.p, nbatch.p, dict_base.p,
+                           out.tiles.p, d_flags.p);
+        GBRS_TRY(read_flags());
+        if (hf.dict_overflow) return fail(GBRS_ERR_INVALID, "internal error: a tile dictionary overflowed its capacity");
+    }
     stg.mark("9 dictionaries");
     // 10. words
     GBRS_TRY(out.words.alloc((size_t)NB * 64));
@@ -1356,7 +1335,7 @@ int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L_in, uint32_t H, ui
                        out.weighted ? out.row_weight.p : (const double *)nullptr,
                        out.weighted ? out.word_weight.p : (double *)nullptr);
     GBRS_HIP_CHECK(hipStreamSynchronize(s));
-    tmpdict.release(); dcount.release(); dict_base.release(); batch_base.release(); nbatch.release();
+    dict_base.release(); batch_base.release(); nbatch.release();
     rowpad.release(); tincl.release(); npm.release(); wordoff.release(); tile_row.release();
     hrow.release(); rowstart.release(); ploc.release(); pmask.release();
     out.row_weight.release();
