@@ -276,6 +276,177 @@ __global__ void set_rewrite_kernel(uint64_t nrows, uint32_t L, const uint32_t *_
     }
 }
 
+// ---- locus sets per mask group (round 4) ----------------------------------------------------------------------------
+// A read that aligns to several isoforms of a gene with DIFFERENT haplotype masks is no whole-row set, but the loci of the row
+// that share a mask are one: den = sum over the groups g of sum_h m_g,h * (theta[l1,h] + theta[l2,h] + ...), and every locus of a
+// group receives the same count/den.  Rows are regrouped by (mask, locus); every group of >= 2 loci is a candidate, and a
+// candidate becomes a set only when at least `min_rows` rows carry it: thin sets fill the tiles' dictionaries for nothing
+// (profiles/r03_estep_experiments.txt item 16: 216 k sets, most of them carried by a handful of reads, made the
+// multi-isoform sample 1.8x slower; the frequent ones are where the reads are).
+constexpr uint32_t GROUP_ROW_MAX = 32;
+
+// per row: pairs sorted by (mask, locus) into gloc / gmask (same offsets); nseg[r] = number of mask groups
+__global__ void group_sort_kernel(uint64_t nrows, const uint32_t *__restrict__ rowstart, const uint32_t *__restrict__ ploc,
+                                  const uint32_t *__restrict__ pmask, uint32_t *__restrict__ gloc, uint32_t *__restrict__ gmask,
+                                  uint32_t *__restrict__ nseg) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrows) return;
+    const uint32_t b = rowstart[r], n = rowstart[r + 1] - b;
+    if (n > GROUP_ROW_MAX) {                     // long rows stay as they are: every pair a group of its own
+        for (uint32_t k = 0; k < n; ++k) { gloc[b + k] = ploc[b + k]; gmask[b + k] = pmask[b + k]; }
+        nseg[r] = n;
+        return;
+    }
+    uint64_t v[GROUP_ROW_MAX];
+    for (uint32_t k = 0; k < n; ++k) v[k] = ((uint64_t)pmask[b + k] << 32) | ploc[b + k];
+    for (uint32_t i = 1; i < n; ++i) {           // insertion sort (the loci arrive ascending: only the masks reorder)
+        const uint64_t x = v[i];
+        uint32_t j = i;
+        while (j > 0 && v[j - 1] > x) { v[j] = v[j - 1]; --j; }
+        v[j] = x;
+    }
+    uint32_t ns = 0;
+    for (uint32_t k = 0; k < n; ++k) {
+        gloc[b + k] = (uint32_t)v[k];
+        gmask[b + k] = (uint32_t)(v[k] >> 32);
+        ns += (k == 0 || (v[k] >> 32) != (v[k - 1] >> 32)) ? 1u : 0u;
+    }
+    nseg[r] = ns;
+}
+
+// per row: its groups as segments [seg_begin, seg_begin + seg_len) of gloc; a group of >= 2 loci is a candidate with the hash
+// of its locus list as key
+__global__ void group_segments_kernel(uint64_t nrows, const uint32_t *__restrict__ rowstart, const uint32_t *__restrict__ gloc,
+                                      const uint32_t *__restrict__ gmask, const uint32_t *__restrict__ segoff,
+                                      uint32_t *__restrict__ seg_begin, uint32_t *__restrict__ seg_len, uint64_t *__restrict__ key,
+                                      uint32_t *__restrict__ cand) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrows) return;
+    const uint32_t b = rowstart[r], e = rowstart[r + 1];
+    uint32_t s = segoff[r];
+    const bool plain = e - b > GROUP_ROW_MAX;
+    uint32_t k = b;
+    while (k < e) {
+        uint32_t k2 = k + 1;
+        uint64_t h = 0;
+        if (!plain) {
+            h = mix64(0x51ed270b1ull, gloc[k]);
+            while (k2 < e && gmask[k2] == gmask[k]) { h = mix64(h, gloc[k2]); ++k2; }
+        }
+        seg_begin[s] = k;
+        seg_len[s] = k2 - k;
+        key[s] = mix64(h, k2 - k);
+        cand[s] = k2 - k >= 2 ? 1u : 0u;
+        ++s;
+        k = k2;
+    }
+}
+
+__global__ void group_compact_kernel(uint64_t nseg, const uint32_t *__restrict__ cand, const uint32_t *__restrict__ cidx,
+                                     const uint64_t *__restrict__ key, uint64_t *__restrict__ ckey, uint32_t *__restrict__ cseg) {
+    const uint64_t s = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nseg || !cand[s]) return;
+    ckey[cidx[s]] = key[s];
+    cseg[cidx[s]] = (uint32_t)s;
+}
+
+// candidates sorted by hash: head[i] = 1 when candidate i's locus list differs from its predecessor's (exact comparison)
+__global__ void group_head_kernel(uint64_t nc, const uint64_t *__restrict__ skey, const uint32_t *__restrict__ sseg,
+                                  const uint32_t *__restrict__ seg_begin, const uint32_t *__restrict__ seg_len,
+                                  const uint32_t *__restrict__ gloc, uint32_t *__restrict__ head) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nc) return;
+    bool same = i > 0 && skey[i] == skey[i - 1];
+    if (same) {
+        const uint32_t a = sseg[i], b = sseg[i - 1];
+        const uint32_t a0 = seg_begin[a], b0 = seg_begin[b], n = seg_len[a];
+        same = n == seg_len[b];
+        for (uint32_t k = 0; same && k < n; ++k) same = gloc[a0 + k] == gloc[b0 + k];
+    }
+    head[i] = same ? 0u : 1u;
+}
+
+// rows per provisional set, and its first candidate (sorted order) as representative
+__global__ void group_count_kernel(uint64_t nc, const uint32_t *__restrict__ head, const uint32_t *__restrict__ hincl,
+                                   const uint32_t *__restrict__ sseg, uint32_t *__restrict__ count, uint32_t *__restrict__ rep) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nc) return;
+    const uint32_t k = hincl[i] - 1;
+    atomicAdd(&count[k], 1u);
+    if (head[i]) rep[k] = sseg[i];
+}
+
+__global__ void group_keep_kernel(uint32_t nprov, uint32_t min_rows, const uint32_t *__restrict__ count, uint32_t *__restrict__ keep) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < nprov) keep[k] = count[k] >= min_rows ? 1u : 0u;
+}
+
+// set_of_seg for the candidates of kept sets; length and representative segment of every kept set
+__global__ void group_assign_kernel(uint64_t nc, const uint32_t *__restrict__ hincl, const uint32_t *__restrict__ sseg,
+                                    const uint32_t *__restrict__ keep, const uint32_t *__restrict__ newid,
+                                    const uint32_t *__restrict__ rep, const uint32_t *__restrict__ seg_len,
+                                    uint32_t *__restrict__ set_of_seg, uint32_t *__restrict__ set_len, uint32_t *__restrict__ set_rep) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nc) return;
+    const uint32_t k = hincl[i] - 1;
+    if (!keep[k]) return;
+    const uint32_t id = newid[k];
+    set_of_seg[sseg[i]] = id;
+    if (rep[k] == sseg[i]) {
+        set_len[id] = seg_len[sseg[i]];
+        set_rep[id] = sseg[i];
+    }
+}
+
+__global__ void group_members_kernel(uint32_t n_sets, const uint32_t *__restrict__ set_ptr, const uint32_t *__restrict__ set_rep,
+                                     const uint32_t *__restrict__ seg_begin, const uint32_t *__restrict__ gloc,
+                                     uint32_t *__restrict__ members) {
+    const uint32_t k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n_sets) return;
+    const uint32_t b = seg_begin[set_rep[k]], o = set_ptr[k], n = set_ptr[k + 1] - o;
+    for (uint32_t j = 0; j < n; ++j) members[o + j] = gloc[b + j];       // ascending: a group is sorted by locus
+}
+
+__global__ void group_row_len_kernel(uint64_t nrows, const uint32_t *__restrict__ segoff, const uint32_t *__restrict__ seg_len,
+                                     const uint32_t *__restrict__ set_of_seg, uint32_t *__restrict__ newlen) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrows) return;
+    uint32_t n = 0;
+    for (uint32_t s = segoff[r]; s < segoff[r + 1]; ++s) n += set_of_seg[s] != NO_SET ? 1u : seg_len[s];
+    newlen[r] = n;
+}
+
+// the rows in their new form: a kept group becomes one pair on its set's id, the others keep their pairs; ids ascending
+__global__ void group_rewrite_kernel(uint64_t nrows, uint32_t L, const uint32_t *__restrict__ segoff,
+                                     const uint32_t *__restrict__ seg_begin, const uint32_t *__restrict__ seg_len,
+                                     const uint32_t *__restrict__ set_of_seg, const uint32_t *__restrict__ newstart,
+                                     const uint32_t *__restrict__ gloc, const uint32_t *__restrict__ gmask,
+                                     uint32_t *__restrict__ ploc2, uint32_t *__restrict__ pmask2) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= nrows) return;
+    const uint32_t o = newstart[r], n = newstart[r + 1] - o;
+    uint32_t w = o;
+    for (uint32_t s = segoff[r]; s < segoff[r + 1]; ++s) {
+        const uint32_t b = seg_begin[s], k = set_of_seg[s];
+        if (k != NO_SET) {
+            ploc2[w] = L + k;
+            pmask2[w] = gmask[b];
+            ++w;
+        } else {
+            for (uint32_t j = 0; j < seg_len[s]; ++j) { ploc2[w] = gloc[b + j]; pmask2[w] = gmask[b + j]; ++w; }
+        }
+    }
+    if (n > GROUP_ROW_MAX) return;               // (a long row was copied in its own order)
+    for (uint32_t i = 1; i < n; ++i) {           // back to ascending ids, as every later step expects of a row
+        const uint32_t xl = ploc2[o + i], xm = pmask2[o + i];
+        uint32_t j = i;
+        while (j > 0 && ploc2[o + j - 1] > xl) { ploc2[o + j] = ploc2[o + j - 1]; pmask2[o + j] = pmask2[o + j - 1]; --j; }
+        ploc2[o + j] = xl;
+        pmask2[o + j] = xm;
+    }
+}
+
+
 __device__ __forceinline__ uint32_t mix32(uint32_t h, uint32_t v) {
     h ^= v + 0x9e3779b9u + (h << 6) + (h >> 2);
     h *= 0x85ebca6bu;
@@ -1062,8 +1233,12 @@ int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L_in, uint32_t H, ui
     GBRS_HIP_CHECK(hipStreamSynchronize(s));
     rflag.release(); ridx.release(); prow.release();
     stg.mark("3 rows");
-    // 3b. locus sets: a row whose pairs all carry one mask becomes one pair on the id of its locus set (em_layout.h)
-    if (locus_sets && R1 > 0) {
+    // 3b. locus sets, first form (round 3): a row whose pairs ALL carry one mask becomes one pair on the id of its locus set
+    // (em_layout.h), every distinct set kept.  Round 4's step 3c below finds the same sets (a whole row is a row with one mask
+    // group) and keeps the frequent ones only, which is what the samples want (C2: all 98,725 sets 0.0901 ms per iteration,
+    // the 17-42 k sets carried by >= 128 / 32 reads 0.0857); this form stays reachable with GBRS_TUNING_LOCUS_SETS=1.
+    const bool whole_row_sets_forced = [] { const char *e = std::getenv("GBRS_TUNING_LOCUS_SETS"); return e && std::atoi(e) == 1; }();
+    if (locus_sets && R1 > 0 && whole_row_sets_forced) {
         DevBuf<uint64_t> key, ckey, skey2;
         DevBuf<uint32_t> flag, cidx, crow, srow2;
         GBRS_TRY(key.alloc(R1)); GBRS_TRY(flag.alloc(R1)); GBRS_TRY(cidx.alloc(R1));
@@ -1137,6 +1312,105 @@ int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L_in, uint32_t H, ui
             }   // ids_fit
         }
         stg.mark("3b locus sets");
+    }
+    // 3c. locus sets per mask group, when the rows are no whole-row sets (reads over several isoforms with differing masks):
+    // the loci of a row that share a mask become one pair on a set id, for the sets that enough rows carry
+    if (locus_sets && R1 > 0 && out.n_sets == 0) {
+        const char *genv = std::getenv("GBRS_TUNING_GROUP_SETS");
+        const bool forced_on = genv && std::atoi(genv) == 1, forced_off = genv && std::atoi(genv) == 0;
+        // rows a set must be carried by.  Iteration time, one box each: multi-isoform sample (2.35 words per read, no sets 0.1970 ms):
+        // 64 rows (39 k sets) 0.199, 128 (21 k) 0.188, 160: 0.186, 192 (13.8 k) 0.184, 256 (10 k) 0.183, 384 / 512: 0.184;
+        // C2 (whole-row sets, all 98.7 k of them 0.0901 ms): 32 rows (42.5 k) 0.0858, 128 (17 k) 0.0857, 512 (4.3 k) 0.0881
+        uint32_t min_rows = 192;
+        if (const char *e = std::getenv("GBRS_TUNING_SET_MIN_ROWS"); e && std::atoi(e) > 0) min_rows = (uint32_t)std::atoi(e);
+        DevBuf<uint32_t> gloc, gmask, nseg, segoff;
+        if (!forced_off) {
+            GBRS_TRY(gloc.alloc(P)); GBRS_TRY(gmask.alloc(P)); GBRS_TRY(nseg.alloc(R1)); GBRS_TRY(segoff.alloc((size_t)R1 + 1));
+            hipLaunchKernelGGL(group_sort_kernel, dim3(grid_for(R1)), dim3(256), 0, s, (uint64_t)R1, rowstart.p, ploc.p, pmask.p,
+                               gloc.p, gmask.p, nseg.p);
+            GBRS_TRY(exclusive_scan(sc, nseg.p, segoff.p, R1, s));
+            uint32_t S = 0;
+            GBRS_TRY(fetch_last_plus(segoff.p, nseg.p, R1, S, s));
+            GBRS_HIP_CHECK(hipMemcpyAsync(segoff.p + R1, &S, 4, hipMemcpyHostToDevice, s));
+            DevBuf<uint32_t> seg_begin, seg_len, cand, cidx;
+            DevBuf<uint64_t> key;
+            GBRS_TRY(seg_begin.alloc(S)); GBRS_TRY(seg_len.alloc(S)); GBRS_TRY(cand.alloc(S)); GBRS_TRY(cidx.alloc(S));
+            GBRS_TRY(key.alloc(S));
+            hipLaunchKernelGGL(group_segments_kernel, dim3(grid_for(R1)), dim3(256), 0, s, (uint64_t)R1, rowstart.p, gloc.p, gmask.p,
+                               segoff.p, seg_begin.p, seg_len.p, key.p, cand.p);
+            GBRS_TRY(exclusive_scan(sc, cand.p, cidx.p, S, s));
+            uint32_t C = 0;
+            GBRS_TRY(fetch_last_plus(cidx.p, cand.p, S, C, s));
+            if (C > 0 && S < P) {
+                DevBuf<uint64_t> ckey, skey2;
+                DevBuf<uint32_t> cseg, sseg, head2, hincl2;
+                GBRS_TRY(ckey.alloc(C)); GBRS_TRY(skey2.alloc(C)); GBRS_TRY(cseg.alloc(C)); GBRS_TRY(sseg.alloc(C));
+                hipLaunchKernelGGL(group_compact_kernel, dim3(grid_for(S)), dim3(256), 0, s, (uint64_t)S, cand.p, cidx.p, key.p,
+                                   ckey.p, cseg.p);
+                GBRS_TRY(sort_pairs<uint64_t>(sc, ckey.p, skey2.p, cseg.p, sseg.p, C, 64, s));
+                key.release(); ckey.release(); cseg.release(); cand.release(); cidx.release();
+                GBRS_TRY(head2.alloc(C)); GBRS_TRY(hincl2.alloc(C));
+                hipLaunchKernelGGL(group_head_kernel, dim3(grid_for(C)), dim3(256), 0, s, (uint64_t)C, skey2.p, sseg.p, seg_begin.p,
+                                   seg_len.p, gloc.p, head2.p);
+                GBRS_TRY(inclusive_scan(sc, head2.p, hincl2.p, C, s));
+                uint32_t Vp = 0;
+                GBRS_HIP_CHECK(hipMemcpyAsync(&Vp, hincl2.p + C - 1, 4, hipMemcpyDeviceToHost, s));
+                GBRS_HIP_CHECK(hipStreamSynchronize(s));
+                DevBuf<uint32_t> cnt, rep, keep, newid;
+                GBRS_TRY(cnt.alloc(Vp)); GBRS_TRY(rep.alloc(Vp)); GBRS_TRY(keep.alloc(Vp)); GBRS_TRY(newid.alloc(Vp));
+                GBRS_HIP_CHECK(hipMemsetAsync(cnt.p, 0, cnt.bytes(), s));
+                hipLaunchKernelGGL(group_count_kernel, dim3(grid_for(C)), dim3(256), 0, s, (uint64_t)C, head2.p, hincl2.p, sseg.p,
+                                   cnt.p, rep.p);
+                // the frequent sets only, and no more of them than half the loci: the threshold doubles until they fit
+                uint32_t V = 0;
+                for (int round = 0; round < 24; ++round) {
+                    hipLaunchKernelGGL(group_keep_kernel, dim3(grid_for(Vp)), dim3(256), 0, s, Vp, min_rows, cnt.p, keep.p);
+                    GBRS_TRY(exclusive_scan(sc, keep.p, newid.p, Vp, s));
+                    GBRS_TRY(fetch_last_plus(newid.p, keep.p, Vp, V, s));
+                    if ((uint64_t)V * 2 <= (uint64_t)L_in || forced_on) break;
+                    min_rows *= 2;
+                }
+                if (V > 0 && (uint64_t)L_in + V < (1u << 27)) {
+                    DevBuf<uint32_t> set_of_seg, set_len, set_rep, newlen, rowstart2, ploc2, pmask2;
+                    GBRS_TRY(set_of_seg.alloc(S)); GBRS_TRY(set_len.alloc(V)); GBRS_TRY(set_rep.alloc(V));
+                    GBRS_HIP_CHECK(hipMemsetAsync(set_of_seg.p, 0xFF, set_of_seg.bytes(), s));
+                    hipLaunchKernelGGL(group_assign_kernel, dim3(grid_for(C)), dim3(256), 0, s, (uint64_t)C, hincl2.p, sseg.p, keep.p,
+                                       newid.p, rep.p, seg_len.p, set_of_seg.p, set_len.p, set_rep.p);
+                    GBRS_TRY(out.set_ptr.alloc((size_t)V + 1));
+                    GBRS_TRY(exclusive_scan(sc, set_len.p, out.set_ptr.p, V, s));
+                    uint32_t n_members = 0;
+                    GBRS_TRY(fetch_last_plus(out.set_ptr.p, set_len.p, V, n_members, s));
+                    GBRS_HIP_CHECK(hipMemcpyAsync(out.set_ptr.p + V, &n_members, 4, hipMemcpyHostToDevice, s));
+                    GBRS_TRY(out.set_members.alloc(n_members));
+                    hipLaunchKernelGGL(group_members_kernel, dim3(grid_for(V)), dim3(256), 0, s, V, out.set_ptr.p, set_rep.p,
+                                       seg_begin.p, gloc.p, out.set_members.p);
+                    GBRS_TRY(newlen.alloc(R1)); GBRS_TRY(rowstart2.alloc((size_t)R1 + 1));
+                    hipLaunchKernelGGL(group_row_len_kernel, dim3(grid_for(R1)), dim3(256), 0, s, (uint64_t)R1, segoff.p, seg_len.p,
+                                       set_of_seg.p, newlen.p);
+                    GBRS_TRY(exclusive_scan(sc, newlen.p, rowstart2.p, R1, s));
+                    uint32_t P2 = 0;
+                    GBRS_TRY(fetch_last_plus(rowstart2.p, newlen.p, R1, P2, s));
+                    GBRS_HIP_CHECK(hipMemcpyAsync(rowstart2.p + R1, &P2, 4, hipMemcpyHostToDevice, s));
+                    GBRS_TRY(ploc2.alloc(P2)); GBRS_TRY(pmask2.alloc(P2));
+                    hipLaunchKernelGGL(group_rewrite_kernel, dim3(grid_for(R1)), dim3(256), 0, s, (uint64_t)R1, L_in, segoff.p,
+                                       seg_begin.p, seg_len.p, set_of_seg.p, rowstart2.p, gloc.p, gmask.p, ploc2.p, pmask2.p);
+                    GBRS_HIP_CHECK(hipStreamSynchronize(s));
+                    GBRS_HIP_CHECK(hipGetLastError());
+                    // worth it when the frequent sets take a twentieth of the words away (GBRS_TUNING_GROUP_SETS=1 / 0 forces the choice)
+                    const bool use = forced_on || (uint64_t)P2 * 100 <= (uint64_t)P * 95;
+                    if (use) {
+                        rowstart.swap(rowstart2); ploc.swap(ploc2); pmask.swap(pmask2);
+                        out.n_sets = V;
+                        out.n_pairs = P2;
+                        L = L_in + V;
+                    } else {
+                        out.set_ptr.release();
+                        out.set_members.release();
+                    }
+                }
+            }
+        }
+        stg.mark("3c mask-group sets");
     }
     // 4. order rows so that similar rows are adjacent
     DevBuf<uint64_t> rkey, skey;

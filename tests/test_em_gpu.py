@@ -22,6 +22,9 @@ LAYOUTS = {"tiles": dict(), "tiles_merged": dict(merge_identical_rows=True), "cs
            # the layout the headline number runs on: the build's own rule (>= 100 words per id) declines the sets on
            # inputs of this size, GBRS_TUNING_LOCUS_SETS=1 forces them (see the fixture below)
            "tiles_locus_sets_forced": dict(),
+           # round 4: locus sets per mask group (the loci of a read that share a mask; what the multi-isoform sample takes),
+           # forced on with every candidate kept (the build's own rule wants a set carried by >= 64 reads)
+           "tiles_group_sets_forced": dict(),
            # round 4: the E-step on persistent workgroups (GBRS_TUNING_PERSISTENT=1; built, measured, not the default).  A golden
            # has a handful of tiles, so every workgroup would get one (the path with nothing to prefetch); 128-word tiles on
            # two (three) workgroups make each walk many tiles, with the next tile's dictionary and theta fetched under the
@@ -31,6 +34,7 @@ LAYOUTS = {"tiles": dict(), "tiles_merged": dict(merge_identical_rows=True), "cs
            "tiles_persistent_walk_merged": dict(merge_identical_rows=True),
            "tiles_persistent_one_tile_each": dict()}
 LAYOUT_ENV = {"tiles_locus_sets_forced": {"GBRS_TUNING_LOCUS_SETS": "1"},
+              "tiles_group_sets_forced": {"GBRS_TUNING_LOCUS_SETS": "0", "GBRS_TUNING_GROUP_SETS": "1", "GBRS_TUNING_SET_MIN_ROWS": "1"},
               "tiles_persistent_walk": {"GBRS_TUNING_PERSISTENT": "1", "GBRS_TUNING_PERSISTENT_GROUPS": "2", "GBRS_TUNING_TILE_WORDS": "128"},
               "tiles_persistent_walk_sets": {"GBRS_TUNING_PERSISTENT": "1", "GBRS_TUNING_PERSISTENT_GROUPS": "3",
                                              "GBRS_TUNING_TILE_WORDS": "128", "GBRS_TUNING_LOCUS_SETS": "1"},
@@ -92,6 +96,22 @@ def _rows_with_one_mask_over_several_loci(g):
     return int(((nl > 1) & same).sum())
 
 
+def _rows_with_a_mask_group(g):
+    """Number of reads of an em_*.npz fixture in which at least two loci carry the same haplotype mask (after the fixture's
+    `-G` mask): the reads a mask-group locus set shortens."""
+    R, L, H, indptr, indices, count, eff_len, groups, gtmask = em_case_inputs(g)
+    m = np.zeros((R, L), dtype=np.int64)
+    for h in range(H):
+        col = np.repeat(np.arange(L), np.diff(indptr[h].astype(np.int64)))
+        keep = np.ones(len(col), dtype=bool) if gtmask is None else gtmask[h, col] != 0
+        m[indices[h].astype(np.int64)[keep], col[keep]] |= 1 << h
+    n = 0
+    for row in m:
+        nz = row[row != 0]
+        n += len(nz) != len(np.unique(nz))
+    return n
+
+
 def close(a, b, rtol=RTOL):
     np.testing.assert_allclose(a, b, rtol=rtol, atol=1e-300)
 
@@ -109,6 +129,8 @@ def test_em_matches_reference_golden(path, layout):
         # every workgroup really walks several tiles (the one-haplotype golden's rows merge into a single tile)
         if int(g["num_haps"]) > 1:
             assert em.info().num_tiles >= (2 if "merged" in layout else 4), em.info().num_tiles
+    if layout == "tiles_group_sets_forced" and expect_layout == 1 and not bool(g["has_count"]):
+        assert (em.info().num_locus_sets > 0) == (_rows_with_a_mask_group(g) > 0)
     if layout in ("tiles_locus_sets_forced", "tiles_persistent_walk_sets") and expect_layout == 1 and not bool(g["has_count"]):
         # unweighted rows (the build never takes sets for weighted ones): the sets must really be there whenever some
         # read aligns to several loci under one mask
@@ -669,6 +691,71 @@ def _shared_mask_rows_problem(R, H, L, seed, max_loci, with_count, n_lists=None)
     count = rng.integers(1, 5, size=R).astype(np.float64) if with_count else None
     eff = np.tile(np.maximum(np.round(rng.lognormal(7.3, 0.6, size=L)) - 99.0, 1.0), (H, 1))
     return indptr, indices, count, np.ascontiguousarray(eff)
+
+
+def _mask_group_rows_problem(R, H, L, seed, max_loci, n_lists=None):
+    """Reads over several loci whose haplotype masks differ from locus to locus, but in GROUPS: a read's locus list (drawn
+    from a pool, so lists repeat) is cut into one to three pieces and every piece carries one random mask - what a read over
+    several isoforms of a gene looks like when most isoforms share the read's variants."""
+    rng = np.random.default_rng(seed)
+    n_lists = n_lists or max(R // 40, 4)
+    pool = [np.sort(rng.choice(L, size=int(rng.integers(1, max_loci + 1)), replace=False)) for _ in range(n_lists)]
+    which = rng.integers(0, n_lists, size=R)
+    rows, loci, masks = [], [], []
+    for r in range(R):
+        lo = pool[which[r]]
+        grp = rng.integers(0, int(rng.integers(1, 4)), size=len(lo))            # piece of every locus
+        gm = rng.integers(1, 1 << H, size=3)
+        rows.append(np.full(len(lo), r))
+        loci.append(lo)
+        masks.append(gm[grp])
+    rows, loci, masks = np.concatenate(rows), np.concatenate(loci).astype(np.int64), np.concatenate(masks)
+    indptr, indices = [], []
+    for h in range(H):
+        sel = (masks >> h) & 1 == 1
+        order = np.lexsort((rows[sel], loci[sel]))
+        indices.append(rows[sel][order].astype(np.uint32))
+        indptr.append(np.searchsorted(loci[sel][order], np.arange(L + 1)).astype(np.uint32))
+    eff = np.tile(np.maximum(np.round(rng.lognormal(7.3, 0.6, size=L)) - 99.0, 1.0), (H, 1))
+    return indptr, indices, np.ascontiguousarray(eff)
+
+
+@pytest.mark.parametrize("R,H,L,hi,min_rows", [(6000, 8, 300, 5, 1), (6000, 8, 300, 5, 16), (20000, 8, 3000, 7, 4),
+                                               (5000, 16, 400, 6, 2), (3000, 4, 100, 9, 1), (4000, 2, 150, 4, 1)])
+def test_em_mask_group_sets_vs_oracle(R, H, L, hi, min_rows, monkeypatch):
+    """Round 4: the loci of a read that share a mask become one word on a locus set when enough reads carry that set
+    (em_layout.hip, step 3c).  Forced on here with a small threshold; prepare, five steps, the stopping-rule sequence and
+    the expected counts against the oracle, default and deterministic layouts; the persistent E-step on the same layout."""
+    from gbrs_amd.engine import EmEngine
+    from oracle.em_oracle import EMOracle
+    monkeypatch.setenv("GBRS_TUNING_GROUP_SETS", "1")
+    monkeypatch.setenv("GBRS_TUNING_SET_MIN_ROWS", str(min_rows))
+    indptr, indices, eff = _mask_group_rows_problem(R, H, L, 31 + R + H, hi)
+    o = EMOracle(R, L, H, indptr, indices, None)
+    o.prepare(0.0, eff)
+    theta0 = o.theta.copy()
+    o.run(tol=0.0, max_iters=5)
+    words = {}
+    for name, flags, env in (("sets", 0, {}), ("deterministic", 32, {}), ("no_sets", 512, {}),
+                             ("persistent", 0, {"GBRS_TUNING_PERSISTENT": "1", "GBRS_TUNING_PERSISTENT_GROUPS": "2",
+                                                "GBRS_TUNING_TILE_WORDS": "256"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        eng = EmEngine.from_host(R, L, H, indptr, indices, None, eff, flags=flags)
+        for k in env:
+            monkeypatch.delenv(k)
+        inf = eng.info()
+        assert (inf.num_locus_sets > 0) == (flags != 512)
+        words[name] = int(inf.num_device_words)
+        eng.prepare(0.0)
+        close(eng.theta(), theta0)
+        n, hist = eng.run(model=4, tol=0.0, max_iters=5)
+        assert n == 5
+        np.testing.assert_allclose(hist, o.err_history, rtol=1e-7)
+        close(eng.theta(), o.theta)
+        close(eng.expected_counts(), o.expected_read_counts())
+        eng.close()
+    assert words["sets"] < words["no_sets"]                       # the sets really shortened the rows
 
 
 @pytest.mark.parametrize("R,H,L,hi,cnt,pc", [(6000, 8, 400, 5, False, 0.0),       # sets of 2-5 loci, many rows per set
