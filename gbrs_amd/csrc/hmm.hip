@@ -842,9 +842,13 @@ forward_wave_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *__
                     const double *__restrict__ eprob, const double *__restrict__ peprob,
                     const double *__restrict__ init_vec, double *__restrict__ xsum,
                     double *__restrict__ invz, double *__restrict__ delta,
-                    int32_t *__restrict__ last_state, const double *__restrict__ inject, int n_real_chrom) {
+                    int32_t *__restrict__ last_state, const double *__restrict__ inject, int n_real_chrom,
+                    int inject_slots /* boundary vectors per sample in `inject` */) {
     static_assert(SS % 2 == 0 && SS <= 64, "one lane per state, 16-byte aligned rows");
     __shared__ __attribute__((aligned(16))) double buf[SB][2][SS];
+    // a lone wavefront on a dependent chain: it goes first wherever it shares a SIMD with throughput work (the block
+    // operators of the blocked scan run beside the directly chained blocks; without this the chains ran at a fifth of their speed)
+    if constexpr (SB == 1) __builtin_amdgcn_s_setprio(3);
     const int chrom = order[blockIdx.y];
     const ChromDesc cd = chroms[chrom];
     // injected start (blocked scan): the descriptor's first gene belongs to the previous block - its vector comes from
@@ -903,7 +907,7 @@ forward_wave_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *__
 #pragma unroll
         for (int b = 0; b < SB; ++b) {
             if (injected) {
-                y_own[b] = inject[((int64_t)min((int)blockIdx.x * SB + b, n_samples - 1) * gridDim.y + cd.inject) * SS + jr];
+                y_own[b] = inject[((int64_t)min((int)blockIdx.x * SB + b, n_samples - 1) * inject_slots + cd.inject) * SS + jr];
             } else {
                 y_own[b] = exp(init_vec[jr] + eprob[g0[b] * SS + jr]);
                 if (act && sv[b]) xsum[g0[b] * SS + j] = exp(init_vec[j]);   // so that log(x) + e reproduces init + e
@@ -1006,7 +1010,7 @@ forward_wave_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *__
     for (int b = 0; b < SB; ++b) {
         double d0;
         if (injected) {
-            d0 = inject[((int64_t)min((int)blockIdx.x * SB + b, n_samples - 1) * gridDim.y + cd.inject) * SS + jr];
+            d0 = inject[((int64_t)min((int)blockIdx.x * SB + b, n_samples - 1) * inject_slots + cd.inject) * SS + jr];
         } else {
             d0 = init_vec[jr] + EM[g0[b] * SS + jr];
             if (act && sv[b]) delta[g0[b] * SS + j] = d0;
@@ -1395,9 +1399,10 @@ __global__ void __launch_bounds__(64)
 backward_wave_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *__restrict__ chroms,
                      const int32_t *__restrict__ order, const double *__restrict__ pprob_t,
                      const double *__restrict__ peprob, double *__restrict__ bhat, double *__restrict__ bscale,
-                     const double *__restrict__ inject) {
+                     const double *__restrict__ inject, int inject_slots) {
     static_assert(SS % 2 == 0 && SS <= 64, "one lane per state, 16-byte aligned rows");
     __shared__ __attribute__((aligned(16))) double buf[SB][2][SS];
+    if constexpr (SB == 1) __builtin_amdgcn_s_setprio(3);          // (see forward_wave_kernel)
     const ChromDesc cd = chroms[order[blockIdx.y]];
     const int n = cd.n_genes;
     if (n <= 0) return;
@@ -1419,7 +1424,7 @@ backward_wave_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *_
     for (int b = 0; b < SB; ++b) {
         const int64_t o = (g0[b] + n - 1) * SS + jr;
         if (injected) {
-            if (act) buf[b][0][j] = inject[((int64_t)min((int)blockIdx.x * SB + b, n_samples - 1) * gridDim.y + cd.inject) * SS + jr];
+            if (act) buf[b][0][j] = inject[((int64_t)min((int)blockIdx.x * SB + b, n_samples - 1) * inject_slots + cd.inject) * SS + jr];
         } else {
             if (act) buf[b][0][j] = peprob[o];
             if (act && sv[b]) {
@@ -2197,11 +2202,18 @@ struct gbrs_hmm {
     DevBuf<int32_t> last_state, states, calls;
     double t_emis = 0, t_fwd = 0, t_bwd = 0, t_bt = 0, t_run = 0;
     // blocked scan (hmm_blocked.inc; 36 states, up to HMM_BLOCKED_MAX samples): the chromosomes cut into blocks
-    int n_vb = 0, blk_samples = 0;
+    // Two block structures (round 4): the forward one (alpha, delta) may open every chromosome with a long block that is
+    // chained DIRECTLY from the chromosome's start while the other blocks' operators are being built (no operator for it);
+    // the backward one closes every chromosome with such a block.  [0] forward, [1] backward.
+    int n_vb = 0, blk_samples = 0;            // n_vb: the larger of the two block counts (buffers are sized by it)
+    int n_blk[2] = {0, 0}, n_head[2] = {0, 0};
     bool last_blocked = false;                // the last run's backward chains started from injected vectors
-    DevBuf<BlockRange> d_ranges;
-    DevBuf<int32_t> d_first_block, d_vorder;  // blocks of chromosome c: first_block[c] .. first_block[c+1]; identity order
+    DevBuf<BlockRange> d_ranges[2];
+    DevBuf<int32_t> d_first_block[2];         // blocks of chromosome c: first_block[c] .. first_block[c+1]
+    DevBuf<int32_t> d_vorder[2];              // block indices, the directly chained ones first (n_head of them)
     DevBuf<ChromDesc> d_vfwd, d_vbwd;         // the blocks as descriptors of the forward / delta and of the backward chains
+    hipStream_t stream_h[3] = {nullptr, nullptr, nullptr};   // the direct chains of alpha / backward / delta
+    hipEvent_t ev_head[3] = {nullptr, nullptr, nullptr};
     DevBuf<double> g_f, g_b, g_d, inj_f, inj_b, inj_d;   // block operators [sample][block][36][36], boundary vectors [sample][block][36]
     DevBuf<int32_t> e_f, e_b;                 // power-of-two exponents of the operators' columns
 };
@@ -2264,8 +2276,8 @@ int hmm_make_logs(gbrs_hmm *h) {
     if (h->free_backward) {
         if (!h->bcorr.p) GBRS_TRY(h->bcorr.alloc(gs));
         if (h->last_blocked)            // the blocks' backward chains become one free-running chain again (hmm_blocked.inc)
-            hipLaunchKernelGGL(blocked_bscale_fix_kernel, dim3(h->n_vb, h->n_samples), dim3(64), 0, h->stream, h->total_genes,
-                               h->n_vb, h->d_ranges.p, h->peprob.p, h->bhat.p, h->inj_b.p, h->bscale.p);
+            hipLaunchKernelGGL(blocked_bscale_fix_kernel, dim3(h->n_blk[1], h->n_samples), dim3(64), 0, h->stream, h->total_genes,
+                               h->n_vb, h->d_ranges[1].p, h->peprob.p, h->bhat.p, h->inj_b.p, h->bscale.p);
         hipLaunchKernelGGL(beta_corr_kernel, dim3(h->n_samples, h->n_chrom), dim3(256), 0, h->stream, h->total_genes,
                            h->d_chroms.p, h->invz.p, h->bscale.p, h->bcorr.p);
     }
@@ -2315,66 +2327,97 @@ int hmm_make_logs(gbrs_hmm *h) {
 #define HMM_BLOCKS_MAX 64
 #endif
 
-// The block structure of the handle's chromosomes and the buffers of the blocked scan for n_samples samples.
+// The block structures of the handle's chromosomes and the buffers of the blocked scan for n_samples samples.
+#ifndef HMM_HEAD_PERCENT
+#define HMM_HEAD_PERCENT 0    // share of a chromosome's genes that is chained directly while the operators of the rest are built.
+                              // Round 4: built (GBRS_TUNING_HMM_HEAD=20..60), parity-green, SLOWER - beside the operator kernels,
+                              // which keep every CU and the memory system busy, a directly chained block runs at ~1.7 us per step
+                              // instead of 0.4 (wave priority did not change that): 40k genes, one sample 1.06 ms without,
+                              // 1.19 / 1.42 / 1.64 / 1.85 ms with 20 / 30 / 40 / 50 % (profiles/r04_hmm_experiments.txt)
+#endif
 int hmm_prepare_blocks(gbrs_hmm *h) {
     const int S = h->S;
     if (h->n_vb == 0) {
-        int block_genes = HMM_BLOCK_GENES, blocks_max = HMM_BLOCKS_MAX;
+        int block_genes = HMM_BLOCK_GENES, blocks_max = HMM_BLOCKS_MAX, head_pct = HMM_HEAD_PERCENT;
         if (const char *env = std::getenv("GBRS_TUNING_HMM_BLOCK_GENES"); env && std::atoi(env) > 1) block_genes = std::atoi(env);
         if (const char *env = std::getenv("GBRS_TUNING_HMM_BLOCKS_MAX"); env && std::atoi(env) > 0) blocks_max = std::atoi(env);
-        std::vector<BlockRange> ranges;
-        std::vector<int32_t> first(h->n_chrom + 1, 0);
+        if (const char *env = std::getenv("GBRS_TUNING_HMM_HEAD"); env) head_pct = std::max(0, std::min(90, std::atoi(env)));
         std::vector<ChromDesc> vf, vb;
-        for (int c = 0; c < h->n_chrom; ++c) {
-            const ChromDesc &cd = h->chroms[c];
-            const int n = cd.n_genes;
-            const int nb = std::max(1, std::min(blocks_max, n / block_genes));
-            const int len = (n + nb - 1) / nb;
-            first[c] = (int32_t)ranges.size();
-            for (int lo = 0; lo < n; lo += len) {
-                const int hi = std::min(n, lo + len);
-                const int v = (int)ranges.size();
-                ranges.push_back(BlockRange{cd.gene_off, cd.trans_off, lo, hi, n, c});
-                ChromDesc f = cd, b = cd;           // bp_off / chunk_off are not used by the chain kernels
-                if (lo > 0) {                       // forward / delta: starts on the previous block's last gene
-                    f.gene_off = cd.gene_off + lo - 1;
-                    f.trans_off = cd.trans_off + lo - 1;
-                    f.n_genes = hi - lo + 1;
-                    f.inject = v;
-                } else {
-                    f.n_genes = hi;
+        for (int dir = 0; dir < 2; ++dir) {
+            std::vector<BlockRange> ranges;
+            std::vector<int32_t> first(h->n_chrom + 1, 0), heads, rest;
+            for (int c = 0; c < h->n_chrom; ++c) {
+                const ChromDesc &cd = h->chroms[c];
+                const int n = cd.n_genes;
+                // the directly chained part: the first genes (forward) / the last ones (backward); none on a chromosome
+                // too short to leave three blocks beside it
+                int direct = (int)((int64_t)n * head_pct / 100);
+                if (n - direct < 3 * block_genes || direct < block_genes) direct = 0;
+                const int rest_n = n - direct;
+                const int nb = std::max(1, std::min(blocks_max - (direct ? 1 : 0), rest_n / block_genes));
+                const int len = (rest_n + nb - 1) / nb;
+                std::vector<std::pair<int, int>> cuts;     // [lo, hi) of the chromosome's blocks, ascending
+                if (dir == 0 && direct) cuts.emplace_back(0, direct);
+                const int r0 = dir == 0 ? direct : 0, r1 = dir == 0 ? n : rest_n;
+                for (int lo = r0; lo < r1; lo += len) cuts.emplace_back(lo, std::min(r1, lo + len));
+                if (dir == 1 && direct) cuts.emplace_back(rest_n, n);
+                first[c] = (int32_t)ranges.size();
+                for (size_t q = 0; q < cuts.size(); ++q) {
+                    const int lo = cuts[q].first, hi = cuts[q].second;
+                    const int v = (int)ranges.size();
+                    const bool is_direct = direct && (dir == 0 ? q == 0 : q + 1 == cuts.size());
+                    ranges.push_back(BlockRange{cd.gene_off, cd.trans_off, lo, hi, n, c, is_direct ? 1 : 0});
+                    (is_direct ? heads : rest).push_back(v);
+                    ChromDesc d = cd;               // bp_off / chunk_off are not used by the chain kernels
+                    if (dir == 0) {
+                        if (lo > 0) {               // forward / delta: starts on the previous block's last gene
+                            d.gene_off = cd.gene_off + lo - 1;
+                            d.trans_off = cd.trans_off + lo - 1;
+                            d.n_genes = hi - lo + 1;
+                            d.inject = v;
+                        } else {
+                            d.n_genes = hi;
+                        }
+                        d.n_trans = d.n_genes;      // every step of the block has its transition block
+                        d.real_chrom = hi == n ? c : -1;
+                        vf.push_back(d);
+                    } else {
+                        d.gene_off = cd.gene_off + lo;
+                        d.trans_off = cd.trans_off + lo;
+                        if (hi < n) {               // backward: ends on the next block's first gene
+                            d.n_genes = hi - lo + 1;
+                            d.inject = v;
+                        } else {
+                            d.n_genes = n - lo;
+                        }
+                        d.n_trans = d.n_genes;
+                        d.real_chrom = -1;
+                        vb.push_back(d);
+                    }
                 }
-                f.n_trans = f.n_genes;              // every step of the block has its transition block
-                f.real_chrom = hi == n ? c : -1;
-                b.gene_off = cd.gene_off + lo;
-                b.trans_off = cd.trans_off + lo;
-                if (hi < n) {                       // backward: ends on the next block's first gene
-                    b.n_genes = hi - lo + 1;
-                    b.inject = v;
-                } else {
-                    b.n_genes = n - lo;
-                }
-                b.n_trans = b.n_genes;
-                b.real_chrom = -1;
-                vf.push_back(f);
-                vb.push_back(b);
             }
+            first[h->n_chrom] = (int32_t)ranges.size();
+            const int VB = (int)ranges.size();
+            std::vector<int32_t> order(heads);
+            order.insert(order.end(), rest.begin(), rest.end());
+            GBRS_TRY(h->d_ranges[dir].alloc(VB));
+            GBRS_TRY(h->d_first_block[dir].alloc(first.size()));
+            GBRS_TRY(h->d_vorder[dir].alloc(VB));
+            GBRS_HIP_CHECK(hipMemcpy(h->d_ranges[dir].p, ranges.data(), VB * sizeof(BlockRange), hipMemcpyHostToDevice));
+            GBRS_HIP_CHECK(hipMemcpy(h->d_first_block[dir].p, first.data(), first.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+            GBRS_HIP_CHECK(hipMemcpy(h->d_vorder[dir].p, order.data(), VB * sizeof(int32_t), hipMemcpyHostToDevice));
+            h->n_blk[dir] = VB;
+            h->n_head[dir] = (int)heads.size();
         }
-        first[h->n_chrom] = (int32_t)ranges.size();
-        const int VB = (int)ranges.size();
-        std::vector<int32_t> ident(VB);
-        for (int v = 0; v < VB; ++v) ident[v] = v;
-        GBRS_TRY(h->d_ranges.alloc(VB));
-        GBRS_TRY(h->d_first_block.alloc(first.size()));
-        GBRS_TRY(h->d_vorder.alloc(VB));
-        GBRS_TRY(h->d_vfwd.alloc(VB));
-        GBRS_TRY(h->d_vbwd.alloc(VB));
-        GBRS_HIP_CHECK(hipMemcpy(h->d_ranges.p, ranges.data(), VB * sizeof(BlockRange), hipMemcpyHostToDevice));
-        GBRS_HIP_CHECK(hipMemcpy(h->d_first_block.p, first.data(), first.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-        GBRS_HIP_CHECK(hipMemcpy(h->d_vorder.p, ident.data(), VB * sizeof(int32_t), hipMemcpyHostToDevice));
-        GBRS_HIP_CHECK(hipMemcpy(h->d_vfwd.p, vf.data(), VB * sizeof(ChromDesc), hipMemcpyHostToDevice));
-        GBRS_HIP_CHECK(hipMemcpy(h->d_vbwd.p, vb.data(), VB * sizeof(ChromDesc), hipMemcpyHostToDevice));
-        h->n_vb = VB;
+        GBRS_TRY(h->d_vfwd.alloc(vf.size()));
+        GBRS_TRY(h->d_vbwd.alloc(vb.size()));
+        GBRS_HIP_CHECK(hipMemcpy(h->d_vfwd.p, vf.data(), vf.size() * sizeof(ChromDesc), hipMemcpyHostToDevice));
+        GBRS_HIP_CHECK(hipMemcpy(h->d_vbwd.p, vb.data(), vb.size() * sizeof(ChromDesc), hipMemcpyHostToDevice));
+        h->n_vb = std::max(h->n_blk[0], h->n_blk[1]);
+        for (int k = 0; k < 3; ++k) {
+            if (!h->stream_h[k]) GBRS_HIP_CHECK(hipStreamCreateWithFlags(&h->stream_h[k], hipStreamNonBlocking));
+            if (!h->ev_head[k]) GBRS_HIP_CHECK(hipEventCreateWithFlags(&h->ev_head[k], hipEventDisableTiming));
+        }
     }
     if (h->blk_samples < h->n_samples) {
         const size_t nb = (size_t)h->n_vb * h->n_samples;
@@ -2442,7 +2485,6 @@ int hmm_launch(gbrs_hmm *h) {
             const bool blocked = SS == MF_S && !mfma && h->n_samples <= blocked_max && h->total_trans > 0;
             if (blocked) GBRS_TRY(hmm_prepare_blocks(h));
             h->last_blocked = blocked;
-            const dim3 blk_grid(h->n_samples, std::max(h->n_vb, 1));
             if ((mfma || blocked) && !h->amat_f.p) {
                 GBRS_TRY(h->amat_f.alloc((size_t)h->total_trans * MF_BLK));
                 GBRS_TRY(h->amat_b.alloc((size_t)h->total_trans * MF_BLK));
@@ -2459,20 +2501,33 @@ int hmm_launch(gbrs_hmm *h) {
                     return;
                 }
                 if (blocked) {
-                    hipLaunchKernelGGL((blockmat_mfma_kernel<0>), dim3(h->n_vb, h->n_samples), dim3(64), 0, st, h->total_genes,
-                                       h->d_ranges.p, h->amat_f.p, h->peprob.p, h->g_f.p, h->e_f.p);
+                    // the directly chained blocks on a stream of their own, beside the operators of the others; the combine
+                    // starts from what those chains stored
+                    auto chains = [&](hipStream_t q, int first, int count) {
+                        if (count > 0)
+                            hipLaunchKernelGGL(k_alpha, dim3(h->n_samples, count), dim3(64), 0, q, h->n_samples, h->total_genes,
+                                               h->d_vfwd.p, h->d_vorder[0].p + first, h->tprob_q.p, h->pprob.p, h->eprob.p, h->peprob.p,
+                                               h->init_vec.p, h->xsum.p, h->invz.p, h->delta.p, h->last_state.p, h->inj_f.p, h->n_chrom,
+                                               h->n_vb);
+                    };
+                    if (h->n_head[0]) {
+                        (void)hipStreamWaitEvent(h->stream_h[0], h->ev_fork, 0);
+                        chains(h->stream_h[0], 0, h->n_head[0]);
+                        (void)hipEventRecord(h->ev_head[0], h->stream_h[0]);
+                    }
+                    hipLaunchKernelGGL((blockmat_mfma_kernel<0>), dim3(h->n_blk[0], h->n_samples), dim3(64), 0, st, h->total_genes,
+                                       h->n_vb, h->d_ranges[0].p, h->amat_f.p, h->peprob.p, h->g_f.p, h->e_f.p);
+                    if (h->n_head[0]) (void)hipStreamWaitEvent(st, h->ev_head[0], 0);
                     hipLaunchKernelGGL((combine_sumprod_kernel<0>), dim3(h->n_chrom, h->n_samples), dim3(64), 0, st, h->total_genes,
-                                       h->n_vb, h->d_ranges.p, h->d_first_block.p, h->g_f.p, h->e_f.p, h->init_vec.p, h->eprob.p,
-                                       h->peprob.p, h->inj_f.p);
-                    hipLaunchKernelGGL(k_alpha, blk_grid, dim3(64), 0, st, h->n_samples, h->total_genes,
-                                       h->d_vfwd.p, h->d_vorder.p, h->tprob_q.p, h->pprob.p, h->eprob.p, h->peprob.p,
-                                       h->init_vec.p, h->xsum.p, h->invz.p, h->delta.p, h->last_state.p, h->inj_f.p, h->n_chrom);
+                                       h->n_vb, h->d_ranges[0].p, h->d_first_block[0].p, h->g_f.p, h->e_f.p, h->init_vec.p, h->eprob.p,
+                                       h->peprob.p, h->xsum.p, h->inj_f.p);
+                    chains(st, h->n_head[0], h->n_blk[0] - h->n_head[0]);
                     return;
                 }
                 hipLaunchKernelGGL(k_alpha, wave_grid, dim3(64), 0, st, h->n_samples, h->total_genes,
                                    h->d_chroms.p, h->d_order.p, h->tprob_q.p, h->pprob.p, h->eprob.p, h->peprob.p,
                                    h->init_vec.p, h->xsum.p, h->invz.p, h->delta.p, h->last_state.p, (const double *)nullptr,
-                                   h->n_chrom);
+                                   h->n_chrom, 0);
             };
             launch_back = [=](hipStream_t st) {
                 if (mfma) {
@@ -2482,18 +2537,29 @@ int hmm_launch(gbrs_hmm *h) {
                     return;
                 }
                 if (blocked) {
-                    hipLaunchKernelGGL((blockmat_mfma_kernel<1>), dim3(h->n_vb, h->n_samples), dim3(64), 0, st, h->total_genes,
-                                       h->d_ranges.p, h->amat_b.p, h->peprob.p, h->g_b.p, h->e_b.p);
+                    auto chains = [&](hipStream_t q, int first, int count) {
+                        if (count > 0)
+                            hipLaunchKernelGGL(k_back, dim3(h->n_samples, count), dim3(64), 0, q, h->n_samples, h->total_genes,
+                                               h->d_vbwd.p, h->d_vorder[1].p + first, h->pprob_t.p, h->peprob.p, h->bhat.p, h->bscale.p,
+                                               h->inj_b.p, h->n_vb);
+                    };
+                    if (h->n_head[1]) {
+                        (void)hipStreamWaitEvent(h->stream_h[1], h->ev_fork, 0);
+                        chains(h->stream_h[1], 0, h->n_head[1]);
+                        (void)hipEventRecord(h->ev_head[1], h->stream_h[1]);
+                    }
+                    hipLaunchKernelGGL((blockmat_mfma_kernel<1>), dim3(h->n_blk[1], h->n_samples), dim3(64), 0, st, h->total_genes,
+                                       h->n_vb, h->d_ranges[1].p, h->amat_b.p, h->peprob.p, h->g_b.p, h->e_b.p);
+                    if (h->n_head[1]) (void)hipStreamWaitEvent(st, h->ev_head[1], 0);
                     hipLaunchKernelGGL((combine_sumprod_kernel<1>), dim3(h->n_chrom, h->n_samples), dim3(64), 0, st, h->total_genes,
-                                       h->n_vb, h->d_ranges.p, h->d_first_block.p, h->g_b.p, h->e_b.p, h->init_vec.p, h->eprob.p,
-                                       h->peprob.p, h->inj_b.p);
-                    hipLaunchKernelGGL(k_back, blk_grid, dim3(64), 0, st, h->n_samples, h->total_genes,
-                                       h->d_vbwd.p, h->d_vorder.p, h->pprob_t.p, h->peprob.p, h->bhat.p, h->bscale.p, h->inj_b.p);
+                                       h->n_vb, h->d_ranges[1].p, h->d_first_block[1].p, h->g_b.p, h->e_b.p, h->init_vec.p, h->eprob.p,
+                                       h->peprob.p, h->bhat.p, h->inj_b.p);
+                    chains(st, h->n_head[1], h->n_blk[1] - h->n_head[1]);
                     return;
                 }
                 hipLaunchKernelGGL(k_back, wave_grid, dim3(64), 0, st, h->n_samples, h->total_genes,
                                    h->d_chroms.p, h->d_order.p, h->pprob_t.p, h->peprob.p, h->bhat.p, h->bscale.p,
-                                   (const double *)nullptr);
+                                   (const double *)nullptr, 0);
             };
             // GBRS_TUNING_HMM_DLANES = smallest batch that takes the samples-on-lanes delta chain (0: never)
             int dl_min = HMM_DLANES_MIN;
@@ -2507,19 +2573,31 @@ int hmm_launch(gbrs_hmm *h) {
                     return;
                 }
                 if (blocked) {
-                    hipLaunchKernelGGL(blockmat_maxplus_kernel, dim3(h->n_vb, h->n_samples), dim3(64 * MP_WAVES), 0, st,
-                                       h->total_genes, h->d_ranges.p, h->tprob.p, h->eprob.p, h->g_d.p);
+                    auto chains = [&](hipStream_t q, int first, int count) {
+                        if (count > 0)
+                            hipLaunchKernelGGL(k_delta, dim3(h->n_samples, count), dim3(64), 0, q, h->n_samples, h->total_genes,
+                                               h->d_vfwd.p, h->d_vorder[0].p + first, h->tprob_q.p, h->pprob.p, h->eprob.p, h->peprob.p,
+                                               h->init_vec.p, h->xsum.p, h->invz.p, h->delta.p, h->last_state.p, h->inj_d.p, h->n_chrom,
+                                               h->n_vb);
+                    };
+                    if (h->n_head[0]) {
+                        (void)hipStreamWaitEvent(h->stream_h[2], h->ev_fork, 0);
+                        chains(h->stream_h[2], 0, h->n_head[0]);
+                        (void)hipEventRecord(h->ev_head[2], h->stream_h[2]);
+                    }
+                    hipLaunchKernelGGL(blockmat_maxplus_kernel, dim3(h->n_blk[0], h->n_samples), dim3(64 * MP_WAVES), 0, st,
+                                       h->total_genes, h->n_vb, h->d_ranges[0].p, h->tprob.p, h->eprob.p, h->g_d.p);
+                    if (h->n_head[0]) (void)hipStreamWaitEvent(st, h->ev_head[2], 0);
                     hipLaunchKernelGGL(combine_maxplus_kernel, dim3(h->n_chrom, h->n_samples), dim3(64), 0, st, h->total_genes,
-                                       h->n_vb, h->d_ranges.p, h->d_first_block.p, h->g_d.p, h->init_vec.p, h->eprob.p, h->inj_d.p);
-                    hipLaunchKernelGGL(k_delta, blk_grid, dim3(64), 0, st, h->n_samples, h->total_genes,
-                                       h->d_vfwd.p, h->d_vorder.p, h->tprob_q.p, h->pprob.p, h->eprob.p, h->peprob.p,
-                                       h->init_vec.p, h->xsum.p, h->invz.p, h->delta.p, h->last_state.p, h->inj_d.p, h->n_chrom);
+                                       h->n_vb, h->d_ranges[0].p, h->d_first_block[0].p, h->g_d.p, h->init_vec.p, h->eprob.p,
+                                       h->delta.p, h->inj_d.p);
+                    chains(st, h->n_head[0], h->n_blk[0] - h->n_head[0]);
                     return;
                 }
                 hipLaunchKernelGGL(k_delta, wave_grid, dim3(64), 0, st, h->n_samples, h->total_genes,
                                    h->d_chroms.p, h->d_order.p, h->tprob_q.p, h->pprob.p, h->eprob.p, h->peprob.p,
                                    h->init_vec.p, h->xsum.p, h->invz.p, h->delta.p, h->last_state.p, (const double *)nullptr,
-                                   h->n_chrom);
+                                   h->n_chrom, 0);
             };
         } else {
             const dim3 quad_grid(h->n_samples, h->n_chrom), quad_block(threads);
@@ -2931,14 +3009,16 @@ int gbrs_genoprob_dosage(int num_haps, int64_t n_rows, const double *gprob, doub
 int gbrs_hmm_destroy(gbrs_hmm_t *h) {
     if (!h) return GBRS_OK;
     (void)hipSetDevice(h->device);
-    for (hipStream_t st : {h->stream, h->stream_b, h->stream_c})
+    for (hipStream_t st : {h->stream, h->stream_b, h->stream_c, h->stream_h[0], h->stream_h[1], h->stream_h[2]})
         if (st) (void)hipStreamSynchronize(st);
     for (auto &e : h->ev)
         if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : {h->ev_fork, h->ev_b, h->ev_c1, h->ev_c})
         if (e) (void)hipEventDestroy(e);
-    for (hipStream_t st : {h->stream, h->stream_b, h->stream_c})
+    for (hipStream_t st : {h->stream, h->stream_b, h->stream_c, h->stream_h[0], h->stream_h[1], h->stream_h[2]})
         if (st) (void)hipStreamDestroy(st);
+    for (hipEvent_t e : h->ev_head)
+        if (e) (void)hipEventDestroy(e);
     if (h->expr_stage) (void)hipHostFree(h->expr_stage);
     delete h;
     return GBRS_OK;
