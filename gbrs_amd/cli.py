@@ -76,6 +76,10 @@ def build_parser():
     cp.add_argument('-c', '--comp-lib', default='zlib')
     cp.add_argument('-v', '--verbose', action='count', default=0)
     cp.add_argument('--device', type=int, default=0)
+    wk = sub.add_parser('worker', help='(extension) quantify -> reconstruct -> quantify -G of many samples in one resident process')
+    wk.add_argument('--jobs', required=True, type=_existing, help='JSON list of samples, see gbrs_amd/worker.py')
+    wk.add_argument('-v', '--verbose', action='count', default=0)
+    wk.add_argument('--device', type=int, default=0)
     return ap
 
 
@@ -117,6 +121,9 @@ def main(argv=None) -> int:
                      report_posterior=args.report_posterior, device=args.device,
                      merge_identical_rows=args.merge_identical_rows, stage_times=stages,
                      one_shot=True)         # the command builds one handle and exits: GBRS_EM_ONE_SHOT
+        elif args.command == 'worker':
+            from .worker import main as worker_main
+            worker_main(args.jobs, device=args.device)
         elif args.command == 'compress':
             from .compress import compress
             files = [f for x in args.emase_files for f in x.split(',')]

@@ -185,74 +185,125 @@ def read_gene_order(gpos_file):
     return order
 
 
-def chromosome_inputs(gene_ids, expr_row, expr_table, avecs, num_haps):
-    """Device inputs of one chromosome: expression rows (n x H), specificity blocks (n x H x H, zero
-    where the gene has none) and the has-block flags.  `avecs` is a FastNpz of per-gene (H x H) blocks."""
-    n = len(gene_ids)
-    rows = expr_table[[expr_row[g] for g in gene_ids]] if n else np.zeros((0, num_haps))   # KeyError: gene without TPM
-    rows = np.ascontiguousarray(rows, dtype=np.float64).reshape(n, num_haps)
-    present = np.fromiter((g in avecs for g in gene_ids), dtype=np.uint8, count=n)
-    blocks = np.zeros((n, num_haps, num_haps), dtype=np.float64)
-    have = np.flatnonzero(present)
-    if len(have):
-        blocks[have] = avecs.stack([gene_ids[k] for k in have], (num_haps, num_haps))
-    return rows, blocks, present
+class ReconstructContext:
+    """Everything `gbrs reconstruct` reads that does not depend on the sample - genome order, gene order, transition
+    tables, specificity blocks - and the device handle that holds the tables.  One command builds one and drops it; a
+    resident process (gbrs_amd.worker) keeps it across samples, so that a sample costs its expression rows only."""
+
+    def __init__(self, tprob_file, avec_file=None, gpos_file=None, device=0):
+        data_dir = os.getenv('GBRS_DATA', '.')
+        self.tprob_file = tprob_file
+        self.avec_file = avec_file or os.path.join(data_dir, 'avecs.npz')
+        self.gpos_file = gpos_file or os.path.join(data_dir, 'ref.gene_pos.ordered.npz')
+        self.device = device
+        self.data_dir = data_dir
+        self.loaded = False
+        self.hmm = None
+        self.num_haps = None
+
+    def load(self, marks=None):
+        """The files (the big transition tables inflate on the library's threads while the small files are parsed)."""
+        if self.loaded:
+            return
+        logger.info('Loading chromosome information')
+        genome = list(get_chromosome_info(self.data_dir))
+        from concurrent.futures import ThreadPoolExecutor
+        tprob = FastNpz(self.tprob_file)
+        self.chroms = [c for c in genome if c in tprob]              # chromosomes without a table are skipped (:495)
+        reader = ThreadPoolExecutor(max_workers=1)
+        tables_pending = reader.submit(tprob.read_many, self.chroms)
+        logger.info(f'Loading alignment specificity: {self.avec_file}')
+        self.avecs = FastNpz(self.avec_file)
+        logger.info(f'Loading gene meta data: {self.gpos_file}')
+        self.gene_order = read_gene_order(self.gpos_file)
+        self._tables_pending, self._reader = tables_pending, reader
+        self.loaded = True
+
+    def tables(self):
+        if self._tables_pending is not None:
+            logger.info(f'Loading transition probabilities: {self.tprob_file}')
+            self._tables = self._tables_pending.result()             # stored members: views of the page cache, no copy
+            self._reader.shutdown(wait=False)
+            self._tables_pending = None
+        return self._tables
+
+    def specificity(self, num_haps):
+        """Per chromosome (blocks [n, H, H], present flags [n]): sample independent, made once."""
+        if getattr(self, '_spec', None) is None or self.num_haps != num_haps:
+            spec = []
+            for c in self.chroms:
+                ids = self.gene_order[c]
+                n = len(ids)
+                present = np.fromiter((g in self.avecs for g in ids), dtype=np.uint8, count=n)
+                blocks = np.zeros((n, num_haps, num_haps), dtype=np.float64)
+                have = np.flatnonzero(present)
+                if len(have):
+                    blocks[have] = self.avecs.stack([ids[k] for k in have], (num_haps, num_haps))
+                spec.append((blocks, present))
+            self._spec, self.num_haps = spec, num_haps
+            self.avecs.close()
+        return self._spec
+
+    def close(self):
+        if self.hmm is not None:
+            self.hmm.close()
+            self.hmm = None
 
 
 def reconstruct(expression_file: str, tprob_file: str, avec_file: str = None, gpos_file: str = None,
                 expr_threshold: float = 1.5, sigma: float = 0.12, outbase: str = None,
-                device: int = 0, stage_times: dict = None) -> None:
+                device: int = 0, stage_times: dict = None, context: ReconstructContext = None) -> None:
     """`gbrs reconstruct`: diplotype posteriors and Viterbi calls along every chromosome from
     gene-level TPMs.  Same inputs, defaults and three output files as gbrs_utils.reconstruct
     (gbrs_utils.py:382-609); the emission model and the three recursions run on the device.
-    `stage_times` (optional dict) receives wall-clock seconds per stage."""
+    `stage_times` (optional dict) receives wall-clock seconds per stage.  `context` (extension,
+    gbrs_amd.worker): the sample-independent inputs and the device handle of an earlier call on the same
+    tables - the transition and specificity tables then stay where they are and the sample moves its expression
+    rows only."""
     clock = time.perf_counter
     marks = stage_times if stage_times is not None else {}
-    data_dir = os.getenv('GBRS_DATA', '.')
     stem = 'gbrs.reconstructed' if outbase is None else outbase
     out_calls, out_post, out_path = f'{stem}.genotypes.tsv', f'{stem}.genoprobs.npz', f'{stem}.genotypes.npz'
-    avec_file = avec_file or os.path.join(data_dir, 'avecs.npz')
-    gpos_file = gpos_file or os.path.join(data_dir, 'ref.gene_pos.ordered.npz')
+    ctx = context if context is not None else ReconstructContext(tprob_file, avec_file, gpos_file, device)
     for label, value in (('Expression File', expression_file), ('Transition Probabilities File', tprob_file),
-                         ('Alignment Specificity File', avec_file), ('Gene Position File', gpos_file),
+                         ('Alignment Specificity File', ctx.avec_file), ('Gene Position File', ctx.gpos_file),
                          ('Expression Threshold', expr_threshold), ('Sigma', sigma), ('Outbase', outbase)):
         logger.info(f'{label}: {value}')
 
     _lib.warm_up_device_async(device)      # HIP start-up overlaps with reading the files
     t0 = clock()
-    logger.info('Loading chromosome information')
-    genome = list(get_chromosome_info(data_dir))
-    # the transition tables are the big read (0.4 GB of deflate streams at DO size): it starts now on the library's
+    # the transition tables are the big read (0.4 GB of deflate streams at DO size): it starts on the library's
     # threads and is collected when the tables are needed, after the small files have been parsed
-    from concurrent.futures import ThreadPoolExecutor
-    tprob = FastNpz(tprob_file)
-    chroms = [c for c in genome if c in tprob]                  # chromosomes without a table are skipped (:495)
-    reader = ThreadPoolExecutor(max_workers=1)
-    tables_pending = reader.submit(tprob.read_many, chroms)
-    logger.info(f'Loading alignment specificity: {avec_file}')
-    avecs = FastNpz(avec_file)
-    logger.info(f'Loading gene meta data: {gpos_file}')
-    gene_order = read_gene_order(gpos_file)
+    ctx.load()
+    chroms, gene_order = ctx.chroms, ctx.gene_order
     logger.info(f'Loading expression level data: {expression_file}')
     haplotypes, expr_row, expr_table = read_gene_tpm(expression_file)
     num_haps = len(haplotypes)
     diplotypes = [a + b for a, b in combinations_with_replacement(haplotypes, 2)]
-    per_chrom = [chromosome_inputs(gene_order[c], expr_row, expr_table, avecs, num_haps) for c in chroms]
-    logger.info(f'Loading transition probabilities: {tprob_file}')
-    tables = tables_pending.result()                            # stored members: views of the page cache, no copy
-    reader.shutdown(wait=False)
-    avecs.close()
+    rows = []
+    for c in chroms:
+        ids = gene_order[c]
+        r = expr_table[[expr_row[g] for g in ids]] if len(ids) else np.zeros((0, num_haps))   # KeyError: gene without TPM
+        rows.append(np.ascontiguousarray(r, dtype=np.float64).reshape(len(ids), num_haps))
+    first_use = ctx.hmm is None or ctx.hmm.H != num_haps
+    spec = ctx.specificity(num_haps) if first_use else None
+    tables = ctx.tables() if first_use else None
     marks['load'] = clock() - t0
 
     posterior, path_names, calls = {}, {}, {}
     if chroms:
         t0 = clock()
-        hmm = DiplotypeHMM(num_haps, chroms, [len(gene_order[c]) for c in chroms], tables, device=device)
+        if first_use:
+            ctx.close()
+            ctx.hmm = DiplotypeHMM(num_haps, chroms, [len(gene_order[c]) for c in chroms], tables, device=device)
+        hmm = ctx.hmm
         marks['tables_to_device'] = clock() - t0
         t0 = clock()
         logger.info('Getting forward probability')
-        hmm.set_expression([x[0] for x in per_chrom], [x[1] for x in per_chrom], [x[2] for x in per_chrom],
-                           expr_threshold, sigma)
+        if first_use:
+            hmm.set_expression(rows, [x[0] for x in spec], [x[1] for x in spec], expr_threshold, sigma)
+        else:
+            hmm.set_expression(rows, expr_threshold=expr_threshold, sigma=sigma)
         logger.info('Getting backward probability')
         hmm.run()
         logger.info('Getting forward-backward probability')
@@ -261,7 +312,8 @@ def reconstruct(expression_file: str, tprob_file: str, avec_file: str = None, gp
             posterior[c] = res['gamma']
             path_names[c] = [diplotypes[s] for s in res['states']]
             calls.update((gid, diplotypes[s]) for gid, s in zip(gene_order[c], res['calls']) if s >= 0)
-        hmm.close()
+        if context is None:
+            ctx.close()
         marks['hmm'] = clock() - t0
 
     t0 = clock()

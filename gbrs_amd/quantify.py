@@ -237,10 +237,12 @@ def quantify(alignment_file: str, group_file: str = None, length_file: str = Non
              pseudocount: float = 0.0, max_iters: int = 999, tolerance: float = 0.0001,
              report_alignment_counts: bool = False, report_posterior: bool = False,
              device: int = 0, merge_identical_rows: bool = False, stage_times: dict = None,
-             one_shot: bool = False) -> None:
+             one_shot: bool = False, alignment=None, target_lengths=None) -> None:
     """Quantify allele-specific expression from an EMASE alignment file.  `stage_times` (optional
     dict) receives the wall-clock seconds of the stages: load, mask, em_setup, em_run, reports,
-    alignment_counts."""
+    alignment_counts.  `alignment` / `target_lengths` (extension, gbrs_amd.worker): the file's contents as
+    load_alignment() and read_length_file() return them, when a resident process has them already - the
+    multiway and the diploid pass of one sample read the same file."""
     clock = time.perf_counter
     marks = stage_times if stage_times is not None else {}
     group_file = _default_support_file(
@@ -269,9 +271,13 @@ def quantify(alignment_file: str, group_file: str = None, length_file: str = Non
     lengths_pending = []
 
     def names_known(apm):
-        if length_file is not None:
+        if length_file is not None and target_lengths is None:
             lengths_pending.append(side.submit(read_length_file, apm, length_file, 100))
-    aln_mat = load_alignment(alignment_file, grpfile=group_file, on_names=names_known)
+    if alignment is not None:
+        aln_mat = alignment
+        aln_mat.haplotype_mask = None              # a mask of an earlier pass is not this pass's
+    else:
+        aln_mat = load_alignment(alignment_file, grpfile=group_file, on_names=names_known)
     marks['load'] = clock() - t0
 
     t0 = clock()
@@ -290,7 +296,10 @@ def quantify(alignment_file: str, group_file: str = None, length_file: str = Non
     logger.info('Running EMASE')
     t0 = clock()
     em = EMfactory(aln_mat, device=device, merge_identical_rows=merge_identical_rows, one_shot=one_shot)
-    if lengths_pending:
+    if target_lengths is not None:
+        em.set_target_lengths(target_lengths)
+        em.prepare(pseudocount=pseudocount)
+    elif lengths_pending:
         em.set_target_lengths(lengths_pending[0].result())
         em.prepare(pseudocount=pseudocount)
     else:

@@ -193,6 +193,59 @@ def run_cli(argv, workdir, tag):
     return wall, st
 
 
+def run_workers(workdir, sample, rec, n_workers, samples_each, tag):
+    """n_workers resident processes (`python -m gbrs_amd worker`) side by side on the one GPU, each taking samples_each
+    samples through quantify -> reconstruct -> quantify -G.  The samples are the same files (page cache warm, as for the
+    single commands) under outbases of their own; native decode / format threads are capped at cores / workers.
+    Returns wall seconds (launch of the first process to exit of the last) and the per-sample stage times."""
+    first = next(iter(sample["files"]))
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    procs = []
+    t0 = time.time()
+    for w in range(n_workers):
+        jobs = [dict(alignment_file=sample["files"][first], group_file=sample["group_file"], length_file=sample["length_file"],
+                     outbase=os.path.join(workdir, f"w{tag}_{w}_{k}"), tprob_file=rec["tprob"], avec_file=rec["avecs"],
+                     gpos_file=rec["gpos"]) for k in range(samples_each)]
+        jf = os.path.join(workdir, f"jobs_{tag}_{w}.json")
+        with open(jf, "w") as fh:
+            json.dump(jobs, fh)
+        env = dict(os.environ, GBRS_DATA=workdir, PYTHONPATH=ROOT, GBRS_T0=repr(t0),
+                   GBRS_IO_THREADS=str(max(1, cores // n_workers)))
+        procs.append(subprocess.Popen([sys.executable, "-m", "gbrs_amd", "worker", "--jobs", jf], env=env, cwd=workdir,
+                                      stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate() for p in procs]
+    wall = time.time() - t0
+    samples = []
+    for p, (out, err) in zip(procs, outs):
+        if p.returncode != 0:
+            raise RuntimeError(f"worker failed (rc {p.returncode}): {err[-2000:]}")
+        for line in out.strip().split("\n"):
+            if not line.startswith("{"):            # (EMfactory.run's iteration table goes to stdout, as in the reference)
+                continue
+            rec_line = json.loads(line)
+            if "summary" in rec_line:
+                if rec_line["summary"]["failed"]:
+                    raise RuntimeError(f"worker reported failed samples: {out[-2000:]}")
+            else:
+                samples.append(rec_line)
+    return wall, samples
+
+
+def mean_stages(samples):
+    """Mean seconds per stage over the samples of a worker run, first sample of a process (tables loaded, library warmed
+    up) apart from the later ones."""
+    def avg(vals):
+        return sum(vals) / len(vals) if vals else None
+    out = {}
+    for part in ("load_alignment", "wall"):
+        out[part] = avg([s[part] for s in samples])
+    for cmd in ("quantify", "reconstruct", "quantify_diploid"):
+        keys = set().union(*[set(s.get(cmd, {})) for s in samples])
+        out[cmd] = {k: avg([s[cmd][k] for s in samples if k in s.get(cmd, {}) and isinstance(s[cmd][k], (int, float))])
+                    for k in sorted(keys)}
+    return out
+
+
 def start_oracle(argv):
     env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1", PYTHONPATH=ROOT)
     return time.time(), subprocess.Popen([sys.executable, os.path.join(ROOT, "oracle", "e2e_oracle.py")] + argv, env=env,
@@ -236,7 +289,7 @@ def scaled_quantify(wall, st, scale, iters_full):
 
 
 def measure(rows=40_000_000, haps=8, loci=120_000, fmt="h5", cpu_rows=2_000_000, workdir=None, keep=False,
-            repeats=2, with_cpu=True, cpu_full="auto"):
+            repeats=2, with_cpu=True, cpu_full="auto", workers=(1, 2, 4), samples_each=2):
     """cpu_full: "auto" = the one-core baseline runs on the whole sample when the host has FULL_CPU_MIN_GB of memory,
     "yes" / "no" force it."""
     own = workdir is None
@@ -281,6 +334,25 @@ def measure(rows=40_000_000, haps=8, loci=120_000, fmt="h5", cpu_rows=2_000_000,
         qbest = min(v["wall_s"] for v in res["quantify"].values())
         res["total_wall_s"] = qbest + res["reconstruct"]["wall_s"]
         res["pipeline_wall_s"] = res["total_wall_s"] + res["quantify_diploid"]["wall_s"]
+        if workers:
+            # BASELINE configs[3] is 8 samples on 8 GPUs: whether its >= 6x can be host-bound shows on one GPU - resident
+            # workers (gbrs_amd.worker) side by side on the card, sharing the host's cores, page cache and PCIe
+            conc = {}
+            for nw in workers:
+                wall, samples = run_workers(workdir, sample, rec, nw, samples_each, f"c{nw}")
+                conc[str(nw)] = dict(workers=nw, samples=len(samples), wall_s=wall, samples_per_s=len(samples) / wall,
+                                     seconds_per_sample_in_worker=sum(x["wall"] for x in samples) / len(samples),
+                                     first_sample_of_a_process_s=sum(x["wall"] for x in samples[::samples_each]) / nw,
+                                     stage_means_s=mean_stages(samples))
+            base = conc[str(workers[0])]["samples_per_s"] / workers[0]
+            res["concurrent"] = dict(
+                note="resident workers on ONE GPU: every process takes its samples through quantify -> reconstruct -> "
+                     "quantify -G (the three commands' own functions; the alignment file is read once per sample, the "
+                     "reconstruct tables once per process); wall = first launch to last exit, interpreter and HIP start-up "
+                     "included; a sample as three fresh commands costs pipeline_wall_s",
+                samples_per_worker=samples_each, by_workers=conc,
+                scaling_vs_one_worker={k: v["samples_per_s"] / (base * workers[0]) for k, v in conc.items()},
+                three_commands_samples_per_s=1.0 / res["pipeline_wall_s"])
         if with_cpu:
             sub, n_sub = sample["cpu_sub"], sample["cpu_sub_entries"]
             # three one-core processes side by side (the box's other cores are idle); the two downstream commands read
@@ -339,6 +411,9 @@ def main():
     ap.add_argument("--repeats", type=int, default=2)
     ap.add_argument("--cpu-full", default="auto", choices=["auto", "yes", "no"],
                     help="one-core baseline on the whole sample (auto: when the host has >= 128 GB)")
+    ap.add_argument("--workers", default="1,2,4", help="concurrent resident workers to measure on the one GPU (empty: skip); "
+                                                       "a GPU box allows at most 6 processes on its card")
+    ap.add_argument("--samples-each", type=int, default=2)
     ap.add_argument("--make-sample", action="store_true", help="(internal) child process that writes the sample files")
     a = ap.parse_args()
     if a.make_sample:
@@ -346,7 +421,9 @@ def main():
         return
     subprocess.run([sys.executable, "-c", "import __graft_entry__ as g; g.build()"], cwd=ROOT, check=True,
                    stdout=sys.stderr)             # built in a child: the parent never loads the HIP runtime
-    out = measure(a.rows, a.haps, a.loci, a.format, a.cpu_rows, a.workdir, a.keep, a.repeats, not a.no_cpu, a.cpu_full)
+    workers = tuple(int(x) for x in a.workers.split(",") if x.strip())
+    out = measure(a.rows, a.haps, a.loci, a.format, a.cpu_rows, a.workdir, a.keep, a.repeats, not a.no_cpu, a.cpu_full,
+                  workers, a.samples_each)
     print(json.dumps(out), flush=True)
 
 
