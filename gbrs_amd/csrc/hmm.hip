@@ -846,9 +846,6 @@ forward_wave_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *__
                     int inject_slots /* boundary vectors per sample in `inject` */) {
     static_assert(SS % 2 == 0 && SS <= 64, "one lane per state, 16-byte aligned rows");
     __shared__ __attribute__((aligned(16))) double buf[SB][2][SS];
-    // a lone wavefront on a dependent chain: it goes first wherever it shares a SIMD with throughput work (the block
-    // operators of the blocked scan run beside the directly chained blocks; without this the chains ran at a fifth of their speed)
-    if constexpr (SB == 1) __builtin_amdgcn_s_setprio(3);
     const int chrom = order[blockIdx.y];
     const ChromDesc cd = chroms[chrom];
     // injected start (blocked scan): the descriptor's first gene belongs to the previous block - its vector comes from
@@ -1402,7 +1399,6 @@ backward_wave_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *_
                      const double *__restrict__ inject, int inject_slots) {
     static_assert(SS % 2 == 0 && SS <= 64, "one lane per state, 16-byte aligned rows");
     __shared__ __attribute__((aligned(16))) double buf[SB][2][SS];
-    if constexpr (SB == 1) __builtin_amdgcn_s_setprio(3);          // (see forward_wave_kernel)
     const ChromDesc cd = chroms[order[blockIdx.y]];
     const int n = cd.n_genes;
     if (n <= 0) return;
@@ -2332,7 +2328,7 @@ int hmm_make_logs(gbrs_hmm *h) {
 #define HMM_HEAD_PERCENT 0    // share of a chromosome's genes that is chained directly while the operators of the rest are built.
                               // Round 4: built (GBRS_TUNING_HMM_HEAD=20..60), parity-green, SLOWER - beside the operator kernels,
                               // which keep every CU and the memory system busy, a directly chained block runs at ~1.7 us per step
-                              // instead of 0.4 (wave priority did not change that): 40k genes, one sample 1.06 ms without,
+                              // instead of 0.4 (wave priority, s_setprio 3, did not change that): 40k genes, one sample 1.06 ms without,
                               // 1.19 / 1.42 / 1.64 / 1.85 ms with 20 / 30 / 40 / 50 % (profiles/r04_hmm_experiments.txt)
 #endif
 int hmm_prepare_blocks(gbrs_hmm *h) {
