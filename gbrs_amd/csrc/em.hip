@@ -481,6 +481,9 @@ struct gbrs_em {
 
     int layout = 0;               // 0 = csc-direct, 1 = packed row tiles
     uint32_t persist_groups = 0;  // > 0: the E-step of a step runs on this many persistent workgroups (em_tiles.inc)
+    uint32_t view = 1;            // 2: the tile layout is built over half-loci (em_layout.h): tL() loci of tH() haplotypes
+    uint32_t tH() const { return H / view; }
+    uint32_t tL() const { return L * view; }
     bool acc_needs_extra = false; // last E-step left the long-row sums in tl.acc_extra for the M-step to add
     bool acc_external = false;    // the caller all-reduces acc (sharded): always materialise all of it
     TileLayout tl;
@@ -569,9 +572,9 @@ int em_estep_tiles_h(gbrs_em *em) {
         em->err_pending = false;
         const dim3 grid((unsigned)tl.n_tiles + ea.n_err_blocks), block(TILE_THREADS);
         const double *ww = tl.weighted ? tl.word_weight.p : (const double *)nullptr;
-        const SetArgs sets{em->L, tl.n_sets ? tl.set_ptr.p : nullptr, tl.set_members.p, tl.dest_list.p, tl.dict_b.p, tl.dest_b.p};
+        const SetArgs sets{em->tL(), tl.n_sets ? tl.set_ptr.p : nullptr, tl.set_members.p, tl.dest_list.p, tl.dict_b.p, tl.dest_b.p};
 #define GBRS_LAUNCH_TILES(W, D)                                                                                        \
-        hipLaunchKernelGGL((tile_estep_kernel<HT, W, ONES, D>), grid, block, 0, em->stream, em->H, tl.tiles.p, tl.words.p, \
+        hipLaunchKernelGGL((tile_estep_kernel<HT, W, ONES, D>), grid, block, 0, em->stream, em->tH(), tl.tiles.p, tl.words.p, \
                            tl.dict.p, ww, em->theta.p, tl.partials.p, tl.slot_dest.p, em->acc.p, em->scalars.p,       \
                            (uint32_t)tl.n_tiles, ea, sets)
         if (!ONES && !tl.deterministic && em->persist_groups > 0 && HT > 0 && HT <= 8) {
@@ -580,7 +583,7 @@ int em_estep_tiles_h(gbrs_em *em) {
             const uint32_t G = std::min<uint32_t>(em->persist_groups, (uint32_t)tl.n_tiles);
             const dim3 pgrid(G + ea.n_err_blocks);
 #define GBRS_LAUNCH_PERSISTENT(HH, W, OW)                                                                              \
-            hipLaunchKernelGGL((tile_estep_persistent_kernel<HH, W, OW>), pgrid, block, 0, em->stream, em->H, tl.tiles.p,  \
+            hipLaunchKernelGGL((tile_estep_persistent_kernel<HH, W, OW>), pgrid, block, 0, em->stream, em->tH(), tl.tiles.p,  \
                                tl.words.p, tl.dict.p, ww, em->theta.p, tl.partials.p, tl.slot_dest.p,                  \
                                (int64_t)(em->acc.p - tl.partials.p), em->scalars.p, (uint32_t)tl.n_tiles, G, ea, sets)
             if (HT == 8 && !tl.weighted && tl.all_one_word) GBRS_LAUNCH_PERSISTENT(HT == 8 ? 8 : 1, false, HT == 8);
@@ -592,7 +595,7 @@ int em_estep_tiles_h(gbrs_em *em) {
 #if !defined(GBRS_NO_ONEWORD)
         } else if (HT == 8 && !tl.weighted && tl.all_one_word) {
             // no row of the layout has more than one word (single-locus reads, or locus sets): no row sums at all
-            hipLaunchKernelGGL((tile_estep_kernel<HT == 8 ? 8 : 1, false, ONES, false, HT == 8>), grid, block, 0, em->stream, em->H,
+            hipLaunchKernelGGL((tile_estep_kernel<HT == 8 ? 8 : 1, false, ONES, false, HT == 8>), grid, block, 0, em->stream, em->tH(),
                                tl.tiles.p, tl.words.p, tl.dict.p, ww, em->theta.p, tl.partials.p, tl.slot_dest.p, em->acc.p,
                                em->scalars.p, (uint32_t)tl.n_tiles, ea, sets);
 #endif
@@ -608,7 +611,7 @@ int em_estep_tiles(gbrs_em *em, bool materialize, bool skip_gather = false) {
     if (ONES || !em->tl.n_tiles) GBRS_TRY(em_flush_err(em));   // prepare / no tile launch to ride on
 
     TileLayout &tl = em->tl;
-    switch (em->H) {
+    switch (em->tH()) {
         case 1: GBRS_TRY((em_estep_tiles_h<1, ONES>(em))); break;
         case 2: GBRS_TRY((em_estep_tiles_h<2, ONES>(em))); break;
         case 4: GBRS_TRY((em_estep_tiles_h<4, ONES>(em))); break;
@@ -619,29 +622,31 @@ int em_estep_tiles(gbrs_em *em, bool materialize, bool skip_gather = false) {
     if (tl.n_long) {
         GBRS_HIP_CHECK(hipMemsetAsync(tl.acc_extra.p, 0, tl.acc_extra.bytes(), em->stream));
         if (tl.deterministic)
-            hipLaunchKernelGGL(long_rows_estep_serial_kernel<ONES>, dim3(1), dim3(64), 0, em->stream, tl.n_long, em->H,
+            hipLaunchKernelGGL(long_rows_estep_serial_kernel<ONES>, dim3(1), dim3(64), 0, em->stream, tl.n_long, em->tH(),
                                tl.long_ptr.p, tl.long_loc.p, tl.long_mask.p, tl.long_weight.p, em->theta.p,
                                tl.acc_extra.p, em->scalars.p);
         else
             hipLaunchKernelGGL(long_rows_estep_kernel<ONES>, dim3((unsigned)((tl.n_long + 3) / 4)), dim3(256), 0, em->stream,
-                               tl.n_long, em->H, tl.long_ptr.p, tl.long_loc.p, tl.long_mask.p, tl.long_weight.p,
+                               tl.n_long, em->tH(), tl.long_ptr.p, tl.long_loc.p, tl.long_mask.p, tl.long_weight.p,
                                em->theta.p, tl.acc_extra.p, em->scalars.p);
     }
     if (em->ev_after_estep) {
         GBRS_HIP_CHECK(hipEventRecord(em->ev_after_estep, em->stream));
         em->ev_after_estep = nullptr;
     }
+    // (the gather walks the layout's loci: half-loci of tH() haplotypes under the half-locus view - the same elements of acc)
+    const uint32_t gH = em->tH(), gL = em->tL();
     uint32_t HP = 1;
-    while (HP < em->H) HP <<= 1;
-    const bool pow2 = (em->H & (em->H - 1)) == 0;
-    const bool all = materialize || em->acc_external || !pow2;     // write every element of acc
-    const uint64_t elems = all ? (uint64_t)em->L * em->H : (uint64_t)tl.n_light * em->H;
+    while (HP < gH) HP <<= 1;
+    const bool pow2 = (gH & (gH - 1)) == 0;
+    const bool all = materialize || em->acc_external || !pow2 || em->view > 1;     // write every element of acc
+    const uint64_t elems = all ? (uint64_t)gL * gH : (uint64_t)tl.n_light * gH;
     const unsigned light = (unsigned)((elems + 255) / 256);
     const unsigned heavy = (unsigned)((tl.n_heavy + 3) / 4);
     em->acc_needs_extra = !all && tl.n_long > 0;
     if (skip_gather) return GBRS_OK;           // the fused gather + M-step kernel follows (em_one_step)
     if (light + heavy > 0)
-        hipLaunchKernelGGL(gather_kernel, dim3(light + heavy), dim3(256), 0, em->stream, em->L, em->H,
+        hipLaunchKernelGGL(gather_kernel, dim3(light + heavy), dim3(256), 0, em->stream, gL, gH,
                            HP, light, heavy, (uint32_t)tl.n_heavy, all ? 1 : 0, (uint32_t)tl.n_light, tl.light_loci.p,
                            tl.slot_ptr.p, tl.heavy_loci.p, tl.locus_class.p, tl.partials.p,
                            (tl.n_long && all) ? tl.acc_extra.p : (const double *)nullptr, em->acc.p, em->scalars.p,
@@ -903,7 +908,8 @@ int em_flush_err(gbrs_em *em) {
 // tile layout, H a power of two, A not handed out for an all-reduce: gather and M-step share a launch
 bool em_can_fuse_mstep(const gbrs_em *em) {
     static const bool off = [] { const char *e = std::getenv("GBRS_TUNING_NO_FUSED_MSTEP"); return e && std::atoi(e) != 0; }();
-    return !off && em->layout == 1 && (em->H & (em->H - 1)) == 0 && !em->acc_external;
+    // (half-locus view: the fused kernel's per-locus totals would be per half; gather and M-step stay two launches there)
+    return !off && em->layout == 1 && (em->H & (em->H - 1)) == 0 && !em->acc_external && em->view == 1;
 }
 
 int em_launch_mstep_gather(gbrs_em *em) {
@@ -1168,12 +1174,23 @@ int em_create_impl(uint64_t R, uint32_t L, uint32_t H, const uint32_t *const *in
             row_order = (distinct && !(flags & GBRS_EM_NO_INTERLEAVE)) ? 1 : 0;
         }
         em->tl.retain_temporaries = (flags & GBRS_EM_ONE_SHOT) != 0;
-        GBRS_TRY(build_tile_layout(em->tl, R, L, H, n, em->ent_row.p, em->col_ptr.p,
+        // 16 haplotypes as half-loci on the 8-haplotype kernels (em_layout.h; the review's "two halves of 8"): built, parity-green,
+        // NO gain - one GPU's shard of config 5: E-step 0.1518 ms against 0.1525 (the words double, the cost per word halves) and
+        // the iteration 0.1997 against 0.1744 (gather and M-step as two launches over every element).  GBRS_TUNING_HALF_LOCI=1
+        // switches it on; weighted rows and the deterministic mode never take it.
+        {
+            const char *env = std::getenv("GBRS_TUNING_HALF_LOCI");
+            const bool want = env ? std::atoi(env) != 0 : false;
+            const bool weighted = count != nullptr || (flags & GBRS_EM_MERGE_IDENTICAL_ROWS);
+            em->view = (H == 16 && want && !weighted && !(flags & GBRS_EM_DETERMINISTIC) && (uint64_t)L * 2 < (1u << 27)) ? 2u : 1u;
+        }
+        GBRS_TRY(build_tile_layout(em->tl, R, em->tL(), em->tH(), n, em->ent_row.p, em->col_ptr.p,
                                    count ? em->count.p : nullptr, (flags & GBRS_EM_MERGE_IDENTICAL_ROWS) != 0,
                                    row_order, (flags & GBRS_EM_DETERMINISTIC) != 0,
                                    em->stream, (flags & GBRS_EM_SIDE_BY_SIDE) ? 2u : 1u,
                                    (flags & GBRS_EM_NO_LOCUS_SETS) == 0 && !count &&
-                                       !(flags & GBRS_EM_MERGE_IDENTICAL_ROWS)));     // (weighted rows: their tiles are dictionary-bound)
+                                       !(flags & GBRS_EM_MERGE_IDENTICAL_ROWS),     // (weighted rows: their tiles are dictionary-bound)
+                                   0, em->view));
         em->layout = 1;
         {
             // persistent E-step workgroups: one per place the chip has for them (tile_estep_kernel's launch bounds: 3 per CU
@@ -1183,7 +1200,7 @@ int em_create_impl(uint64_t R, uint32_t L, uint32_t H, const uint32_t *const *in
             const char *env = std::getenv("GBRS_TUNING_PERSISTENT");
             int n_cu = 0;
             GBRS_HIP_CHECK(hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, device));
-            const unsigned per_cu = (em->tl.weighted || H > 8) ? 2u : 3u;
+            const unsigned per_cu = (em->tl.weighted || em->tH() > 8) ? 2u : 3u;
             const unsigned share = (flags & GBRS_EM_SIDE_BY_SIDE) ? 2u : 1u;
             unsigned groups = per_cu * (unsigned)std::max(n_cu, 1) / share;
             if (const char *g = std::getenv("GBRS_TUNING_PERSISTENT_GROUPS"); g && std::atoi(g) > 0) groups = (unsigned)std::atoi(g);
@@ -1690,14 +1707,14 @@ int gbrs_em_info(gbrs_em_t *em, gbrs_em_info_t *info) {
         // rows = theta rows gathered and sum rows stored by the tiles: one per slot, one per (slot, member) for a locus set
         const uint64_t rows = tl.n_dest_rows ? tl.n_dest_rows : tl.n_slots;
         info->bytes_per_iter = 4 * tl.n_batches * 64 + 16 * tl.n_tiles + 4 * tl.n_slots +
-                               8 * rows * em->H * 3 + 4 * rows + 4 * ((uint64_t)em->L + 1) +
+                               8 * rows * em->tH() * 3 + 4 * rows + 4 * ((uint64_t)em->tL() + 1) +
                                (tl.weighted ? 8 * tl.n_batches * 64 : 0) + 8 * HL * 6;
         info->num_heavy_loci = tl.n_heavy;
         info->num_light_loci = tl.n_light;
         // the E-step launch alone: words, tile headers, dictionary + slot destinations, theta gathered
         // once per slot, one partial-sum row stored per slot [, the per-word row weights]
         info->estep_bytes = 4 * tl.n_batches * 64 + 16 * tl.n_tiles + 4 * tl.n_slots + 4 * rows +
-                            8 * rows * em->H * 2 + (tl.weighted ? 8 * tl.n_batches * 64 : 0) +
+                            8 * rows * em->tH() * 2 + (tl.weighted ? 8 * tl.n_batches * 64 : 0) +
                             (tl.n_sets ? 8 * tl.n_slots : 0);       // dict_b / dest_b beside the dictionary
         if (tl.n_sets) info->bytes_per_iter += 8 * tl.n_slots;
     }

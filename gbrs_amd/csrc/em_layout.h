@@ -152,7 +152,14 @@ int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L, uint32_t H, uint6
                       const uint32_t *ent_row, const uint64_t *col_ptr, const double *count,
                       bool merge_identical_rows, int row_order /* 0 sorted, 1 interleaved, 2 streams */,
                       bool deterministic, hipStream_t stream, unsigned side_by_side = 1 /* handles sharing the device */,
-                      bool locus_sets = false, uint32_t dict_cap = 0 /* > 0: at most this many loci per tile dictionary */);
+                      bool locus_sets = false, uint32_t dict_cap = 0 /* > 0: at most this many loci per tile dictionary */,
+                      uint32_t view_factor = 1);
+// view_factor = 2 (round 4, 16 haplotypes): the layout is built over HALF-LOCI - locus l's haplotypes 0-7 are "locus" 2l,
+// its haplotypes 8-15 "locus" 2l + 1, L and H passed here are 2 L and 8.  The locus-major vectors (theta, A, lengths:
+// element l * 16 + h) are element for element the half-locus view's (2l + h / 8) * 8 + h % 8, so nothing outside the layout
+// moves; a read that aligns to both halves of a locus has two words in its row, and the tiles run on the 8-haplotype
+// E-step kernel (theta row and sums in registers, 0/1 doubles from the LDS tables, six waves per SIMD) instead of the
+// 16-haplotype one (128 registers, four waves per SIMD, theta from LDS for every word).
 
 // `gbrs compress`: equivalence classes of identical rows, in first-seen order.
 struct CompressResult {

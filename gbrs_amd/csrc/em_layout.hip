@@ -108,7 +108,9 @@ constexpr int KEY_ITERS = 32, KEY_SPAN = 64 * KEY_ITERS;
 __global__ void __launch_bounds__(256)
 make_keys_kernel(uint64_t n, uint32_t ncols, uint32_t L, uint64_t R, unsigned row_shift,
                  const uint64_t *__restrict__ col_ptr, const uint32_t *__restrict__ ent_row,
-                 uint64_t *__restrict__ keys, BuildFlags *flags) {
+                 uint64_t *__restrict__ keys, BuildFlags *flags, uint32_t view_h = 0) {
+    // view_h > 0 (em_layout.h, "half-loci"): haplotype h of locus l is keyed as haplotype h % view_h of locus
+    // l * (H / view_h) + h / view_h - the same element of the locus-major vectors under a narrower haplotype count
     // key = row << row_shift | locus << 5 | haplotype; row_shift = 32, or 5 + the locus bits so that a
     // radix sort of the used bits has no all-zero digit to pass over
     const int lane = threadIdx.x & 63;
@@ -125,7 +127,11 @@ make_keys_kernel(uint64_t n, uint32_t ncols, uint32_t L, uint64_t R, unsigned ro
         const uint64_t k = kb + lane;
         if (k >= n) continue;
         const uint32_t mine = col_ptr[c + 1] > min(kb + 63, n - 1) ? c : find_column_from(col_ptr, c, ncols, k);
-        const uint32_t h = mine / L, l = mine - h * L;
+        uint32_t h = mine / L, l = mine - h * L;
+        if (view_h) {
+            l = l * (ncols / L / view_h) + h / view_h;
+            h = h % view_h;
+        }
         const uint32_t r = ent_row[k];
         bad |= r >= R;
         keys[k] = ((uint64_t)r << row_shift) | ((uint64_t)l << 5) | h;
@@ -1136,7 +1142,7 @@ int compress_device(CompressResult &out, uint64_t R, uint32_t L, uint32_t H, uin
 int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L_in, uint32_t H, uint64_t N,
                       const uint32_t *ent_row, const uint64_t *col_ptr, const double *count,
                       bool merge, int row_order, bool deterministic, hipStream_t s, unsigned side_by_side, bool locus_sets,
-                      uint32_t dict_cap) {
+                      uint32_t dict_cap, uint32_t view_factor) {
     uint32_t L = L_in;                     // grows by the number of locus sets in step 3b
     out.n_sets = 0;
     out.n_dest_rows = 0;
@@ -1182,8 +1188,10 @@ int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L_in, uint32_t H, ui
     GBRS_TRY(keys2.alloc(N));
     stg.mark("1a key buffers");
     const unsigned row_shift = 5 + bits_for(L - 1);           // <= 32 (L < 2^27 checked above)
-    hipLaunchKernelGGL(make_keys_kernel, dim3(grid_for(N, 4 * KEY_SPAN)), dim3(256), 0, s, N, H * L, L, R, row_shift,
-                       col_ptr, ent_row, keys.p, d_flags.p);
+    // (view_factor > 1: L_in and H are those of the half-locus view, the CSC columns those of the caller's L_in / factor loci
+    // with H * factor haplotypes)
+    hipLaunchKernelGGL(make_keys_kernel, dim3(grid_for(N, 4 * KEY_SPAN)), dim3(256), 0, s, N, H * L, L / view_factor, R, row_shift,
+                       col_ptr, ent_row, keys.p, d_flags.p, view_factor > 1 ? H : 0u);
     stg.mark("1b make keys");
     GBRS_TRY(sort_keys64(sc, keys.p, keys2.p, N, row_shift + bits_for(R - 1), s));
     stg.mark("1c sort entries");

@@ -737,6 +737,8 @@ def test_em_mask_group_sets_vs_oracle(R, H, L, hi, min_rows, monkeypatch):
     o.run(tol=0.0, max_iters=5)
     words = {}
     for name, flags, env in (("sets", 0, {}), ("deterministic", 32, {}), ("no_sets", 512, {}),
+                             # 16 haplotypes as half-loci on the 8-haplotype kernels (built in round 4, not the default)
+                             ("half_loci", 0, {"GBRS_TUNING_HALF_LOCI": "1"}),
                              ("persistent", 0, {"GBRS_TUNING_PERSISTENT": "1", "GBRS_TUNING_PERSISTENT_GROUPS": "2",
                                                 "GBRS_TUNING_TILE_WORDS": "256"})):
         for k, v in env.items():
