@@ -1603,8 +1603,13 @@ __device__ __forceinline__ double mfma_own(const mfma_d4 &d0, const mfma_d4 &d1,
     return q < 4 ? d0[q] : q < 8 ? d1[q - 4] : d2[0];
 }
 
-// alpha sweep (forward_wave_kernel role 0, same stored quantities: x, 1/Z)
-template <int NSET>
+// alpha sweep (forward_wave_kernel role 0, same stored quantities: x, 1/Z).
+// NG (round 4): groups of 16 samples per wavefront; one load of the step's 27 operands serves all of them and the groups'
+// products and vector tails are independent instruction streams.  Built to test whether the operand traffic (320 + 320
+// streams of 14 KB per step at 256 samples) is what the chains of a large batch share: it is not - NG = 2 halves that
+// traffic and the wavefront count and the 256-sample pass takes the same 16.3-16.7 ms (smaller batches lose: a step is
+// twice as long).  GBRS_TUNING_HMM_MFMA_NG=2 selects it; parity-tested at 16-70 samples.
+template <int NSET, int NG>
 __global__ void __launch_bounds__(64)
 alpha_mfma_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *__restrict__ chroms,
                   const int32_t *__restrict__ order, const double *__restrict__ amat,
@@ -1615,54 +1620,65 @@ alpha_mfma_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *__re
     const int n = cd.n_genes;
     if (n <= 0) return;
     const int lane = threadIdx.x, g = lane >> 4;
-    const int sample = min((int)blockIdx.x * 16 + (lane & 15), n_samples - 1);
-    const int64_t g0 = (int64_t)sample * genes_per_sample + cd.gene_off;
     const int n_ord = min(n, cd.n_trans + 1) - 1;       // step i = o + 1 needs block o
     const int last_o = max(n_ord - 1, 0);
     const double *BLK = amat + cd.trans_off * (int64_t)MF_BLK;
-    const double *pe_row = peprob + g0 * S + 9 * g;     // + i * S: my states of gene i
-    double *x_row = xsum + g0 * S + 9 * g;
-    double *iz = invz + g0;
-    double y[MF_Q];
-    {
+    const double *pe_row[NG];                            // + i * S: my states of gene i
+    double *x_row[NG], *iz[NG];
+    double y[NG][MF_Q];
+#pragma unroll
+    for (int cg = 0; cg < NG; ++cg) {
+        const int sample = min(((int)blockIdx.x * NG + cg) * 16 + (lane & 15), n_samples - 1);   // past the end: shadows the last sample
+        const int64_t g0 = (int64_t)sample * genes_per_sample + cd.gene_off;
+        pe_row[cg] = peprob + g0 * S + 9 * g;
+        x_row[cg] = xsum + g0 * S + 9 * g;
+        iz[cg] = invz + g0;
         double e0[MF_Q], iv[MF_Q], x0[MF_Q];
         mfma_load_row(eprob + g0 * S + 9 * g, e0);
         mfma_load_row(init_vec + 9 * g, iv);
 #pragma unroll
         for (int q = 0; q < MF_Q; ++q) {
-            y[q] = exp(iv[q] + e0[q]);
+            y[cg][q] = exp(iv[q] + e0[q]);
             x0[q] = exp(iv[q]);                          // so that log(x) + e reproduces init + e
         }
-        mfma_store_row(x_row, x0);
+        mfma_store_row(x_row[cg], x0);
     }
-    double a[NSET][2 * MF_PAIRS], pe[NSET][MF_Q];
+    double a[NSET][2 * MF_PAIRS], pe[NSET][NG][MF_Q];
 #pragma unroll
     for (int u = 0; u < NSET; ++u) {
         const int ou = min(u, last_o);
         if (n_ord > 0) {
             mfma_load_block(BLK + (int64_t)HMM_BLK(ou) * MF_BLK, lane, a[u]);
-            mfma_load_row(pe_row + (int64_t)(ou + 1) * S, pe[u]);
+#pragma unroll
+            for (int cg = 0; cg < NG; ++cg) mfma_load_row(pe_row[cg] + (int64_t)(ou + 1) * S, pe[u][cg]);
         }
     }
-    auto step = [&](int o, const double (&ac)[2 * MF_PAIRS], const double (&pc)[MF_Q], double (&an)[2 * MF_PAIRS], double (&pn)[MF_Q]) {
-        mfma_d4 d0, d1, d2;
-        mfma_matvec(ac, y, d0, d1, d2);
-        double pe_now[MF_Q];
+    auto step = [&](int o, const double (&ac)[2 * MF_PAIRS], const double (&pc)[NG][MF_Q], double (&an)[2 * MF_PAIRS], double (&pn)[NG][MF_Q]) {
+        mfma_d4 d0[NG], d1[NG], d2[NG];
 #pragma unroll
-        for (int q = 0; q < MF_Q; ++q) pe_now[q] = pc[q];
+        for (int cg = 0; cg < NG; ++cg) mfma_matvec(ac, y[cg], d0[cg], d1[cg], d2[cg]);
+        double pe_now[NG][MF_Q];
+#pragma unroll
+        for (int cg = 0; cg < NG; ++cg)
+#pragma unroll
+            for (int q = 0; q < MF_Q; ++q) pe_now[cg][q] = pc[cg][q];
         // refill the set the previous step released (clamped index: past the end it re-reads the last block)
         const int of = min(o + NSET - 1, last_o);
         mfma_load_block(BLK + (int64_t)HMM_BLK(of) * MF_BLK, lane, an);
-        mfma_load_row(pe_row + (int64_t)(of + 1) * S, pn);
-        const double inv_z = fast_recip_pos(d2[1]);            // Z of the previous vector
-        if (g == 0) iz[o] = inv_z;
-        double x[MF_Q];
 #pragma unroll
-        for (int q = 0; q < MF_Q; ++q) {
-            x[q] = mfma_own(d0, d1, d2, q) * inv_z + TINY;
-            y[q] = x[q] * pe_now[q];
+        for (int cg = 0; cg < NG; ++cg) mfma_load_row(pe_row[cg] + (int64_t)(of + 1) * S, pn[cg]);
+#pragma unroll
+        for (int cg = 0; cg < NG; ++cg) {
+            const double inv_z = fast_recip_pos(d2[cg][1]);        // Z of the previous vector
+            if (g == 0) iz[cg][o] = inv_z;
+            double x[MF_Q];
+#pragma unroll
+            for (int q = 0; q < MF_Q; ++q) {
+                x[q] = mfma_own(d0[cg], d1[cg], d2[cg], q) * inv_z + TINY;
+                y[cg][q] = x[q] * pe_now[cg][q];
+            }
+            mfma_store_row(x_row[cg] + (int64_t)(o + 1) * S, x);
         }
-        mfma_store_row(x_row + (int64_t)(o + 1) * S, x);
     };
     int o = 0;
     for (; o + NSET <= n_ord; o += NSET) {
@@ -1673,16 +1689,19 @@ alpha_mfma_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *__re
     for (int u = 0; u < NSET - 1; ++u)
         if (o + u < n_ord) step(o + u, a[u], pe[u], a[(u + NSET - 1) % NSET], pe[(u + NSET - 1) % NSET]);
     // Z of the last vector: my nine states, then the four lane groups of my sample
-    double z = 0.0;
 #pragma unroll
-    for (int q = 0; q < MF_Q; ++q) z += y[q];
-    z += __shfl_xor(z, 16, 64);
-    z += __shfl_xor(z, 32, 64);
-    if (g == 0) iz[n_ord] = fast_recip_pos(z);
+    for (int cg = 0; cg < NG; ++cg) {
+        double z = 0.0;
+#pragma unroll
+        for (int q = 0; q < MF_Q; ++q) z += y[cg][q];
+        z += __shfl_xor(z, 16, 64);
+        z += __shfl_xor(z, 32, 64);
+        if (g == 0) iz[cg][n_ord] = fast_recip_pos(z);
+    }
 }
 
 // free-running backward sweep (backward_wave_kernel's quantities, rescaled on every step: bscale is general)
-template <int NSET>
+template <int NSET, int NG>
 __global__ void __launch_bounds__(64)
 backward_mfma_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *__restrict__ chroms,
                      const int32_t *__restrict__ order, const double *__restrict__ amat_t,
@@ -1692,52 +1711,63 @@ backward_mfma_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *_
     const int n = cd.n_genes;
     if (n <= 0) return;
     const int lane = threadIdx.x, g = lane >> 4;
-    const int sample = min((int)blockIdx.x * 16 + (lane & 15), n_samples - 1);
-    const int64_t g0 = (int64_t)sample * genes_per_sample + cd.gene_off;
     const double *BLK = amat_t + cd.trans_off * (int64_t)MF_BLK;
-    const double *pe_row = peprob + g0 * S + 9 * g;
-    double *b_row = bhat + g0 * S + 9 * g;
-    double *bs = bscale + g0;
-    double w[MF_Q];                                   // pe_{i+1} * bt_{i+1}
-    {
+    const double *pe_row[NG];
+    double *b_row[NG], *bs[NG];
+    double w[NG][MF_Q];                               // pe_{i+1} * bt_{i+1}
+#pragma unroll
+    for (int cg = 0; cg < NG; ++cg) {
+        const int sample = min(((int)blockIdx.x * NG + cg) * 16 + (lane & 15), n_samples - 1);
+        const int64_t g0 = (int64_t)sample * genes_per_sample + cd.gene_off;
+        pe_row[cg] = peprob + g0 * S + 9 * g;
+        b_row[cg] = bhat + g0 * S + 9 * g;
+        bs[cg] = bscale + g0;
         double one[MF_Q];
 #pragma unroll
         for (int q = 0; q < MF_Q; ++q) one[q] = 1.0;
-        mfma_load_row(pe_row + (int64_t)(n - 1) * S, w);
-        mfma_store_row(b_row + (int64_t)(n - 1) * S, one);
-        if (g == 0) bs[n - 1] = 1.0;
+        mfma_load_row(pe_row[cg] + (int64_t)(n - 1) * S, w[cg]);
+        mfma_store_row(b_row[cg] + (int64_t)(n - 1) * S, one);
+        if (g == 0) bs[cg][n - 1] = 1.0;
     }
     // order o <-> gene i = n-2-o, transition block i (the host checked n_trans >= n-1)
     const int n_ord = n - 1;
     const int last_o = max(n_ord - 1, 0);
-    double a[NSET][2 * MF_PAIRS], pe[NSET][MF_Q];
+    double a[NSET][2 * MF_PAIRS], pe[NSET][NG][MF_Q];
 #pragma unroll
     for (int u = 0; u < NSET; ++u) {
         const int i = n - 2 - min(u, last_o);
         if (n_ord > 0) {
             mfma_load_block(BLK + (int64_t)HMM_BLK(i) * MF_BLK, lane, a[u]);
-            mfma_load_row(pe_row + (int64_t)i * S, pe[u]);
+#pragma unroll
+            for (int cg = 0; cg < NG; ++cg) mfma_load_row(pe_row[cg] + (int64_t)i * S, pe[u][cg]);
         }
     }
-    auto step = [&](int o, const double (&ac)[2 * MF_PAIRS], const double (&pc)[MF_Q], double (&an)[2 * MF_PAIRS], double (&pn)[MF_Q]) {
+    auto step = [&](int o, const double (&ac)[2 * MF_PAIRS], const double (&pc)[NG][MF_Q], double (&an)[2 * MF_PAIRS], double (&pn)[NG][MF_Q]) {
         const int i = n - 2 - o;
-        mfma_d4 d0, d1, d2;
-        mfma_matvec(ac, w, d0, d1, d2);
-        double pe_now[MF_Q];
+        mfma_d4 d0[NG], d1[NG], d2[NG];
 #pragma unroll
-        for (int q = 0; q < MF_Q; ++q) pe_now[q] = pc[q];
+        for (int cg = 0; cg < NG; ++cg) mfma_matvec(ac, w[cg], d0[cg], d1[cg], d2[cg]);
+        double pe_now[NG][MF_Q];
+#pragma unroll
+        for (int cg = 0; cg < NG; ++cg)
+#pragma unroll
+            for (int q = 0; q < MF_Q; ++q) pe_now[cg][q] = pc[cg][q];
         const int in = n - 2 - min(o + NSET - 1, last_o);
         mfma_load_block(BLK + (int64_t)HMM_BLK(in) * MF_BLK, lane, an);
-        mfma_load_row(pe_row + (int64_t)in * S, pn);
-        const double r = fast_recip_pos(d2[1]);
-        if (g == 0) bs[i] = r;
-        double bh[MF_Q];
 #pragma unroll
-        for (int q = 0; q < MF_Q; ++q) {
-            bh[q] = mfma_own(d0, d1, d2, q) * r;
-            w[q] = bh[q] * pe_now[q];
+        for (int cg = 0; cg < NG; ++cg) mfma_load_row(pe_row[cg] + (int64_t)in * S, pn[cg]);
+#pragma unroll
+        for (int cg = 0; cg < NG; ++cg) {
+            const double r = fast_recip_pos(d2[cg][1]);
+            if (g == 0) bs[cg][i] = r;
+            double bh[MF_Q];
+#pragma unroll
+            for (int q = 0; q < MF_Q; ++q) {
+                bh[q] = mfma_own(d0[cg], d1[cg], d2[cg], q) * r;
+                w[cg][q] = bh[q] * pe_now[cg][q];
+            }
+            mfma_store_row(b_row[cg] + (int64_t)i * S, bh);
         }
-        mfma_store_row(b_row + (int64_t)i * S, bh);
     };
     int o = 0;
     for (; o + NSET <= n_ord; o += NSET) {
@@ -2312,6 +2342,12 @@ int hmm_make_logs(gbrs_hmm *h) {
 #ifndef HMM_NSET_M
 #define HMM_NSET_M 3      // register sets (transition blocks in flight) of the MFMA sweeps
 #endif
+#ifndef HMM_NSET_M2
+#define HMM_NSET_M2 3     // the same with two sample groups per wavefront
+#endif
+#ifndef HMM_MFMA_NG2_MIN
+#define HMM_MFMA_NG2_MIN (1 << 30)   // samples from which a wavefront of the MFMA sweeps carries two groups of 16: never by
+#endif                               // default - measured (round 4): 256 samples 16.3-16.7 ms either way, 128: 9.2 -> 12.0, 64: 6.9 -> 9.3
 
 #ifndef HMM_BLOCKED_MAX
 #define HMM_BLOCKED_MAX 2     // 36 states, at most this many samples: the blocked scan (the operators cost 36 columns per block)
@@ -2488,10 +2524,14 @@ int hmm_launch(gbrs_hmm *h) {
                                    h->amat_f.p, h->amat_b.p);
                 GBRS_HIP_CHECK(hipEventRecord(h->ev[1], sa));        // one-off table work stays outside the run's timing
             }
-            const dim3 mfma_grid((h->n_samples + 15) / 16, h->n_chrom);
+            // sample groups of 16 per wavefront of the MFMA sweeps: 2 from HMM_MFMA_NG2_MIN samples on (GBRS_TUNING_HMM_MFMA_NG = 1 / 2 forces)
+            int mfma_ng = h->n_samples >= HMM_MFMA_NG2_MIN ? 2 : 1;
+            if (const char *env = std::getenv("GBRS_TUNING_HMM_MFMA_NG"); env && (std::atoi(env) == 1 || std::atoi(env) == 2)) mfma_ng = std::atoi(env);
+            const dim3 mfma_grid((h->n_samples + 16 * mfma_ng - 1) / (16 * mfma_ng), h->n_chrom);
             launch_alpha = [=](hipStream_t st) {
                 if (mfma) {
-                    hipLaunchKernelGGL((alpha_mfma_kernel<HMM_NSET_M>), mfma_grid, dim3(64), 0, st, h->n_samples, h->total_genes,
+                    auto k = mfma_ng == 2 ? &alpha_mfma_kernel<HMM_NSET_M2, 2> : &alpha_mfma_kernel<HMM_NSET_M, 1>;
+                    hipLaunchKernelGGL(k, mfma_grid, dim3(64), 0, st, h->n_samples, h->total_genes,
                                        h->d_chroms.p, h->d_order.p, h->amat_f.p, h->eprob.p, h->peprob.p, h->init_vec.p,
                                        h->xsum.p, h->invz.p);
                     return;
@@ -2527,7 +2567,8 @@ int hmm_launch(gbrs_hmm *h) {
             };
             launch_back = [=](hipStream_t st) {
                 if (mfma) {
-                    hipLaunchKernelGGL((backward_mfma_kernel<HMM_NSET_M>), mfma_grid, dim3(64), 0, st, h->n_samples,
+                    auto k = mfma_ng == 2 ? &backward_mfma_kernel<HMM_NSET_M2, 2> : &backward_mfma_kernel<HMM_NSET_M, 1>;
+                    hipLaunchKernelGGL(k, mfma_grid, dim3(64), 0, st, h->n_samples,
                                        h->total_genes, h->d_chroms.p, h->d_order.p, h->amat_b.p, h->peprob.p, h->bhat.p,
                                        h->bscale.p);
                     return;

@@ -187,9 +187,9 @@ def test_hmm_full_size_properties():
     hmm.close()
 
 
-@pytest.mark.parametrize("n_samples", [1, 4, 5, 16, 25, 40])
+@pytest.mark.parametrize("n_samples,mfma_ng", [(1, 1), (4, 1), (5, 1), (16, 1), (25, 1), (40, 1), (16, 2), (25, 2), (40, 2), (70, 2)])
 @pytest.mark.parametrize("minus_one", [False, True], ids=["tprob_n", "tprob_n_minus_1"])
-def test_hmm_sample_batches_and_short_chromosomes(n_samples, minus_one, monkeypatch):
+def test_hmm_sample_batches_and_short_chromosomes(n_samples, mfma_ng, minus_one, monkeypatch):
     """8 founders (the single-wave kernels; from 16 samples on this test sends the alpha and backward sweeps
     through the 16-samples-per-wavefront MFMA kernels that large batches use): distinct samples in one launch, including batch sizes
     that leave a partly filled wave, chromosomes of 1, 2, 3 genes and lengths around the prefetch
@@ -198,6 +198,7 @@ def test_hmm_sample_batches_and_short_chromosomes(n_samples, minus_one, monkeypa
     from gbrs_amd.hmm import DiplotypeHMM
     from oracle import hmm_oracle
     monkeypatch.setenv("GBRS_TUNING_HMM_MFMA", "16")
+    monkeypatch.setenv("GBRS_TUNING_HMM_MFMA_NG", str(mfma_ng))   # round 4: one or two groups of 16 samples per wavefront of the sweeps
     monkeypatch.setenv("GBRS_TUNING_HMM_DLANES", "16")       # and the samples-on-lanes delta chain
     monkeypatch.setenv("GBRS_TUNING_HMM_BPLANES", "5")       # and the samples-on-lanes backpointers (partly filled wavefronts)
     lens = [1, 2, 3, 4, 5, 7, 63, 64, 65, 129, 200]
@@ -291,8 +292,8 @@ def test_hmm_large_batch_default_dispatch():
     hmm.close()
 
 
-@pytest.mark.parametrize("n_samples", [3, 21])
-def test_hmm_do_tables_sample_batches(n_samples, monkeypatch):
+@pytest.mark.parametrize("n_samples,mfma_ng", [(3, 1), (21, 1), (21, 2), (37, 2)])
+def test_hmm_do_tables_sample_batches(n_samples, mfma_ng, monkeypatch):
     """DO-like transition tables (entries down to exp(-69), structural zeros, a near-deterministic chain) and
     sparsely expressed samples, single-sample kernels (3) and the 16-samples-per-wave MFMA sweeps (21):
     every sample against the oracle."""
@@ -300,6 +301,7 @@ def test_hmm_do_tables_sample_batches(n_samples, monkeypatch):
     from gbrs_amd.hmm import DiplotypeHMM
     from oracle import hmm_oracle
     monkeypatch.setenv("GBRS_TUNING_HMM_MFMA", "16")
+    monkeypatch.setenv("GBRS_TUNING_HMM_MFMA_NG", str(mfma_ng))
     monkeypatch.setenv("GBRS_TUNING_HMM_DLANES", "16")       # and the samples-on-lanes delta chain
     lens = [1, 2, 17, 64, 150]
     probs = [synth.make_hmm_problem(H=8, genes_per_chrom=lens, seed=4321 + s, style="do",
