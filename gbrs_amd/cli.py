@@ -80,6 +80,9 @@ def build_parser():
     wk.add_argument('--jobs', required=True, type=_existing, help='JSON list of samples, see gbrs_amd/worker.py')
     wk.add_argument('-v', '--verbose', action='count', default=0)
     wk.add_argument('--device', type=int, default=0)
+    wk.add_argument('--devices', default=None,
+                    help='comma-separated HIP device ordinals, or "all": one resident worker process per entry, the samples '
+                         'dealt round-robin (BASELINE configs[3]: 8 samples, one per GPU; replicas only, no collective)')
     return ap
 
 
@@ -123,7 +126,14 @@ def main(argv=None) -> int:
                      one_shot=True)         # the command builds one handle and exits: GBRS_EM_ONE_SHOT
         elif args.command == 'worker':
             from .worker import main as worker_main
-            worker_main(args.jobs, device=args.device)
+            devices = None
+            if args.devices:
+                if args.devices == 'all':
+                    from . import _lib
+                    devices = list(range(max(1, int(_lib.load().gbrs_device_count()))))
+                else:
+                    devices = [int(x) for x in args.devices.split(',') if x.strip() != '']
+            worker_main(args.jobs, device=args.device, devices=devices)
         elif args.command == 'compress':
             from .compress import compress
             files = [f for x in args.emase_files for f in x.split(',')]

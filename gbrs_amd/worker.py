@@ -6,6 +6,7 @@ order; gbrs_utils.py:420-447) for every sample.  The three steps are the very fu
 (gbrs_amd.quantify.quantify, gbrs_amd.hmm.reconstruct): same files out.
 
     python -m gbrs_amd worker --jobs jobs.json [--device 0]
+    python -m gbrs_amd worker --jobs jobs.json --devices 0,1,2,3,4,5,6,7     # one worker process per GPU, samples dealt round-robin
 
 jobs.json: a list of objects {"alignment_file", "outbase", "tprob_file", and optionally "group_file", "length_file",
 "avec_file", "gpos_file", "expr_threshold", "sigma", "pseudocount", "max_iters", "tolerance", "diploid": true|false};
@@ -112,10 +113,65 @@ def run_jobs(jobs, device: int = 0, emit=print):
     return done, time.perf_counter() - t0
 
 
-def main(jobs_file: str, device: int = 0) -> int:
+def run_jobs_on_devices(jobs, devices, emit=print):
+    """BASELINE configs[3] as a product path: the samples of `jobs` spread over several GPUs, ONE resident worker process
+    per entry of `devices` (a device may be listed twice: two workers share it), no collective and no torch - samples are
+    independent (replicas only).  Jobs are handed out round-robin (sample k to worker k mod N), every child is
+    `python -m gbrs_amd worker --jobs <its share> --device d`; its per-sample JSON lines are relayed as they come."""
+    import subprocess
+    import sys
+    import tempfile
+    import threading
+    n = len(devices)
+    shares = [[j for k, j in enumerate(jobs) if k % n == w] for w in range(n)]
+    tmp = tempfile.mkdtemp(prefix='gbrs_worker_')
+    procs, results, lock = [], [], threading.Lock()
+    t0 = time.perf_counter()
+    for w, (dev, share) in enumerate(zip(devices, shares)):
+        if not share:
+            continue
+        jf = os.path.join(tmp, f'jobs_{w}.json')
+        with open(jf, 'w') as fh:
+            json.dump(share, fh)
+        procs.append((w, dev, subprocess.Popen([sys.executable, '-m', 'gbrs_amd', 'worker', '--jobs', jf, '--device', str(dev)],
+                                               stdout=subprocess.PIPE, text=True)))
+
+    def relay(w, dev, proc):
+        for line in proc.stdout:
+            if not line.startswith('{'):
+                continue                      # (EMfactory.run's iteration table)
+            rec = json.loads(line)
+            if 'summary' in rec:
+                continue
+            rec['worker'], rec['device'] = w, dev
+            with lock:
+                results.append(rec)
+                if emit:
+                    emit(json.dumps(rec), flush=True)
+        proc.wait()
+    threads = [threading.Thread(target=relay, args=p) for p in procs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    import shutil
+    shutil.rmtree(tmp, ignore_errors=True)
+    failed = [p.returncode for _, _, p in procs if p.returncode != 0]
+    if failed:
+        raise RuntimeError(f'{len(failed)} worker process(es) failed: exit codes {failed}')
+    return results, time.perf_counter() - t0
+
+
+def main(jobs_file: str, device: int = 0, devices=None) -> int:
     with open(jobs_file) as fh:
         jobs = json.load(fh)
     t_start = float(os.environ['GBRS_T0']) if os.getenv('GBRS_T0') else None
+    if devices:
+        done, seconds = run_jobs_on_devices(jobs, devices)
+        summary = {'samples': len(done), 'failed': sum('error' in d for d in done) + (len(jobs) - len(done)),
+                   'seconds': seconds, 'workers': len(devices), 'samples_per_s': len(done) / seconds if seconds > 0 else None}
+        print(json.dumps({'summary': summary}), flush=True)
+        return 0
     done, seconds = run_jobs(jobs, device)
     summary = {'samples': len(done), 'failed': sum('error' in d for d in done), 'seconds_in_worker': seconds}
     if t_start is not None:

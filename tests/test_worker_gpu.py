@@ -83,3 +83,32 @@ def test_worker_equals_the_three_commands(tmp_path, monkeypatch):
                     np.testing.assert_allclose(za[c], zb[c], rtol=1e-8, atol=1e-300)
     # the samples differ (the worker did not hand the first sample's state to the second)
     assert not filecmp.cmp(tmp_path / "wrk0.multiway.genes.tpm", tmp_path / "wrk1.multiway.genes.tpm", shallow=False)
+
+
+def test_worker_processes_per_device(tmp_path, monkeypatch):
+    """`gbrs worker --devices d0,d1,...`: one resident worker process per listed device (BASELINE configs[3]: samples one
+    per GPU, replicas only); on a one-GPU box the list names device 0 twice.  Three samples dealt round-robin to two
+    processes: every sample reported once, its files there, calls equal to a single worker's."""
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import e2e_bench
+    from gbrs_amd import cli
+    from gbrs_amd.worker import run_jobs, run_jobs_on_devices
+    monkeypatch.setenv("GBRS_DATA", str(tmp_path))
+    monkeypatch.setenv("PYTHONPATH", ROOT)
+    samples = [_write_sample(tmp_path, seed, rows=20_000, loci=400) for seed in (7, 8, 9)]
+    aln, grp, lens = samples[0]
+    assert cli.main(["quantify", "-i", aln, "-g", grp, "-L", lens, "-o", str(tmp_path / "seed")]) == 0
+    rec, _ = e2e_bench.write_reconstruct_inputs(str(tmp_path), str(tmp_path / "seed.multiway.genes.tpm"))
+
+    def jobs(tag):
+        return [dict(alignment_file=a, group_file=g, length_file=l, outbase=str(tmp_path / f"{tag}{k}"),
+                     tprob_file=rec["tprob"], avec_file=rec["avecs"], gpos_file=rec["gpos"]) for k, (a, g, l) in enumerate(samples)]
+    lines = []
+    done, seconds = run_jobs_on_devices(jobs("multi"), [0, 0], emit=lambda text, flush=True: lines.append(text))
+    assert sorted(d["outbase"] for d in done) == sorted(j["outbase"] for j in jobs("multi"))
+    assert sorted(d["worker"] for d in done) == [0, 0, 1] and not any("error" in d for d in done)
+    single, _ = run_jobs(jobs("single"), device=0, emit=None)
+    assert not any("error" in d for d in single)
+    for k in range(3):
+        assert filecmp.cmp(tmp_path / f"multi{k}.genotypes.tsv", tmp_path / f"single{k}.genotypes.tsv", shallow=False)
+        assert os.path.getsize(tmp_path / f"multi{k}.diploid.genes.tpm") > 0
