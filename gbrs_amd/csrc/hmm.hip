@@ -185,15 +185,16 @@ __global__ void __launch_bounds__(64)
 emission_batch_kernel(int64_t n_genes, int n_samples, int samples_per_block, const double *__restrict__ expr,
                       const double *__restrict__ avecs, const uint8_t *__restrict__ has_avec,
                       const double *__restrict__ init_vec, double expr_threshold, double sigma,
-                      double *__restrict__ eprob, double *__restrict__ peprob) {
+                      double *__restrict__ eprob, double *__restrict__ peprob,
+                      int64_t gene_begin, int64_t gene_end /* the launch covers genes [gene_begin, gene_end) of the n_genes */) {
     constexpr int H = HT, S = H * (H + 1) / 2, HH = H * H;
     static_assert(HT == EM_LANES, "lane q of a gene owns specificity row q and profile element q");
     constexpr int SPL = (S + EM_LANES - 1) / EM_LANES;
     constexpr int av_stride = HH + 1, ex_stride = H + 1, out_stride = S + 1;
     __shared__ double l_av[EM_GENES * av_stride], l_ex[EM_GENES * ex_stride], l_u[EM_GENES * ex_stride],
         l_out[EM_GENES * out_stride], l_pe[EM_GENES * out_stride], l_init[2 * S];
-    const int64_t g0 = (int64_t)blockIdx.x * EM_GENES;
-    const int ng = (int)min((int64_t)EM_GENES, n_genes - g0);
+    const int64_t g0 = gene_begin + (int64_t)blockIdx.x * EM_GENES;
+    const int ng = (int)min((int64_t)EM_GENES, gene_end - g0);
     const int s_begin = blockIdx.y * samples_per_block, s_end = min(n_samples, s_begin + samples_per_block);
     const int tid = threadIdx.x;
     for (int x = tid; x < ng * HH; x += 64) l_av[(x / HH) * av_stride + x % HH] = avecs[g0 * HH + x];
@@ -1829,7 +1830,8 @@ __device__ __forceinline__ void dl_from(const double (&t)[DL_GROUPS], const doub
 __global__ void __launch_bounds__(64 * DL_WAVES)
 delta_lanes_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *__restrict__ chroms,
                    const int32_t *__restrict__ order, const double *__restrict__ tprob, const double *__restrict__ eprob,
-                   const double *__restrict__ init_vec, double *__restrict__ delta, int32_t *__restrict__ last_state) {
+                   const double *__restrict__ init_vec, double *__restrict__ delta, int32_t *__restrict__ last_state,
+                   int n_chrom /* of the handle: the launch may cover a group of them */) {
     constexpr int S = MF_S, BLK = S * S;
     __shared__ __attribute__((aligned(16))) double dbuf[2][DL_SAMPLES][DL_STRIDE];
     const int chrom = order[blockIdx.y];
@@ -1906,7 +1908,7 @@ delta_lanes_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *__r
             const double v = dbuf[cur][c][s2];
             if (v > bv) { bv = v; bk = s2; }
         }
-        last_state[(int64_t)sample_raw * gridDim.y + chrom] = bk;
+        last_state[(int64_t)sample_raw * n_chrom + chrom] = bk;
     }
 }
 
@@ -1953,13 +1955,17 @@ constexpr int POST_GROUPS = 4;
 __global__ void __launch_bounds__(1024)
 posterior_kernel(int S, int OUT_ROWS, int64_t n_rows, const double *__restrict__ xsum,
                  const double *__restrict__ peprob, const double *__restrict__ invz,
-                 const double *__restrict__ bhat, double *__restrict__ gamma) {
+                 const double *__restrict__ bhat, double *__restrict__ gamma,
+                 int64_t gene_begin, int64_t range_len, int64_t genes_per_sample) {
+    // n_rows rows are walked: row v is gene gene_begin + v % range_len of sample v / range_len (the whole handle:
+    // gene_begin 0, range_len = genes_per_sample; a chromosome group of the pipelined batch pass: its gene range)
     extern __shared__ double lds[];               // g[POST_GROUPS][OUT_ROWS * S], norm[POST_GROUPS * OUT_ROWS]
     const int per = OUT_ROWS * S;
     double *l_g = lds, *l_norm = lds + POST_GROUPS * per;
     const int64_t r0 = (int64_t)blockIdx.x * OUT_ROWS * POST_GROUPS;
     const int t = threadIdx.x;
     const int row = t / S;
+    auto actual = [&](int64_t v) { return (v / range_len) * genes_per_sample + gene_begin + v % range_len; };
     double ah[POST_GROUPS], bh[POST_GROUPS];
     bool live[POST_GROUPS];
 #pragma unroll
@@ -1969,8 +1975,8 @@ posterior_kernel(int S, int OUT_ROWS, int64_t n_rows, const double *__restrict__
         live[q] = t < nr * S;
         ah[q] = bh[q] = 0.0;
         if (live[q]) {
-            const int64_t o = rq * S + t;
-            ah[q] = (xsum[o] * peprob[o]) * invz[rq + row];      // alpha-hat = y / Z, y = x * pe as in the sweep
+            const int64_t ar = actual(rq + row), o = ar * S + (t - row * S);
+            ah[q] = (xsum[o] * peprob[o]) * invz[ar];            // alpha-hat = y / Z, y = x * pe as in the sweep
             bh[q] = bhat[o];
         }
     }
@@ -1988,7 +1994,7 @@ posterior_kernel(int S, int OUT_ROWS, int64_t n_rows, const double *__restrict__
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < POST_GROUPS; ++q)
-        if (live[q]) gamma[(r0 + (int64_t)q * OUT_ROWS) * S + t] = ah[q] * bh[q] / l_norm[q * OUT_ROWS + row];
+        if (live[q]) gamma[actual(r0 + (int64_t)q * OUT_ROWS + row) * S + (t - row * S)] = ah[q] * bh[q] / l_norm[q * OUT_ROWS + row];
 }
 
 // The reference's log-domain intermediates, one thread per (sample, gene, state); made on the first
@@ -2051,18 +2057,19 @@ backtrace_write_kernel(int S, int64_t genes_per_sample, int64_t bp_per_sample, i
                        int64_t chunks_per_sample, int n_chrom, const ChromDesc *__restrict__ chroms,
                        const uint16_t *__restrict__ bp, const uint16_t *__restrict__ exit_map,
                        const int32_t *__restrict__ last_state, int32_t *__restrict__ states,
-                       int32_t *__restrict__ calls) {
+                       int32_t *__restrict__ calls, int chrom_base /* the launch covers chromosomes chrom_base + blockIdx.y */) {
     extern __shared__ uint16_t stage[];        // max(BT_B, chunks above) * S maps, then BT_B path entries
-    const ChromDesc cd = chroms[blockIdx.y];
+    const int chrom = chrom_base + (int)blockIdx.y;
+    const ChromDesc cd = chroms[chrom];
     const int sample = blockIdx.z;
     const int n = cd.n_genes;
     const int m = min(n, cd.n_trans);
     const int n_chunks = (m + BT_B - 1) / BT_B;
     const int c = blockIdx.x;
     if (c >= max(n_chunks, 1)) return;
-    int32_t *ST = states + (int64_t)sample * states_per_sample + cd.gene_off + blockIdx.y;
+    int32_t *ST = states + (int64_t)sample * states_per_sample + cd.gene_off + chrom;
     int32_t *CL = calls + (int64_t)sample * genes_per_sample + cd.gene_off;
-    const int last = last_state[(int64_t)sample * n_chrom + blockIdx.y];
+    const int last = last_state[(int64_t)sample * n_chrom + chrom];
     if (c == 0) {
         for (int i = m + threadIdx.x; i < n; i += 64) CL[i] = -1;
         if (threadIdx.x == 0) ST[m] = last;
@@ -2240,6 +2247,17 @@ struct gbrs_hmm {
     DevBuf<ChromDesc> d_vfwd, d_vbwd;         // the blocks as descriptors of the forward / delta and of the backward chains
     hipStream_t stream_h[3] = {nullptr, nullptr, nullptr};   // the direct chains of alpha / backward / delta
     hipEvent_t ev_head[3] = {nullptr, nullptr, nullptr};
+    // Pipelined batch pass (round 4, hmm_launch_groups): the chromosomes in two groups of consecutive chromosomes, each with
+    // its own emission -> chains -> posterior / backtrace pipeline on its own three streams, so that the emission of the
+    // second group and the posteriors / backtraces of whichever group is done run beside the chains that set the pass's length.
+    bool emission_pending = false;            // gbrs_hmm_set_expression left the emission kernel to the next run
+    double em_thr = 0.0, em_sigma = 0.0;
+    int n_groups = 0;
+    int grp_lo[2] = {0, 0}, grp_hi[2] = {0, 0}, grp_order_off[2] = {0, 0}, grp_max_bp[2] = {0, 0};
+    DevBuf<int32_t> d_order_grp;              // per group: its chromosomes, longest first
+    hipStream_t stream_g[3] = {nullptr, nullptr, nullptr};   // the second group's streams (the first uses stream / stream_b / stream_c)
+    hipEvent_t gev_em[2] = {nullptr, nullptr}, gev_b[2] = {nullptr, nullptr}, gev_c[2] = {nullptr, nullptr},
+               gev_done[2] = {nullptr, nullptr}, gev_start = nullptr;
     DevBuf<double> g_f, g_b, g_d, inj_f, inj_b, inj_d;   // block operators [sample][block][36][36], boundary vectors [sample][block][36]
     DevBuf<int32_t> e_f, e_b;                 // power-of-two exponents of the operators' columns
 };
@@ -2275,7 +2293,19 @@ void launch_posterior(gbrs_hmm *h, hipStream_t st) {
     const dim3 grid((unsigned)((rows + per_block - 1) / per_block)), block(((out_rows * S + 63) / 64) * 64);
     const size_t lds = (size_t)POST_GROUPS * (out_rows * S + out_rows) * sizeof(double);
     hipLaunchKernelGGL(posterior_kernel, grid, block, lds, st, S, out_rows, rows, h->xsum.p, h->peprob.p, h->invz.p,
-                       h->bhat.p, h->gamma.p);
+                       h->bhat.p, h->gamma.p, (int64_t)0, h->total_genes, h->total_genes);
+}
+
+// the same over the genes [gene_begin, gene_begin + range_len) of every sample
+void launch_posterior_range(gbrs_hmm *h, hipStream_t st, int64_t gene_begin, int64_t range_len) {
+    const int S = h->S;
+    const int64_t rows = range_len * h->n_samples;
+    if (rows <= 0) return;
+    const int out_rows = std::max(1, 1024 / S), per_block = out_rows * POST_GROUPS;
+    const dim3 grid((unsigned)((rows + per_block - 1) / per_block)), block(((out_rows * S + 63) / 64) * 64);
+    const size_t lds = (size_t)POST_GROUPS * (out_rows * S + out_rows) * sizeof(double);
+    hipLaunchKernelGGL(posterior_kernel, grid, block, lds, st, S, out_rows, rows, h->xsum.p, h->peprob.p, h->invz.p,
+                       h->bhat.p, h->gamma.p, gene_begin, range_len, h->total_genes);
 }
 
 void launch_logs(gbrs_hmm *h, int parts, hipStream_t st) {
@@ -2461,10 +2491,189 @@ int hmm_prepare_blocks(gbrs_hmm *h) {
     return GBRS_OK;
 }
 
+// The emission kernel gbrs_hmm_set_expression would have launched (all genes), when a deferred one has to be made up
+// outside the pipelined pass (a get() of the emissions before any run, or a run that takes another path).
+int hmm_flush_emission(gbrs_hmm *h) {
+    if (!h->emission_pending) return GBRS_OK;
+    const dim3 grid((unsigned)((h->total_genes + EM_GENES - 1) / EM_GENES), (unsigned)((h->n_samples + EM_BATCH_SPB - 1) / EM_BATCH_SPB));
+    hipLaunchKernelGGL(emission_batch_kernel<EM_LANES>, grid, dim3(64), 0, h->stream, h->total_genes, h->n_samples,
+                       EM_BATCH_SPB, h->expr.p, h->avecs.p, h->has_avec.p, h->init_vec.p, h->em_thr, h->em_sigma,
+                       h->eprob.p, h->peprob.p, (int64_t)0, h->total_genes);
+    GBRS_HIP_CHECK(hipGetLastError());
+    GBRS_HIP_CHECK(hipStreamSynchronize(h->stream));
+    h->emission_pending = false;
+    h->pe_ready = true;
+    return GBRS_OK;
+}
+
+#ifndef HMM_PIPE_MIN
+// Samples from which a batch pass runs as two pipelined chromosome groups (emission of group 2 beside the sweeps of group 1).
+// Parity-green and measured slower on one MI355X (256 samples 19.75-19.88 against 16.43-16.53 ms, 128: 13.14-13.18 against
+// 9.21-9.31; profiles/r04_hmm_experiments.txt item 4), so never by default: GBRS_TUNING_HMM_PIPELINE=<samples> switches it on.
+#define HMM_PIPE_MIN (1 << 30)
+#endif
+#ifndef HMM_PIPE_FIRST_PERCENT
+#define HMM_PIPE_FIRST_PERCENT 30   // share of the genes in the group that goes first (the one with the longest chromosome)
+#endif
+
+int hmm_prepare_groups(gbrs_hmm *h) {
+    if (h->n_groups) return GBRS_OK;
+    const int nc = h->n_chrom;
+    // two runs of consecutive chromosomes (a group's genes are one range of the gene axis); the cut that puts about
+    // HMM_PIPE_FIRST_PERCENT of the genes beside the longest chromosome, and that group goes first
+    int longest = 0;
+    for (int c = 1; c < nc; ++c)
+        if (h->chroms[c].n_genes > h->chroms[longest].n_genes) longest = c;
+    int pct = HMM_PIPE_FIRST_PERCENT;
+    if (const char *env = std::getenv("GBRS_TUNING_HMM_PIPE_FIRST"); env && std::atoi(env) > 0 && std::atoi(env) < 100) pct = std::atoi(env);
+    const int64_t want = h->total_genes * pct / 100;
+    int cut = 1;
+    if (2 * (int64_t)h->chroms[longest].gene_off <= h->total_genes) {      // longest in the front half: first group = [0, cut)
+        int64_t acc = 0;
+        for (cut = 0; cut < nc - 1; ++cut) {
+            acc += h->chroms[cut].n_genes;
+            if (cut >= longest && acc >= want) { ++cut; break; }
+        }
+        cut = std::max(1, std::min(cut, nc - 1));
+        h->grp_lo[0] = 0; h->grp_hi[0] = cut; h->grp_lo[1] = cut; h->grp_hi[1] = nc;
+    } else {                                                               // first group = [cut, nc)
+        int64_t acc = 0;
+        for (cut = nc - 1; cut > 0; --cut) {
+            acc += h->chroms[cut].n_genes;
+            if (cut <= longest && acc >= want) break;
+        }
+        cut = std::max(1, std::min(cut, nc - 1));
+        h->grp_lo[0] = cut; h->grp_hi[0] = nc; h->grp_lo[1] = 0; h->grp_hi[1] = cut;
+    }
+    std::vector<int32_t> order;
+    for (int g = 0; g < 2; ++g) {
+        std::vector<int32_t> mine;
+        for (int c = h->grp_lo[g]; c < h->grp_hi[g]; ++c) mine.push_back(c);
+        std::stable_sort(mine.begin(), mine.end(), [&](int a, int b) { return h->chroms[a].n_genes > h->chroms[b].n_genes; });
+        h->grp_order_off[g] = (int)order.size();
+        order.insert(order.end(), mine.begin(), mine.end());
+        int mb = 0;
+        for (int c : mine) mb = std::max(mb, std::min(h->chroms[c].n_genes, h->chroms[c].n_trans));
+        h->grp_max_bp[g] = mb;
+    }
+    GBRS_TRY(h->d_order_grp.alloc(order.size()));
+    GBRS_HIP_CHECK(hipMemcpy(h->d_order_grp.p, order.data(), order.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    for (auto &st : h->stream_g) GBRS_HIP_CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    for (hipEvent_t *e : {&h->gev_em[0], &h->gev_em[1], &h->gev_b[0], &h->gev_b[1], &h->gev_c[0], &h->gev_c[1], &h->gev_done[0], &h->gev_done[1]})
+        GBRS_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
+    GBRS_HIP_CHECK(hipEventCreate(&h->gev_start));
+    h->n_groups = 2;
+    return GBRS_OK;
+}
+
+// A large batch of 36-state samples as two pipelined chromosome groups (see gbrs_hmm above).  Same kernels, same
+// arithmetic and stored quantities as the one-group pass of hmm_launch - only the launches are per group.
+int hmm_launch_groups(gbrs_hmm *h) {
+    constexpr int S = MF_S;
+    GBRS_TRY(hmm_prepare_groups(h));
+    hipStream_t sa = h->stream;
+    if (!h->amat_f.p) {
+        GBRS_TRY(h->amat_f.alloc((size_t)h->total_trans * MF_BLK));
+        GBRS_TRY(h->amat_b.alloc((size_t)h->total_trans * MF_BLK));
+        hipLaunchKernelGGL(mfma_blocks_kernel, dim3(4096), dim3(256), 0, sa, h->total_trans, h->tprob.p, h->amat_f.p, h->amat_b.p);
+    }
+    h->logs_ready = false;
+    h->free_backward = true;
+    h->last_blocked = false;
+    GBRS_HIP_CHECK(hipEventRecord(h->gev_start, sa));
+    GBRS_HIP_CHECK(hipEventRecord(h->ev[1], sa));
+    const int ns = h->n_samples;
+    int bpl_min = HMM_BPL_MIN;
+    if (const char *env = std::getenv("GBRS_TUNING_HMM_BPLANES"); env) bpl_min = std::atoi(env) > 0 ? std::atoi(env) : INT_MAX;
+    for (int g = 0; g < 2; ++g) {
+        hipStream_t s0 = g == 0 ? h->stream : h->stream_g[0], s1 = g == 0 ? h->stream_b : h->stream_g[1],
+                    s2 = g == 0 ? h->stream_c : h->stream_g[2];
+        const int c_lo = h->grp_lo[g], c_hi = h->grp_hi[g], ncg = c_hi - c_lo;
+        if (ncg <= 0) continue;
+        const int64_t gene_lo = h->chroms[c_lo].gene_off;
+        const int64_t gene_hi = h->chroms[c_hi - 1].gene_off + h->chroms[c_hi - 1].n_genes;
+        const int32_t *ord = h->d_order_grp.p + h->grp_order_off[g];
+        if (g > 0) GBRS_HIP_CHECK(hipStreamWaitEvent(s0, h->gev_start, 0));
+        // emission of the group's genes
+        {
+            const dim3 grid((unsigned)((gene_hi - gene_lo + EM_GENES - 1) / EM_GENES), (unsigned)((ns + EM_BATCH_SPB - 1) / EM_BATCH_SPB));
+            hipLaunchKernelGGL(emission_batch_kernel<EM_LANES>, grid, dim3(64), 0, s0, h->total_genes, ns, EM_BATCH_SPB, h->expr.p,
+                               h->avecs.p, h->has_avec.p, h->init_vec.p, h->em_thr, h->em_sigma, h->eprob.p, h->peprob.p,
+                               gene_lo, gene_hi);
+            GBRS_HIP_CHECK(hipEventRecord(h->gev_em[g], s0));
+        }
+        GBRS_HIP_CHECK(hipStreamWaitEvent(s1, h->gev_em[g], 0));
+        GBRS_HIP_CHECK(hipStreamWaitEvent(s2, h->gev_em[g], 0));
+        const dim3 mfma_grid((ns + 15) / 16, ncg);
+        hipLaunchKernelGGL((alpha_mfma_kernel<HMM_NSET_M, 1>), mfma_grid, dim3(64), 0, s0, ns, h->total_genes, h->d_chroms.p, ord,
+                           h->amat_f.p, h->eprob.p, h->peprob.p, h->init_vec.p, h->xsum.p, h->invz.p);
+        if (g == 0) GBRS_HIP_CHECK(hipEventRecord(h->ev[2], s0));
+        hipLaunchKernelGGL((backward_mfma_kernel<HMM_NSET_M, 1>), mfma_grid, dim3(64), 0, s1, ns, h->total_genes, h->d_chroms.p, ord,
+                           h->amat_b.p, h->peprob.p, h->bhat.p, h->bscale.p);
+        GBRS_HIP_CHECK(hipEventRecord(h->gev_b[g], s1));
+        hipLaunchKernelGGL(delta_lanes_kernel, dim3((ns + DL_SAMPLES - 1) / DL_SAMPLES, ncg), dim3(64 * DL_WAVES), 0, s2, ns,
+                           h->total_genes, h->d_chroms.p, ord, h->tprob.p, h->eprob.p, h->init_vec.p, h->delta.p, h->last_state.p,
+                           h->n_chrom);
+        if (h->grp_max_bp[g] > 0) {
+            if (ns >= bpl_min) {
+                const int per_wg = std::min(64 * BPL_WAVES, ((ns + 63) / 64) * 64);
+                hipLaunchKernelGGL((viterbi_bp_lanes_kernel<MF_S>), dim3(h->grp_max_bp[g], ncg, (ns + per_wg - 1) / per_wg), dim3(per_wg), 0,
+                                   s2, ns, h->total_genes, h->total_bp, h->d_chroms.p + c_lo, h->tprob.p, h->delta.p, h->bp.p);
+            } else {
+                hipLaunchKernelGGL(viterbi_bp_kernel, dim3(h->grp_max_bp[g], ncg), dim3(256), (size_t)S * (S + 1) * sizeof(double), s2,
+                                   S, ns, h->total_genes, h->total_bp, h->d_chroms.p + c_lo, h->tprob.p, h->delta.p, h->bp.p);
+            }
+        }
+        if (g == 0) GBRS_HIP_CHECK(hipEventRecord(h->ev_c1, s2));
+        {
+            const int bt_chunks = std::max(1, (h->grp_max_bp[g] + BT_B - 1) / BT_B);
+            const dim3 bt_grid(bt_chunks, ncg, ns);
+            hipLaunchKernelGGL(backtrace_maps_kernel, bt_grid, dim3(64), (size_t)BT_B * S * sizeof(uint16_t), s2, S, h->total_bp,
+                               h->total_chunks, h->d_chroms.p + c_lo, h->bp.p, h->bt_exit.p);
+            hipLaunchKernelGGL(backtrace_write_kernel, bt_grid, dim3(64), ((size_t)std::max(BT_B, bt_chunks) * S + BT_B) * sizeof(uint16_t),
+                               s2, S, h->total_genes, h->total_bp, h->total_genes + h->n_chrom, h->total_chunks, h->n_chrom,
+                               h->d_chroms.p, h->bp.p, h->bt_exit.p, h->last_state.p, h->states.p, h->calls.p, c_lo);
+        }
+        GBRS_HIP_CHECK(hipEventRecord(h->gev_c[g], s2));
+        GBRS_HIP_CHECK(hipStreamWaitEvent(s0, h->gev_b[g], 0));
+        launch_posterior_range(h, s0, gene_lo, gene_hi - gene_lo);
+        if (g == 0) GBRS_HIP_CHECK(hipEventRecord(h->ev[3], s0));
+        GBRS_HIP_CHECK(hipStreamWaitEvent(s0, h->gev_c[g], 0));
+        GBRS_HIP_CHECK(hipEventRecord(h->gev_done[g], s0));
+    }
+    GBRS_HIP_CHECK(hipStreamWaitEvent(sa, h->gev_done[0], 0));
+    GBRS_HIP_CHECK(hipStreamWaitEvent(sa, h->gev_done[1], 0));
+    GBRS_HIP_CHECK(hipEventRecord(h->ev[4], sa));
+    GBRS_HIP_CHECK(hipGetLastError());
+    GBRS_HIP_CHECK(hipStreamSynchronize(sa));
+    h->emission_pending = false;
+    h->pe_ready = true;
+    float ms = 0.f, ms2 = 0.f;
+    // (first group's alpha / delta + backpointers; first group's backward + posterior; whole pass incl. both emissions)
+    if (hipEventElapsedTime(&ms, h->ev[1], h->ev[2]) == hipSuccess && hipEventElapsedTime(&ms2, h->ev[1], h->ev_c1) == hipSuccess)
+        h->t_fwd = std::max(ms, ms2);
+    if (hipEventElapsedTime(&ms, h->ev[1], h->ev[3]) == hipSuccess) h->t_bwd = ms;
+    h->t_bt = 0.0;
+    if (hipEventElapsedTime(&ms, h->ev[1], h->ev[4]) == hipSuccess) h->t_run = ms;
+    return GBRS_OK;
+}
+
 // SS_WAVE > 0: the single-wave chain kernels for that (even, <= 64) state count; otherwise KMAX / MAXT /
 // EXACT select the quad chains (EXACT, S = 4*KMAX > 64) or the generic multi-wave kernels.
 template <int SS_WAVE, int KMAX, int MAXT, bool EXACT>
 int hmm_launch(gbrs_hmm *h) {
+    if (h->emission_pending) {
+        // a large 36-state batch whose emission gbrs_hmm_set_expression left to this run: two pipelined chromosome groups,
+        // provided the batch takes the kernels that pass is made of (MFMA sweeps, samples-on-lanes delta chain)
+        if constexpr (SS_WAVE == MF_S) {
+            int mfma_min = HMM_MFMA_MIN, dl_min = HMM_DLANES_MIN;
+            if (const char *env = std::getenv("GBRS_TUNING_HMM_MFMA"); env) mfma_min = std::atoi(env) > 0 ? std::atoi(env) : INT_MAX;
+            if (const char *env = std::getenv("GBRS_TUNING_HMM_DLANES"); env) dl_min = std::atoi(env) > 0 ? std::atoi(env) : INT_MAX;
+            const char *ng = std::getenv("GBRS_TUNING_HMM_MFMA_NG");
+            if (h->n_samples >= mfma_min && h->n_samples >= dl_min && !(ng && std::atoi(ng) == 2)) return hmm_launch_groups(h);
+        }
+        GBRS_TRY(hmm_flush_emission(h));
+    }
     const int S = h->S;
     const int threads = ((S * 4 + 63) / 64) * 64;
     const int64_t rows = h->total_genes * h->n_samples;
@@ -2477,7 +2686,7 @@ int hmm_launch(gbrs_hmm *h) {
                            h->total_chunks, h->d_chroms.p, h->bp.p, h->bt_exit.p);
         hipLaunchKernelGGL(backtrace_write_kernel, bt_grid, dim3(64), bt_write_lds, st, S, h->total_genes,
                            h->total_bp, h->total_genes + h->n_chrom, h->total_chunks, h->n_chrom, h->d_chroms.p,
-                           h->bp.p, h->bt_exit.p, h->last_state.p, h->states.p, h->calls.p);
+                           h->bp.p, h->bt_exit.p, h->last_state.p, h->states.p, h->calls.p, 0);
     };
     const dim3 unit_grid(h->n_chrom, h->n_samples);
     hipStream_t sa = h->stream, sb = h->stream_b, sc = h->stream_c;
@@ -2606,7 +2815,7 @@ int hmm_launch(gbrs_hmm *h) {
                 if (dlanes) {
                     hipLaunchKernelGGL(delta_lanes_kernel, dim3((h->n_samples + DL_SAMPLES - 1) / DL_SAMPLES, h->n_chrom), dim3(64 * DL_WAVES), 0, st,
                                        h->n_samples, h->total_genes, h->d_chroms.p, h->d_order.p, h->tprob.p, h->eprob.p,
-                                       h->init_vec.p, h->delta.p, h->last_state.p);
+                                       h->init_vec.p, h->delta.p, h->last_state.p, h->n_chrom);
                     return;
                 }
                 if (blocked) {
@@ -2881,13 +3090,23 @@ int gbrs_hmm_set_expression(gbrs_hmm_t *h, int n_samples, const double *const *e
     const size_t em_lds = (size_t)EM_GENES * ((H * H + 1) + (H + 1) + 2 * (h->S + 1)) * sizeof(double);
     const int64_t em_blocks = ((h->total_genes + EM_GENES - 1) / EM_GENES) * n_samples;
     (void)total;
-    if (H == EM_LANES && n_samples >= EM_BATCH_MIN) {
+    // Large 36-state batches: the emission kernel is left to the run, which launches it per chromosome group in front of
+    // that group's chains (hmm_launch_groups) - the second group's emission then runs beside the first group's chains.
+    // GBRS_TUNING_HMM_PIPELINE = smallest batch that does so (0: never).
+    int pipe_min = HMM_PIPE_MIN;
+    if (const char *env = std::getenv("GBRS_TUNING_HMM_PIPELINE"); env) pipe_min = std::atoi(env) > 0 ? std::atoi(env) : INT_MAX;
+    h->emission_pending = false;
+    if (H == EM_LANES && h->S == MF_S && n_samples >= pipe_min && n_samples >= EM_BATCH_MIN && h->n_chrom >= 2 && h->total_trans > 0) {
+        h->emission_pending = true;
+        h->em_thr = expr_threshold;
+        h->em_sigma = sigma;
+    } else if (H == EM_LANES && n_samples >= EM_BATCH_MIN) {
         // the gene-only part of the model once per EM_BATCH_SPB samples instead of once per sample
         const dim3 grid((unsigned)((h->total_genes + EM_GENES - 1) / EM_GENES),
                         (unsigned)((n_samples + EM_BATCH_SPB - 1) / EM_BATCH_SPB));
         hipLaunchKernelGGL(emission_batch_kernel<EM_LANES>, grid, dim3(64), 0, h->stream, h->total_genes, n_samples,
                            EM_BATCH_SPB, h->expr.p, h->avecs.p, h->has_avec.p, h->init_vec.p, expr_threshold, sigma,
-                           h->eprob.p, h->peprob.p);
+                           h->eprob.p, h->peprob.p, (int64_t)0, h->total_genes);
     } else {
         hipLaunchKernelGGL(emission_kernel, dim3((unsigned)em_blocks), dim3(64), em_lds, h->stream, H, h->S,
                            h->total_genes, n_samples, h->expr.p, h->avecs.p, h->has_avec.p, h->init_vec.p,
@@ -2897,9 +3116,9 @@ int gbrs_hmm_set_expression(gbrs_hmm_t *h, int n_samples, const double *const *e
     GBRS_HIP_CHECK(hipGetLastError());
     GBRS_HIP_CHECK(hipStreamSynchronize(h->stream));
     float ms = 0.f;
-    if (hipEventElapsedTime(&ms, h->ev[0], h->ev[1]) == hipSuccess) h->t_emis = ms;
+    if (hipEventElapsedTime(&ms, h->ev[0], h->ev[1]) == hipSuccess) h->t_emis = ms;    // (a deferred emission is part of the run's time)
     h->have_eprob = true;
-    h->pe_ready = true;
+    h->pe_ready = !h->emission_pending;
     h->ran = false;
     return GBRS_OK;
 }
@@ -2917,6 +3136,7 @@ int gbrs_hmm_set_eprob(gbrs_hmm_t *h, int n_samples, const double *const *eprob)
                                      (size_t)cd.n_genes * h->S * sizeof(double), hipMemcpyHostToDevice));
     }
     h->have_eprob = true;
+    h->emission_pending = false;
     h->pe_ready = false;
     h->ran = false;
     h->t_emis = 0;
@@ -2952,6 +3172,7 @@ int gbrs_hmm_get(gbrs_hmm_t *h, int sample, int chrom, double *gamma, int32_t *s
     if (!h->ran && (gamma || states || calls || alpha || beta || delta || scaler))
         return fail(GBRS_ERR_STATE, "run() has not been called");
     GBRS_TRY(select_device(h->device));
+    if (eprob && h->emission_pending) GBRS_TRY(hmm_flush_emission(h));      // asked for before any run made them
     if (alpha || beta || scaler) GBRS_TRY(hmm_make_logs(h));
     const ChromDesc &cd = h->chroms[chrom];
     const int S = h->S, n = cd.n_genes;
@@ -3055,6 +3276,10 @@ int gbrs_hmm_destroy(gbrs_hmm_t *h) {
     for (hipStream_t st : {h->stream, h->stream_b, h->stream_c, h->stream_h[0], h->stream_h[1], h->stream_h[2]})
         if (st) (void)hipStreamDestroy(st);
     for (hipEvent_t e : h->ev_head)
+        if (e) (void)hipEventDestroy(e);
+    for (hipStream_t st : h->stream_g)
+        if (st) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
+    for (hipEvent_t e : {h->gev_em[0], h->gev_em[1], h->gev_b[0], h->gev_b[1], h->gev_c[0], h->gev_c[1], h->gev_done[0], h->gev_done[1], h->gev_start})
         if (e) (void)hipEventDestroy(e);
     if (h->expr_stage) (void)hipHostFree(h->expr_stage);
     delete h;

@@ -187,9 +187,11 @@ def test_hmm_full_size_properties():
     hmm.close()
 
 
-@pytest.mark.parametrize("n_samples,mfma_ng", [(1, 1), (4, 1), (5, 1), (16, 1), (25, 1), (40, 1), (16, 2), (25, 2), (40, 2), (70, 2)])
+@pytest.mark.parametrize("n_samples,mfma_ng,pipeline", [(1, 1, 0), (4, 1, 0), (5, 1, 0), (16, 1, 0), (25, 1, 0), (40, 1, 0),
+                                                        (16, 2, 0), (25, 2, 0), (40, 2, 0), (70, 2, 0),
+                                                        (16, 1, 16), (25, 1, 16), (40, 1, 16), (70, 1, 16)])
 @pytest.mark.parametrize("minus_one", [False, True], ids=["tprob_n", "tprob_n_minus_1"])
-def test_hmm_sample_batches_and_short_chromosomes(n_samples, mfma_ng, minus_one, monkeypatch):
+def test_hmm_sample_batches_and_short_chromosomes(n_samples, mfma_ng, pipeline, minus_one, monkeypatch):
     """8 founders (the single-wave kernels; from 16 samples on this test sends the alpha and backward sweeps
     through the 16-samples-per-wavefront MFMA kernels that large batches use): distinct samples in one launch, including batch sizes
     that leave a partly filled wave, chromosomes of 1, 2, 3 genes and lengths around the prefetch
@@ -199,6 +201,8 @@ def test_hmm_sample_batches_and_short_chromosomes(n_samples, mfma_ng, minus_one,
     from oracle import hmm_oracle
     monkeypatch.setenv("GBRS_TUNING_HMM_MFMA", "16")
     monkeypatch.setenv("GBRS_TUNING_HMM_MFMA_NG", str(mfma_ng))   # round 4: one or two groups of 16 samples per wavefront of the sweeps
+    # round 4: the batch pass as two pipelined chromosome groups (emission left to the run; default from 96 samples on)
+    monkeypatch.setenv("GBRS_TUNING_HMM_PIPELINE", str(pipeline))
     monkeypatch.setenv("GBRS_TUNING_HMM_DLANES", "16")       # and the samples-on-lanes delta chain
     monkeypatch.setenv("GBRS_TUNING_HMM_BPLANES", "5")       # and the samples-on-lanes backpointers (partly filled wavefronts)
     lens = [1, 2, 3, 4, 5, 7, 63, 64, 65, 129, 200]
