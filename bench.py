@@ -41,6 +41,10 @@ def parse():
     # than 500 after 50 (profiles/r02_estep_experiments.txt, item 8); the defaults measure the settled loop (65 ms)
     ap.add_argument("--steps", type=int, default=500)
     ap.add_argument("--warmup", type=int, default=50)
+    ap.add_argument("--preroll-ms", type=float, default=40.0,
+                    help="untimed EM steps for this long in front of the W warmup steps, so that the K timed steps run at the clock the "
+                         "chip settles on under this load (it needs ~25 ms, profiles/r03_short_run_clock.txt); the K steps after W "
+                         "warmup steps on the chip as the setup left it are timed first and reported as `cold_start`; 0 = only those")
     ap.add_argument("--rows", type=int, default=40_000_000, help="reads per GPU")
     ap.add_argument("--haps", type=int, default=8)
     ap.add_argument("--loci", type=int, default=120_000)
@@ -84,6 +88,38 @@ class DevArray:
     partial-sum buffer for the RCCL all-reduce."""
     def __init__(self, ptr, n):
         self.__cuda_array_interface__ = dict(shape=(n,), typestr="<f8", data=(ptr, False), version=2)
+
+
+def timed_region(args, run_steps, barrier, world, torch, dist, dev):
+    """W untimed warmup steps, then exactly K steps between two barriers (+ device synchronisation), max over ranks - twice:
+    first on the chip as the setup left it (`cold`: the form of rounds 1-3), then again after --preroll-ms of the same steps,
+    untimed.  Returns (dt of the second region, dict describing the first and the pre-roll)."""
+    def once():
+        run_steps(args.warmup)
+        barrier()
+        t0 = time.perf_counter()
+        run_steps(args.steps)
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt
+    dt = once()
+    if args.preroll_ms <= 0:
+        return dt, None
+    cold = dict(ms_per_step=dt / args.steps * 1e3, value=world * args.steps / dt, unit="iters/s",
+                note=f"the first {args.steps} steps after {args.warmup} warmup steps on the chip as the setup left it (what "
+                     "rounds 1-3 reported as the headline)")
+    n_pre = int(min(20000, max(1, round(args.preroll_ms * 1e-3 / (dt / args.steps)))))     # the same count on every rank
+    t0 = time.perf_counter()
+    run_steps(n_pre)
+    barrier()
+    pre_ms = (time.perf_counter() - t0) * 1e3
+    dt = once()
+    return dt, dict(cold_start=cold, preroll=dict(steps=n_pre, ms=pre_ms, asked_ms=args.preroll_ms,
+                                                  note="untimed EM steps in front of the warmup steps of the reported region"))
 
 
 def em_bench(args, rank, world, torch, dist, keep_host=False):
@@ -149,18 +185,9 @@ def em_bench(args, rank, world, torch, dist, keep_host=False):
             eng.finish_step(want_err=False)
         eng.sync()
 
-    run_steps(args.warmup)
-    barrier()
-    t0 = time.perf_counter()
-    run_steps(args.steps)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt, region = timed_region(args, run_steps, barrier, world, torch, dist, dev)
     inf = eng.info()
-    res = dict(dt=dt, t_gen=t_gen, t_create=t_create, t_create_host=t_host, N=n_entries, info=inf, host=host,
+    res = dict(dt=dt, region=region, t_gen=t_gen, t_create=t_create, t_create_host=t_host, N=n_entries, info=inf, host=host,
                mean_loci_per_read=prob.get("mean_loci_per_read"))
     # ---- outside the timed region: is the state the timed steps produced a valid EM state? ----------
     res["check"] = em_state_check(torch, [eng.expected_counts()], float(args.rows) * world)
@@ -362,16 +389,7 @@ def em_bench_pipelined(args, rank, world, torch, dist, state):
             dist.barrier()
         torch.cuda.synchronize()
 
-    drv.step(args.warmup)
-    barrier()
-    t0 = time.perf_counter()
-    drv.step(args.steps)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+    dt, region = timed_region(args, drv.step, barrier, world, torch, dist, dev)
     check = em_state_check(torch, [e.expected_counts() for e in engs], float(args.rows) * world)
     # time to solution through the same two-engine loop: prepare, then the reference's stopping rule (EMfactory.py:266-278)
     # over both locus ranges on the device (gbrs_em_pair_check), looked at every 8 iterations; max over ranks
@@ -401,7 +419,7 @@ def em_bench_pipelined(args, rank, world, torch, dist, state):
         infos.append(inf)
     for e in engs:
         e.close()
-    return dict(dt=dt, t_gen=state["t_gen"], t_create=state["t_create"], t_create_host=None, N=state["N"],
+    return dict(dt=dt, region=region, t_gen=state["t_gen"], t_create=state["t_create"], t_create_host=None, N=state["N"],
                 info=infos[0], infos=infos, estep_ms=estep_ms, step_ms=step_ms, l_split=state["l_split"],
                 check=check, **({"solve": solve} if solve else {}))
 
@@ -812,7 +830,8 @@ def main():
         "metric": f"EM iterations/s (EMASE Model 4, {short(args.rows)} reads x {args.haps} haplotypes x "
                   f"{short(args.loci)} isoforms per GPU)",
         "value": value, "unit": "iters/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": ms_per_step, **(em.get("region") or {}),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
         "path": path, "rccl_ranks": world if ((world > 1 or args.rccl_selftest) and args.backend == "nccl") else 0,
         "backend": args.backend if world > 1 else None,
@@ -909,6 +928,7 @@ def main():
                 "note": "same sample with identical reads merged into weighted rows while building the device "
                         "layout (GBRS_EM_MERGE_IDENTICAL_ROWS, what `gbrs compress` does first); not the headline",
                 "value": args.steps / m["dt"], "unit": "iters/s", "ms_per_step": m["dt"] / args.steps * 1e3,
+                **(m.get("region") or {}),
                 "estep_kernel_ms": m["estep_ms"], "device_rows": int(m["info"].num_device_rows),
                 "device_words": int(m["info"].num_device_words), "layout_bytes": int(m["info"].bytes_per_iter),
                 "state_check": m.get("check")}
@@ -926,6 +946,7 @@ def main():
                         "(locus, haplotype) alignment dropped with p = 0.1): gbrs_amd/synth_torch.py "
                         "make_multi_isoform_device; same sample model, R, H, L as the headline",
                 "value": args.steps / v["dt"], "unit": "iters/s", "ms_per_step": v["dt"] / args.steps * 1e3,
+                **(v.get("region") or {}),
                 "entries": v["N"], "entries_per_read": v["N"] / args.rows,
                 "loci_per_read": v["mean_loci_per_read"],
                 "words_per_read": int(vi.num_device_words) / max(int(vi.num_rows), 1),
