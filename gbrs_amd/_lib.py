@@ -71,6 +71,8 @@ class HmmInfo(C.Structure):
         ("last_backward_ms", C.c_double), ("last_backtrace_ms", C.c_double),
         ("num_states", C.c_int32), ("n_samples", C.c_int32),
         ("last_run_ms", C.c_double),
+        ("last_delta_blocks", C.c_int32), ("last_delta_longest_fixup", C.c_int32),
+        ("last_delta_fallbacks", C.c_int32), ("reserved0", C.c_int32),
     ]
 
 

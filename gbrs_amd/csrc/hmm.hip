@@ -322,6 +322,15 @@ emission_batch_kernel(int64_t n_genes, int n_samples, int samples_per_block, con
 // step's transition block T[i-1][j][:] at columns k = q + LPS*m.
 // ------------------------------------------------------------------------------------------
 
+// The chain kernels with two register sets are the blocked scan's (1,000 one-wavefront workgroups per kernel, three such
+// kernels at a time on 1,024 SIMDs): they are built for HMM_BLK_WAVES wavefronts per SIMD, so that the three sides of a
+// pass can share the SIMDs instead of queueing for whole register files; with three sets (60 wavefronts per pass) a
+// wavefront may take the whole file.
+#ifndef HMM_BLK_WAVES
+#define HMM_BLK_WAVES 2
+#endif
+#define HMM_CHAIN_WAVES(NSET) ((NSET) <= 2 ? HMM_BLK_WAVES : 1)
+
 struct ChromDesc {
     int64_t gene_off;     // offset of the chromosome's first gene in the per-sample gene axis
     int64_t trans_off;    // offset (in S*S blocks) of tprob[c][0] in the transition buffer
@@ -837,14 +846,16 @@ __device__ __forceinline__ void wave_lds_fence() {
 // in parallel instead of on the sequential path).  The two are separate launches on separate
 // streams (each keeps its own register budget).
 template <int SS, int NSET, int SB, int ROLE, int HB>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, HMM_CHAIN_WAVES(NSET))
 forward_wave_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *__restrict__ chroms,
                     const int32_t *__restrict__ order, const double *__restrict__ tprob, const double *__restrict__ pprob,
                     const double *__restrict__ eprob, const double *__restrict__ peprob,
                     const double *__restrict__ init_vec, double *__restrict__ xsum,
                     double *__restrict__ invz, double *__restrict__ delta,
                     int32_t *__restrict__ last_state, const double *__restrict__ inject, int n_real_chrom,
-                    int inject_slots /* boundary vectors per sample in `inject` */) {
+                    int inject_slots /* boundary vectors per sample in `inject` */,
+                    const int32_t *__restrict__ only_if = nullptr /* [sample][chromosome]: run only where set (the fallback of
+                                                                     the rank-convergence delta, hmm_blocked.inc) */) {
     static_assert(SS % 2 == 0 && SS <= 64, "one lane per state, 16-byte aligned rows");
     __shared__ __attribute__((aligned(16))) double buf[SB][2][SS];
     const int chrom = order[blockIdx.y];
@@ -867,6 +878,15 @@ forward_wave_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *__
         const int sample = blockIdx.x * SB + b;
         sv[b] = sample < n_samples;
         g0[b] = (int64_t)min(sample, n_samples - 1) * genes_per_sample + cd.gene_off;
+    }
+    if (only_if) {
+        bool wanted = false;
+#pragma unroll
+        for (int b = 0; b < SB; ++b) {
+            sv[b] = sv[b] && only_if[(int64_t)(blockIdx.x * SB + b) * n_real_chrom + chrom] != 0;
+            wanted = wanted || sv[b];
+        }
+        if (!wanted) return;
     }
     const int n_ord = min(n, cd.n_trans + 1) - 1;   // step i = o + 1 needs T[o]
     int cur = 0;
@@ -1393,7 +1413,7 @@ viterbi_bp_quad_kernel(int n_samples, int64_t genes_per_sample, int64_t bp_per_s
 // a per-gene constant, log C_i = sum_{t>=i} log(1/Z_t) - sum_{i<=t<=n-2} log(r_t), which
 // beta_corr_kernel adds afterwards; the posterior is scale free.
 template <int SS, int NSET, int SB>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, HMM_CHAIN_WAVES(NSET))
 backward_wave_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *__restrict__ chroms,
                      const int32_t *__restrict__ order, const double *__restrict__ pprob_t,
                      const double *__restrict__ peprob, double *__restrict__ bhat, double *__restrict__ bscale,
@@ -1616,6 +1636,9 @@ alpha_mfma_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *__re
                   const int32_t *__restrict__ order, const double *__restrict__ amat,
                   const double *__restrict__ eprob, const double *__restrict__ peprob,
                   const double *__restrict__ init_vec, double *__restrict__ xsum, double *__restrict__ invz) {
+#if defined(HMM_DIAG_EXCL_MFMA)                  // diagnostic builds: the wavefront takes its SIMD's whole register file, nothing runs beside it
+    asm volatile("v_accvgpr_write_b32 a255, 0" ::: "a255");
+#endif
     constexpr int S = MF_S;
     const ChromDesc cd = chroms[order[blockIdx.y]];
     const int n = cd.n_genes;
@@ -1707,6 +1730,9 @@ __global__ void __launch_bounds__(64)
 backward_mfma_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *__restrict__ chroms,
                      const int32_t *__restrict__ order, const double *__restrict__ amat_t,
                      const double *__restrict__ peprob, double *__restrict__ bhat, double *__restrict__ bscale) {
+#if defined(HMM_DIAG_EXCL_MFMA)                  // diagnostic builds: the wavefront takes its SIMD's whole register file, nothing runs beside it
+    asm volatile("v_accvgpr_write_b32 a255, 0" ::: "a255");
+#endif
     constexpr int S = MF_S;
     const ChromDesc cd = chroms[order[blockIdx.y]];
     const int n = cd.n_genes;
@@ -2241,10 +2267,14 @@ struct gbrs_hmm {
     int n_vb = 0, blk_samples = 0;            // n_vb: the larger of the two block counts (buffers are sized by it)
     int n_blk[2] = {0, 0}, n_head[2] = {0, 0};
     bool last_blocked = false;                // the last run's backward chains started from injected vectors
+    bool last_delta_spec = false;             // the last run's delta came from the rank-convergence scheme: delta_apply_kernel is due
     DevBuf<BlockRange> d_ranges[2];
     DevBuf<int32_t> d_first_block[2];         // blocks of chromosome c: first_block[c] .. first_block[c+1]
     DevBuf<int32_t> d_vorder[2];              // block indices, the directly chained ones first (n_head of them)
     DevBuf<ChromDesc> d_vfwd, d_vbwd;         // the blocks as descriptors of the forward / delta and of the backward chains
+    std::vector<BlockRange> h_ranges0;        // host copy of d_ranges[0]
+    DevBuf<double> dspec_c;                   // rank-convergence delta: every block's constant against the block before it,
+    DevBuf<int32_t> dspec_g, dspec_fail;      // the gene from which its stored values stand, per (sample, chromosome) failure flags
     hipStream_t stream_h[3] = {nullptr, nullptr, nullptr};   // the direct chains of alpha / backward / delta
     hipEvent_t ev_head[3] = {nullptr, nullptr, nullptr};
     // Pipelined batch pass (round 4, hmm_launch_groups): the chromosomes in two groups of consecutive chromosomes, each with
@@ -2353,6 +2383,9 @@ int hmm_make_logs(gbrs_hmm *h) {
 #ifndef HMM_HOIST_D
 #define HMM_HOIST_D 18
 #endif
+#ifndef HMM_HOIST_BLK
+#define HMM_HOIST_BLK 6     // the same in the blocked scan's chain instances
+#endif
 #ifndef HMM_SB
 #define HMM_SB 2          // samples per wave in large batches (n_samples >= HMM_BATCH_MIN)
 #endif
@@ -2380,7 +2413,11 @@ int hmm_make_logs(gbrs_hmm *h) {
 #endif                               // default - measured (round 4): 256 samples 16.3-16.7 ms either way, 128: 9.2 -> 12.0, 64: 6.9 -> 9.3
 
 #ifndef HMM_BLOCKED_MAX
-#define HMM_BLOCKED_MAX 2     // 36 states, at most this many samples: the blocked scan (the operators cost 36 columns per block)
+#define HMM_BLOCKED_MAX 3     // 36 states, at most this many samples: the blocked scan (the sum-product operators cost 36 columns per block and sample;
+                              // round 4, Viterbi values by rank convergence: 0.77 / 1.13 / 1.60 ms at 1 / 2 / 3 samples against 1.9-2.0 on the chains, equal at 4)
+#endif
+#ifndef HMM_DELTA_SPEC
+#define HMM_DELTA_SPEC 1      // blocked scan: Viterbi values by rank convergence (one chain per block + fix-up) instead of max-plus block operators
 #endif
 #ifndef HMM_BLOCK_GENES
 #define HMM_BLOCK_GENES 40    // genes per block aimed at (at most HMM_BLOCKS_MAX blocks per chromosome)
@@ -2470,6 +2507,7 @@ int hmm_prepare_blocks(gbrs_hmm *h) {
             GBRS_HIP_CHECK(hipMemcpy(h->d_vorder[dir].p, order.data(), VB * sizeof(int32_t), hipMemcpyHostToDevice));
             h->n_blk[dir] = VB;
             h->n_head[dir] = (int)heads.size();
+            if (dir == 0) h->h_ranges0 = ranges;
         }
         GBRS_TRY(h->d_vfwd.alloc(vf.size()));
         GBRS_TRY(h->d_vbwd.alloc(vb.size()));
@@ -2486,6 +2524,8 @@ int hmm_prepare_blocks(gbrs_hmm *h) {
         GBRS_TRY(h->g_f.alloc(nb * S * S)); GBRS_TRY(h->g_b.alloc(nb * S * S)); GBRS_TRY(h->g_d.alloc(nb * S * S));
         GBRS_TRY(h->e_f.alloc(nb * S)); GBRS_TRY(h->e_b.alloc(nb * S));
         GBRS_TRY(h->inj_f.alloc(nb * S)); GBRS_TRY(h->inj_b.alloc(nb * S)); GBRS_TRY(h->inj_d.alloc(nb * S));
+        GBRS_TRY(h->dspec_c.alloc(nb)); GBRS_TRY(h->dspec_g.alloc(nb));
+        GBRS_TRY(h->dspec_fail.alloc((size_t)h->n_samples * h->n_chrom));
         h->blk_samples = h->n_samples;
     }
     return GBRS_OK;
@@ -2716,6 +2756,10 @@ int hmm_launch(gbrs_hmm *h) {
             auto k_alpha = batched ? &forward_wave_kernel<SS, HMM_NSET_B, HMM_SB, 0, 18> : &forward_wave_kernel<SS, HMM_NSET, 1, 0, HMM_HOIST_A>;
             auto k_delta = batched ? &forward_wave_kernel<SS, HMM_NSET_B, HMM_SB, 1, 18> : &forward_wave_kernel<SS, HMM_NSET, 1, 1, HMM_HOIST_D>;
             auto k_back = batched ? &backward_wave_kernel<SS, HMM_NSET_B, HMM_SB> : &backward_wave_kernel<SS, HMM_NSET, 1>;
+            // the blocked scan's chains (~40 steps each, ~1,000 wavefronts per kernel): two register sets, fewer hoisted reads
+            auto kb_alpha = &forward_wave_kernel<SS, 2, 1, 0, HMM_HOIST_BLK>;
+            auto kb_delta = &forward_wave_kernel<SS, 2, 1, 1, HMM_HOIST_BLK>;
+            auto kb_back = &backward_wave_kernel<SS, 2, 1>;
             // GBRS_TUNING_HMM_MFMA = smallest batch that takes the MFMA sweeps (0: never) - the parity tests run them at 16
             int mfma_min = HMM_MFMA_MIN;
             if (const char *env = std::getenv("GBRS_TUNING_HMM_MFMA"); env) mfma_min = std::atoi(env) > 0 ? std::atoi(env) : INT_MAX;
@@ -2726,6 +2770,7 @@ int hmm_launch(gbrs_hmm *h) {
             const bool blocked = SS == MF_S && !mfma && h->n_samples <= blocked_max && h->total_trans > 0;
             if (blocked) GBRS_TRY(hmm_prepare_blocks(h));
             h->last_blocked = blocked;
+            h->last_delta_spec = false;
             if ((mfma || blocked) && !h->amat_f.p) {
                 GBRS_TRY(h->amat_f.alloc((size_t)h->total_trans * MF_BLK));
                 GBRS_TRY(h->amat_b.alloc((size_t)h->total_trans * MF_BLK));
@@ -2750,10 +2795,10 @@ int hmm_launch(gbrs_hmm *h) {
                     // starts from what those chains stored
                     auto chains = [&](hipStream_t q, int first, int count) {
                         if (count > 0)
-                            hipLaunchKernelGGL(k_alpha, dim3(h->n_samples, count), dim3(64), 0, q, h->n_samples, h->total_genes,
+                            hipLaunchKernelGGL(kb_alpha, dim3(h->n_samples, count), dim3(64), 0, q, h->n_samples, h->total_genes,
                                                h->d_vfwd.p, h->d_vorder[0].p + first, h->tprob_q.p, h->pprob.p, h->eprob.p, h->peprob.p,
                                                h->init_vec.p, h->xsum.p, h->invz.p, h->delta.p, h->last_state.p, h->inj_f.p, h->n_chrom,
-                                               h->n_vb);
+                                               h->n_vb, (const int32_t *)nullptr);
                     };
                     if (h->n_head[0]) {
                         (void)hipStreamWaitEvent(h->stream_h[0], h->ev_fork, 0);
@@ -2772,7 +2817,7 @@ int hmm_launch(gbrs_hmm *h) {
                 hipLaunchKernelGGL(k_alpha, wave_grid, dim3(64), 0, st, h->n_samples, h->total_genes,
                                    h->d_chroms.p, h->d_order.p, h->tprob_q.p, h->pprob.p, h->eprob.p, h->peprob.p,
                                    h->init_vec.p, h->xsum.p, h->invz.p, h->delta.p, h->last_state.p, (const double *)nullptr,
-                                   h->n_chrom, 0);
+                                   h->n_chrom, 0, (const int32_t *)nullptr);
             };
             launch_back = [=](hipStream_t st) {
                 if (mfma) {
@@ -2785,7 +2830,7 @@ int hmm_launch(gbrs_hmm *h) {
                 if (blocked) {
                     auto chains = [&](hipStream_t q, int first, int count) {
                         if (count > 0)
-                            hipLaunchKernelGGL(k_back, dim3(h->n_samples, count), dim3(64), 0, q, h->n_samples, h->total_genes,
+                            hipLaunchKernelGGL(kb_back, dim3(h->n_samples, count), dim3(64), 0, q, h->n_samples, h->total_genes,
                                                h->d_vbwd.p, h->d_vorder[1].p + first, h->pprob_t.p, h->peprob.p, h->bhat.p, h->bscale.p,
                                                h->inj_b.p, h->n_vb);
                     };
@@ -2811,6 +2856,17 @@ int hmm_launch(gbrs_hmm *h) {
             int dl_min = HMM_DLANES_MIN;
             if (const char *env = std::getenv("GBRS_TUNING_HMM_DLANES"); env) dl_min = std::atoi(env) > 0 ? std::atoi(env) : INT_MAX;
             const bool dlanes = SS == MF_S && h->n_samples >= dl_min && h->total_trans > 0;
+            // GBRS_TUNING_HMM_DELTA_SPEC=0: the blocked scan's delta through max-plus block operators (round 3) instead of rank
+            // convergence; GBRS_TUNING_HMM_DELTA_TOL=<absolute tolerance> (negative: no block ever converges - every chromosome
+            // takes the fallback chain; the tests use it)
+            bool delta_spec = blocked && HMM_DELTA_SPEC != 0;
+            if (const char *env = std::getenv("GBRS_TUNING_HMM_DELTA_SPEC"); env) delta_spec = blocked && std::atoi(env) != 0;
+            double delta_tol_abs = 1e-9, delta_tol_rel = 1e-13;
+            if (const char *env = std::getenv("GBRS_TUNING_HMM_DELTA_TOL"); env) {
+                delta_tol_abs = std::atof(env);
+                if (delta_tol_abs < 0.0) delta_tol_rel = 0.0;
+            }
+            h->last_delta_spec = delta_spec;
             launch_delta = [=](hipStream_t st) {
                 if (dlanes) {
                     hipLaunchKernelGGL(delta_lanes_kernel, dim3((h->n_samples + DL_SAMPLES - 1) / DL_SAMPLES, h->n_chrom), dim3(64 * DL_WAVES), 0, st,
@@ -2821,11 +2877,27 @@ int hmm_launch(gbrs_hmm *h) {
                 if (blocked) {
                     auto chains = [&](hipStream_t q, int first, int count) {
                         if (count > 0)
-                            hipLaunchKernelGGL(k_delta, dim3(h->n_samples, count), dim3(64), 0, q, h->n_samples, h->total_genes,
+                            hipLaunchKernelGGL(kb_delta, dim3(h->n_samples, count), dim3(64), 0, q, h->n_samples, h->total_genes,
                                                h->d_vfwd.p, h->d_vorder[0].p + first, h->tprob_q.p, h->pprob.p, h->eprob.p, h->peprob.p,
                                                h->init_vec.p, h->xsum.p, h->invz.p, h->delta.p, h->last_state.p, h->inj_d.p, h->n_chrom,
-                                               h->n_vb);
+                                               h->n_vb, (const int32_t *)nullptr);
                     };
+                    if (delta_spec) {
+                        // rank convergence instead of block operators (hmm_blocked.inc): guess -> chains in all blocks -> fix-up in
+                        // all blocks -> the unblocked chain for the chromosomes whose flag a fix-up raised (idle otherwise)
+                        const dim3 bgrid(h->n_blk[0], h->n_samples);
+                        hipLaunchKernelGGL(delta_guess_kernel, bgrid, dim3(64), 0, st, h->total_genes, h->n_vb, h->n_chrom,
+                                           h->d_ranges[0].p, h->eprob.p, h->inj_d.p, h->dspec_c.p, h->dspec_g.p, h->dspec_fail.p);
+                        chains(st, 0, h->n_blk[0]);
+                        hipLaunchKernelGGL(delta_fixup_kernel<SS>, bgrid, dim3(64), 0, st, h->total_genes, h->n_vb, h->n_chrom,
+                                           h->d_ranges[0].p, h->tprob_q.p, h->eprob.p, h->delta.p, h->dspec_c.p, h->dspec_g.p,
+                                           h->dspec_fail.p, delta_tol_abs, delta_tol_rel);
+                        hipLaunchKernelGGL(k_delta, wave_grid, dim3(64), 0, st, h->n_samples, h->total_genes,
+                                           h->d_chroms.p, h->d_order.p, h->tprob_q.p, h->pprob.p, h->eprob.p, h->peprob.p,
+                                           h->init_vec.p, h->xsum.p, h->invz.p, h->delta.p, h->last_state.p, (const double *)nullptr,
+                                           h->n_chrom, 0, (const int32_t *)h->dspec_fail.p);
+                        return;
+                    }
                     if (h->n_head[0]) {
                         (void)hipStreamWaitEvent(h->stream_h[2], h->ev_fork, 0);
                         chains(h->stream_h[2], 0, h->n_head[0]);
@@ -2843,7 +2915,7 @@ int hmm_launch(gbrs_hmm *h) {
                 hipLaunchKernelGGL(k_delta, wave_grid, dim3(64), 0, st, h->n_samples, h->total_genes,
                                    h->d_chroms.p, h->d_order.p, h->tprob_q.p, h->pprob.p, h->eprob.p, h->peprob.p,
                                    h->init_vec.p, h->xsum.p, h->invz.p, h->delta.p, h->last_state.p, (const double *)nullptr,
-                                   h->n_chrom, 0);
+                                   h->n_chrom, 0, (const int32_t *)nullptr);
             };
         } else {
             const dim3 quad_grid(h->n_samples, h->n_chrom), quad_block(threads);
@@ -2899,6 +2971,10 @@ int hmm_launch(gbrs_hmm *h) {
         }
         GBRS_HIP_CHECK(hipEventRecord(h->ev_c1, sc));
         launch_backtrace(sc);
+        if (h->last_delta_spec)                       // behind everything that reads the blocks' vectors as the fix-up left them
+            hipLaunchKernelGGL(delta_apply_kernel, dim3(h->n_blk[0], h->n_samples), dim3(64), 0, sc, h->total_genes, h->n_vb,
+                               h->n_chrom, h->d_ranges[0].p, h->d_first_block[0].p, h->dspec_c.p, h->dspec_g.p,
+                               h->dspec_fail.p, h->delta.p);
         GBRS_HIP_CHECK(hipEventRecord(h->ev_c, sc));
         GBRS_HIP_CHECK(hipStreamWaitEvent(sa, h->ev_b, 0));
         launch_posterior(h, sa);                      // the posterior is scale free: no beta correction needed
@@ -3211,6 +3287,27 @@ int gbrs_hmm_info(gbrs_hmm_t *h, gbrs_hmm_info_t *info) {
     info->last_run_ms = h->t_run;
     info->num_states = h->S;
     info->n_samples = h->n_samples;
+    if (h->last_delta_spec && h->n_blk[0] > 0) {
+        // how the rank-convergence delta of the last run went: blocks fixed up, the longest fix-up, chains recomputed
+        GBRS_TRY(select_device(h->device));
+        std::vector<int32_t> g((size_t)h->n_vb * h->n_samples), f((size_t)h->n_samples * h->n_chrom);
+        GBRS_HIP_CHECK(hipMemcpy(g.data(), h->dspec_g.p, g.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+        GBRS_HIP_CHECK(hipMemcpy(f.data(), h->dspec_fail.p, f.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+        int blocks = 0, longest = 0, fallbacks = 0;
+        for (int s = 0; s < h->n_samples; ++s) {
+            for (int v = 0; v < h->n_blk[0]; ++v) {
+                const BlockRange &r = h->h_ranges0[v];
+                if (r.lo == 0) continue;
+                if (f[(size_t)s * h->n_chrom + r.chrom]) continue;
+                ++blocks;
+                longest = std::max(longest, g[(size_t)s * h->n_vb + v] - r.lo + 1);
+            }
+            for (int c = 0; c < h->n_chrom; ++c) fallbacks += f[(size_t)s * h->n_chrom + c] != 0;
+        }
+        info->last_delta_blocks = blocks;
+        info->last_delta_longest_fixup = longest;
+        info->last_delta_fallbacks = fallbacks;
+    }
     return GBRS_OK;
 }
 

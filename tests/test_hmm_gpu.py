@@ -43,14 +43,23 @@ def test_hmm_matches_reference_golden(path):
     hmm.close()
 
 
+# the Viterbi values of the blocked scan: by rank convergence (default), by max-plus block operators (round 3), and with a
+# tolerance no block can meet, so that every chromosome takes the fallback chain behind the fix-up
+DELTA_ROUTES = {"rank": {}, "operators": {"GBRS_TUNING_HMM_DELTA_SPEC": "0"}, "fallback": {"GBRS_TUNING_HMM_DELTA_TOL": "-1"}}
+
+
+@pytest.mark.parametrize("delta_route", list(DELTA_ROUTES))
 @pytest.mark.parametrize("block_genes", [2, 5, 9])
 @pytest.mark.parametrize("path", [p for p in golden_files("hmm") if "h8" in p], ids=lambda p: p.split("/")[-1][:-4])
-def test_blocked_scan_matches_reference_golden(path, block_genes, monkeypatch):
-    """The blocked scan of the 36-state recursions (hmm_blocked.inc: block transfer operators on MFMA / max-plus, a
-    sequential combine, the chain kernels inside all blocks at once) with blocks of 2, 5 and 9 genes, so that the
-    goldens' short chromosomes are cut many times: the same tolerances as the unblocked run, calls bit-exact."""
+def test_blocked_scan_matches_reference_golden(path, block_genes, delta_route, monkeypatch):
+    """The blocked scan of the 36-state recursions (hmm_blocked.inc: block transfer operators on MFMA, a sequential
+    combine, the chain kernels inside all blocks at once; Viterbi values by rank convergence or max-plus operators) with
+    blocks of 2, 5 and 9 genes, so that the goldens' short chromosomes are cut many times (and blocks of 2 genes cannot
+    converge: those chromosomes take the fallback): the same tolerances as the unblocked run, calls bit-exact."""
     monkeypatch.setenv("GBRS_TUNING_HMM_BLOCK_GENES", str(block_genes))
     monkeypatch.setenv("GBRS_TUNING_HMM_BLOCKED", "2")
+    for k, v in DELTA_ROUTES[delta_route].items():
+        monkeypatch.setenv(k, v)
     g = load_golden(path)
     c = hmm_case_inputs(g)
     chroms = c["chroms"]
@@ -70,6 +79,98 @@ def test_blocked_scan_matches_reference_golden(path, block_genes, monkeypatch):
         gap = viterbi_decision_margins(c["tprob"][ch], g[f"delta_{ch}"]).min()
         assert np.max(np.abs(r["delta"] - g[f"delta_{ch}"])) < 1e-6 * gap
         np.testing.assert_allclose(r["gamma"], g[f"gamma_{ch}"], rtol=1e-8, atol=1e-300)
+    inf = hmm.info()
+    if delta_route == "operators":
+        assert inf.last_delta_blocks == 0 and inf.last_delta_fallbacks == 0
+    elif delta_route == "fallback":
+        many = sum(1 for n in hmm.n_genes if min(64, int(n) // block_genes) >= 2)      # chromosomes cut into 2+ blocks
+        assert inf.last_delta_blocks == 0 and inf.last_delta_fallbacks == many
+    hmm.close()
+
+
+@pytest.mark.parametrize("style,expressed", [("benign", 0.5), ("do", 0.5), ("do", 0.1)])
+def test_rank_convergence_delta_at_size(style, expressed, monkeypatch):
+    """Viterbi values by rank convergence on three long chromosomes, SURVEY's tables and the DO-like ones (recombination
+    1e-15 .. 1e-2 per interval, structural zeros = -inf entries) with half and a tenth of the haplotypes expressed: the
+    blocks really converge (no fallback, fix-ups far shorter than a block), delta equals the sequential chain's and the
+    oracle's, the path is identical."""
+    from gbrs_amd import synth
+    from gbrs_amd.hmm import DiplotypeHMM
+    from oracle import hmm_oracle
+    prob = synth.make_hmm_problem(H=8, genes_per_chrom=[2600, 1700, 1100], style=style, expressed_fraction=expressed)
+    chroms = prob.chroms
+    ex = [np.array([prob.expr[g] for g in prob.gene_ids[c]]) for c in chroms]
+    ha = [np.array([g in prob.avecs for g in prob.gene_ids[c]], dtype=np.uint8) for c in chroms]
+    av = [np.array([prob.avecs.get(g, np.zeros((8, 8))) for g in prob.gene_ids[c]]) for c in chroms]
+    res = {}
+    for mode in ("0", "2"):
+        monkeypatch.setenv("GBRS_TUNING_HMM_BLOCKED", mode)
+        hmm = DiplotypeHMM(8, chroms, [len(prob.gene_ids[c]) for c in chroms], [prob.tprob[c] for c in chroms])
+        hmm.set_expression(ex, av, ha, 1.5, 0.12)
+        hmm.run()
+        res[mode] = [hmm.get(ci, want=("states", "calls", "delta")) for ci in range(3)]
+        inf = hmm.info()
+        if mode == "2":
+            assert inf.last_delta_fallbacks == 0
+            assert inf.last_delta_blocks == sum(max(1, min(64, n // 40)) - 1 for n in (2600, 1700, 1100))
+            assert 1 <= inf.last_delta_longest_fixup <= 41
+        else:
+            assert inf.last_delta_blocks == 0
+        hmm.close()
+    iv = hmm_oracle.init_vector(8)
+    for ci, (a, b) in enumerate(zip(res["0"], res["2"])):
+        np.testing.assert_array_equal(a["states"], b["states"])
+        np.testing.assert_array_equal(a["calls"], b["calls"])
+        np.testing.assert_allclose(b["delta"], a["delta"], rtol=1e-10, atol=1e-9)
+        ids = prob.gene_ids[chroms[ci]]
+        E = np.array([hmm_oracle.emission(prob.expr[g], prob.avecs.get(g), iv) for g in ids])
+        d_ref, st_ref, _ = hmm_oracle.viterbi(prob.tprob[chroms[ci]], E, iv)
+        np.testing.assert_allclose(b["delta"], d_ref, rtol=1e-10, atol=1e-9)
+        np.testing.assert_array_equal(b["states"], st_ref)
+
+
+@pytest.mark.parametrize("delta_route", list(DELTA_ROUTES))
+def test_blocked_scan_two_samples_all_delta_routes(delta_route, monkeypatch):
+    """Two samples in the blocked scan (per-sample slots of the guesses, constants and flags), each against its own
+    one-sample unblocked run."""
+    from gbrs_amd import synth
+    from gbrs_amd.hmm import DiplotypeHMM
+    prob = synth.make_hmm_problem(H=8, genes_per_chrom=[900, 350, 130], style="do")
+    chroms = prob.chroms
+    rng = np.random.default_rng(5)
+    ha = [np.array([g in prob.avecs for g in prob.gene_ids[c]], dtype=np.uint8) for c in chroms]
+    av = [np.array([prob.avecs.get(g, np.zeros((8, 8))) for g in prob.gene_ids[c]]) for c in chroms]
+    e0 = [np.array([prob.expr[g] for g in prob.gene_ids[c]]) for c in chroms]
+    e1 = [rng.gamma(1.0, 5.0, size=e.shape) * (rng.random(e.shape) < 0.3) for e in e0]
+    dims = (8, chroms, [len(prob.gene_ids[c]) for c in chroms], [prob.tprob[c] for c in chroms])
+    want = ("states", "calls", "delta", "gamma")
+    monkeypatch.setenv("GBRS_TUNING_HMM_BLOCKED", "0")
+    single = []
+    for ex in (e0, e1):
+        hmm = DiplotypeHMM(*dims)
+        hmm.set_expression(ex, av, ha, 1.5, 0.12)
+        hmm.run()
+        single.append([hmm.get(ci, want=want) for ci in range(3)])
+        hmm.close()
+    monkeypatch.setenv("GBRS_TUNING_HMM_BLOCKED", "2")
+    monkeypatch.setenv("GBRS_TUNING_HMM_BLOCK_GENES", "30")
+    for k, v in DELTA_ROUTES[delta_route].items():
+        monkeypatch.setenv(k, v)
+    hmm = DiplotypeHMM(*dims)
+    hmm.set_expression([np.stack([a, b]) for a, b in zip(e0, e1)], av, ha, 1.5, 0.12)
+    hmm.run()
+    inf = hmm.info()
+    if delta_route == "rank":
+        assert inf.last_delta_fallbacks == 0 and inf.last_delta_blocks > 0
+    elif delta_route == "fallback":
+        assert inf.last_delta_fallbacks == 2 * 3
+    for s in range(2):
+        for ci in range(3):
+            r = hmm.get(ci, sample=s, want=want)
+            np.testing.assert_array_equal(r["states"], single[s][ci]["states"])
+            np.testing.assert_array_equal(r["calls"], single[s][ci]["calls"])
+            np.testing.assert_allclose(r["delta"], single[s][ci]["delta"], rtol=1e-10, atol=1e-9)
+            np.testing.assert_allclose(r["gamma"], single[s][ci]["gamma"], rtol=1e-8, atol=1e-300)
     hmm.close()
 
 
