@@ -824,6 +824,15 @@ __device__ __forceinline__ void load_lane(const double *__restrict__ block, int 
     }
 }
 
+// index of the first maximum, from four running maxima over interleaved index classes (k = 0, 1, 2, 3 mod 4), each with
+// the index where it was first reached: on equal values the smaller index wins, which is np.argmax's rule
+__device__ __forceinline__ int first_max4(double m0, int k0, double m1, int k1, double m2, int k2, double m3, int k3) {
+    if (m1 > m0 || (m1 == m0 && k1 < k0)) { m0 = m1; k0 = k1; }
+    if (m3 > m2 || (m3 == m2 && k3 < k2)) { m2 = m3; k2 = k3; }
+    if (m2 > m0 || (m2 == m0 && k2 < k0)) k0 = k2;
+    return k0;
+}
+
 // orders this wave's LDS writes before its later LDS reads for the compiler; the hardware keeps
 // one wave's DS instructions in order
 __device__ __forceinline__ void wave_lds_fence() {
@@ -845,7 +854,7 @@ __device__ __forceinline__ void wave_lds_fence() {
 // argmax_k(delta_t[k] + T[t][j][k]) of stored rows, which viterbi_bp_kernel evaluates for every t
 // in parallel instead of on the sequential path).  The two are separate launches on separate
 // streams (each keeps its own register budget).
-template <int SS, int NSET, int SB, int ROLE, int HB>
+template <int SS, int NSET, int SB, int ROLE, int HB, bool BP = false /* role 1: write the backpointers of every step too */>
 __global__ void __launch_bounds__(64, HMM_CHAIN_WAVES(NSET))
 forward_wave_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *__restrict__ chroms,
                     const int32_t *__restrict__ order, const double *__restrict__ tprob, const double *__restrict__ pprob,
@@ -855,7 +864,8 @@ forward_wave_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *__
                     int32_t *__restrict__ last_state, const double *__restrict__ inject, int n_real_chrom,
                     int inject_slots /* boundary vectors per sample in `inject` */,
                     const int32_t *__restrict__ only_if = nullptr /* [sample][chromosome]: run only where set (the fallback of
-                                                                     the rank-convergence delta, hmm_blocked.inc) */) {
+                                                                     the rank-convergence delta, hmm_blocked.inc) */,
+                    uint16_t *__restrict__ bp = nullptr, int64_t bp_per_sample = 0 /* BP instances */) {
     static_assert(SS % 2 == 0 && SS <= 64, "one lane per state, 16-byte aligned rows");
     __shared__ __attribute__((aligned(16))) double buf[SB][2][SS];
     const int chrom = order[blockIdx.y];
@@ -1047,6 +1057,7 @@ forward_wave_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *__
             constexpr int NV = SS / 2, BATCH = HB > 0 ? HB : NV;
             const double2 *dp = reinterpret_cast<const double2 *>(buf[b][cur]);
             double m0 = 0.0, m1 = 0.0, m2 = 0.0, m3 = 0.0;
+            int k0 = 0, k1 = 1, k2 = 2, k3 = 3;          // BP: where each running maximum was first reached
 #pragma unroll
             for (int mb = 0; mb < NV; mb += BATCH) {
                 double2 dp_r[BATCH];
@@ -1064,9 +1075,20 @@ forward_wave_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *__
                     const double a = v.x + tc[2 * m], c = v.y + tc[2 * m + 1];
                     if (m == 0) { m0 = a; m1 = c; }
                     else if (m == 1) { m2 = a; m3 = c; }
-                    else if (m & 1) { m2 = fmax(m2, a); m3 = fmax(m3, c); }
-                    else { m0 = fmax(m0, a); m1 = fmax(m1, c); }
+                    else if (m & 1) {
+                        if constexpr (BP) { k2 = a > m2 ? 2 * m : k2; k3 = c > m3 ? 2 * m + 1 : k3; }
+                        m2 = fmax(m2, a); m3 = fmax(m3, c);
+                    } else {
+                        if constexpr (BP) { k0 = a > m0 ? 2 * m : k0; k1 = c > m1 ? 2 * m + 1 : k1; }
+                        m0 = fmax(m0, a); m1 = fmax(m1, c);
+                    }
                 }
+            }
+            if constexpr (BP) {
+                // backpointer row of the gene this step starts from (gbrs_utils.py:567-579 takes argmax(delta[:, t] + T[t][j]):
+                // the first maximum): merge the four running maxima, the smaller index on equal values
+                if (act && sv[b]) bp[((int64_t)(blockIdx.x * SB + b) * bp_per_sample + cd.bp_off + o) * SS + j] =
+                    (uint16_t)first_max4(m0, k0, m1, k1, m2, k2, m3, k3);
             }
             const double d = fmax(fmax(m0, m1), fmax(m2, m3)) + e_now[b];
             if (act) buf[b][cur ^ 1][j] = d;
@@ -1086,6 +1108,31 @@ forward_wave_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *__
 #pragma unroll
     for (int u = 0; u < NSET - 1; ++u)
         if (o + u < n_ord) step(o + u, pr[u], em_r[u], pr[(u + NSET - 1) % NSET], em_r[(u + NSET - 1) % NSET]);
+    if constexpr (BP) {
+        // the chromosome's last gene has a backpointer row too when its transition block exists (tprob of length n, the DO
+        // convention): argmax(delta[:, n-1] + T[n-1][j]) - no step of the recursion uses that block
+        if (cd.real_chrom >= 0 && cd.n_trans > n_ord) {
+            double tl[SS];
+            load_lane<SS>(BLK + (int64_t)n_ord * SS * SS, jr, tl);
+#pragma unroll
+            for (int b = 0; b < SB; ++b) {
+                const double2 *dp = reinterpret_cast<const double2 *>(buf[b][cur]);
+                double m0 = 0.0, m1 = 0.0, m2 = 0.0, m3 = 0.0;
+                int k0 = 0, k1 = 1, k2 = 2, k3 = 3;
+#pragma unroll
+                for (int m = 0; m < SS / 2; ++m) {
+                    const double2 v = dp[m];
+                    const double a = v.x + tl[2 * m], c = v.y + tl[2 * m + 1];
+                    if (m == 0) { m0 = a; m1 = c; }
+                    else if (m == 1) { m2 = a; m3 = c; }
+                    else if (m & 1) { k2 = a > m2 ? 2 * m : k2; k3 = c > m3 ? 2 * m + 1 : k3; m2 = fmax(m2, a); m3 = fmax(m3, c); }
+                    else { k0 = a > m0 ? 2 * m : k0; k1 = c > m1 ? 2 * m + 1 : k1; m0 = fmax(m0, a); m1 = fmax(m1, c); }
+                }
+                if (act && sv[b]) bp[((int64_t)(blockIdx.x * SB + b) * bp_per_sample + cd.bp_off + n_ord) * SS + j] =
+                    (uint16_t)first_max4(m0, k0, m1, k1, m2, k2, m3, k3);
+            }
+        }
+    }
     if (j < SB && blockIdx.x * SB + j < n_samples && cd.real_chrom >= 0) {      // sid = argmax delta[:, n-1] (first max)
         const double *dl = buf[j][cur];
         double bv = dl[0];
@@ -2465,19 +2512,23 @@ int hmm_prepare_blocks(gbrs_hmm *h) {
                     const int lo = cuts[q].first, hi = cuts[q].second;
                     const int v = (int)ranges.size();
                     const bool is_direct = direct && (dir == 0 ? q == 0 : q + 1 == cuts.size());
-                    ranges.push_back(BlockRange{cd.gene_off, cd.trans_off, lo, hi, n, c, is_direct ? 1 : 0});
+                    ranges.push_back(BlockRange{cd.gene_off, cd.trans_off, lo, hi, n, c, is_direct ? 1 : 0, cd.bp_off});
                     (is_direct ? heads : rest).push_back(v);
-                    ChromDesc d = cd;               // bp_off / chunk_off are not used by the chain kernels
+                    ChromDesc d = cd;               // chunk_off is not used by the chain kernels
                     if (dir == 0) {
                         if (lo > 0) {               // forward / delta: starts on the previous block's last gene
                             d.gene_off = cd.gene_off + lo - 1;
                             d.trans_off = cd.trans_off + lo - 1;
+                            d.bp_off = cd.bp_off + lo - 1;      // the delta chain writes the backpointer rows of its steps
                             d.n_genes = hi - lo + 1;
                             d.inject = v;
                         } else {
                             d.n_genes = hi;
                         }
                         d.n_trans = d.n_genes;      // every step of the block has its transition block
+                        // the chromosome's last block: one more block exactly when the chromosome has T[n-1] (its last
+                        // backpointer row, forward_wave_kernel BP)
+                        if (hi == n) d.n_trans = d.n_genes - 1 + (cd.n_trans >= n ? 1 : 0);
                         d.real_chrom = hi == n ? c : -1;
                         vf.push_back(d);
                     } else {
@@ -2758,7 +2809,8 @@ int hmm_launch(gbrs_hmm *h) {
             auto k_back = batched ? &backward_wave_kernel<SS, HMM_NSET_B, HMM_SB> : &backward_wave_kernel<SS, HMM_NSET, 1>;
             // the blocked scan's chains (~40 steps each, ~1,000 wavefronts per kernel): two register sets, fewer hoisted reads
             auto kb_alpha = &forward_wave_kernel<SS, 2, 1, 0, HMM_HOIST_BLK>;
-            auto kb_delta = &forward_wave_kernel<SS, 2, 1, 1, HMM_HOIST_BLK>;
+            auto kb_delta = &forward_wave_kernel<SS, 2, 1, 1, HMM_HOIST_BLK, true>;          // backpointers in the same pass over T
+            auto kf_delta = &forward_wave_kernel<SS, HMM_NSET, 1, 1, HMM_HOIST_D, true>;       // the fallback chain behind the fix-up
             auto kb_back = &backward_wave_kernel<SS, 2, 1>;
             // GBRS_TUNING_HMM_MFMA = smallest batch that takes the MFMA sweeps (0: never) - the parity tests run them at 16
             int mfma_min = HMM_MFMA_MIN;
@@ -2798,7 +2850,7 @@ int hmm_launch(gbrs_hmm *h) {
                             hipLaunchKernelGGL(kb_alpha, dim3(h->n_samples, count), dim3(64), 0, q, h->n_samples, h->total_genes,
                                                h->d_vfwd.p, h->d_vorder[0].p + first, h->tprob_q.p, h->pprob.p, h->eprob.p, h->peprob.p,
                                                h->init_vec.p, h->xsum.p, h->invz.p, h->delta.p, h->last_state.p, h->inj_f.p, h->n_chrom,
-                                               h->n_vb, (const int32_t *)nullptr);
+                                               h->n_vb, (const int32_t *)nullptr, (uint16_t *)nullptr, (int64_t)0);
                     };
                     if (h->n_head[0]) {
                         (void)hipStreamWaitEvent(h->stream_h[0], h->ev_fork, 0);
@@ -2817,7 +2869,7 @@ int hmm_launch(gbrs_hmm *h) {
                 hipLaunchKernelGGL(k_alpha, wave_grid, dim3(64), 0, st, h->n_samples, h->total_genes,
                                    h->d_chroms.p, h->d_order.p, h->tprob_q.p, h->pprob.p, h->eprob.p, h->peprob.p,
                                    h->init_vec.p, h->xsum.p, h->invz.p, h->delta.p, h->last_state.p, (const double *)nullptr,
-                                   h->n_chrom, 0, (const int32_t *)nullptr);
+                                   h->n_chrom, 0, (const int32_t *)nullptr, (uint16_t *)nullptr, (int64_t)0);
             };
             launch_back = [=](hipStream_t st) {
                 if (mfma) {
@@ -2880,7 +2932,7 @@ int hmm_launch(gbrs_hmm *h) {
                             hipLaunchKernelGGL(kb_delta, dim3(h->n_samples, count), dim3(64), 0, q, h->n_samples, h->total_genes,
                                                h->d_vfwd.p, h->d_vorder[0].p + first, h->tprob_q.p, h->pprob.p, h->eprob.p, h->peprob.p,
                                                h->init_vec.p, h->xsum.p, h->invz.p, h->delta.p, h->last_state.p, h->inj_d.p, h->n_chrom,
-                                               h->n_vb, (const int32_t *)nullptr);
+                                               h->n_vb, (const int32_t *)nullptr, h->bp.p, h->total_bp);
                     };
                     if (delta_spec) {
                         // rank convergence instead of block operators (hmm_blocked.inc): guess -> chains in all blocks -> fix-up in
@@ -2891,11 +2943,11 @@ int hmm_launch(gbrs_hmm *h) {
                         chains(st, 0, h->n_blk[0]);
                         hipLaunchKernelGGL(delta_fixup_kernel<SS>, bgrid, dim3(64), 0, st, h->total_genes, h->n_vb, h->n_chrom,
                                            h->d_ranges[0].p, h->tprob_q.p, h->eprob.p, h->delta.p, h->dspec_c.p, h->dspec_g.p,
-                                           h->dspec_fail.p, delta_tol_abs, delta_tol_rel);
-                        hipLaunchKernelGGL(k_delta, wave_grid, dim3(64), 0, st, h->n_samples, h->total_genes,
+                                           h->dspec_fail.p, delta_tol_abs, delta_tol_rel, h->bp.p, h->total_bp);
+                        hipLaunchKernelGGL(kf_delta, wave_grid, dim3(64), 0, st, h->n_samples, h->total_genes,
                                            h->d_chroms.p, h->d_order.p, h->tprob_q.p, h->pprob.p, h->eprob.p, h->peprob.p,
                                            h->init_vec.p, h->xsum.p, h->invz.p, h->delta.p, h->last_state.p, (const double *)nullptr,
-                                           h->n_chrom, 0, (const int32_t *)h->dspec_fail.p);
+                                           h->n_chrom, 0, (const int32_t *)h->dspec_fail.p, h->bp.p, h->total_bp);
                         return;
                     }
                     if (h->n_head[0]) {
@@ -2915,7 +2967,7 @@ int hmm_launch(gbrs_hmm *h) {
                 hipLaunchKernelGGL(k_delta, wave_grid, dim3(64), 0, st, h->n_samples, h->total_genes,
                                    h->d_chroms.p, h->d_order.p, h->tprob_q.p, h->pprob.p, h->eprob.p, h->peprob.p,
                                    h->init_vec.p, h->xsum.p, h->invz.p, h->delta.p, h->last_state.p, (const double *)nullptr,
-                                   h->n_chrom, 0, (const int32_t *)nullptr);
+                                   h->n_chrom, 0, (const int32_t *)nullptr, (uint16_t *)nullptr, (int64_t)0);
             };
         } else {
             const dim3 quad_grid(h->n_samples, h->n_chrom), quad_block(threads);
@@ -2949,7 +3001,7 @@ int hmm_launch(gbrs_hmm *h) {
         launch_back(sb);
         GBRS_HIP_CHECK(hipEventRecord(h->ev_b, sb));
         launch_delta(sc);
-        if (h->max_bp_rows > 0) {
+        if (h->max_bp_rows > 0 && !h->last_blocked) {     // the blocked scan's delta chains write the backpointers themselves
             if constexpr (QUAD)
                 hipLaunchKernelGGL((viterbi_bp_quad_kernel<KMAX>), dim3(h->max_bp_rows, h->n_chrom), dim3(threads), 0,
                                    sc, h->n_samples, h->total_genes, h->total_bp, h->d_chroms.p, h->tprob_q.p,
