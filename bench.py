@@ -628,6 +628,10 @@ def hmm_bench(args, torch, ns=None, with_cpu=True, sample_seed=1):
         emis.append(inf.last_emission_ms)
         tot.append(inf.last_emission_ms + inf.last_run_ms)   # device time; the run's chains overlap
     inf = hmm.info()
+    rank = dict(blocks_fixed_up=int(inf.last_delta_blocks), longest_fixup_genes=int(inf.last_delta_longest_fixup),
+                fallbacks=int(inf.last_delta_fallbacks),
+                note="blocked scan (1-3 samples): Viterbi values by rank convergence - blocks whose values were matched to the "
+                     "block before them, the longest such fix-up, (sample, chromosome) pairs recomputed by the sequential chain")
     ms = float(np.median(tot))
     wall_ms = float(np.median(wall))
     t0 = time.perf_counter()
@@ -646,6 +650,7 @@ def hmm_bench(args, torch, ns=None, with_cpu=True, sample_seed=1):
                                     "+ run, median of the timed passes; the transition and specificity tables are "
                                     "resident on the handle; `value` above is device-event time of the same passes"),
                genes=prob.num_genes, states=HH * (HH + 1) // 2,
+               **({"delta_rank_convergence": rank} if rank["blocks_fixed_up"] or rank["fallbacks"] else {}),
                kernels_ms=dict(emission=inf.last_emission_ms, forward_viterbi=inf.last_forward_ms,
                                backward_posterior=inf.last_backward_ms, backtrace=inf.last_backtrace_ms,
                                run=inf.last_run_ms,

@@ -41,3 +41,7 @@ for _ in range(passes):
 m = np.median(np.array(tot), axis=0)
 print(f"samples {ns}: device {m[0]:.4f} ms  run wall {m[1]:.3f} ms  forward {m[2]:.3f}  backward {m[3]:.3f}  "
       f"{prob.num_genes * ns / m[0] / 1e3:.1f} M genes/s   set_expression wall {m[4]:.3f} ms, set + run wall {m[4] + m[1]:.3f} ms")
+inf = hmm.info()
+if inf.last_delta_blocks or inf.last_delta_fallbacks:
+    print(f"delta by rank convergence: {inf.last_delta_blocks} blocks fixed up, longest fix-up {inf.last_delta_longest_fixup} genes, "
+          f"{inf.last_delta_fallbacks} (sample, chromosome) fallbacks")
