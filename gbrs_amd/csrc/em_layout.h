@@ -48,23 +48,35 @@ constexpr int TILE_WAVES = TILE_THREADS / 64;
 constexpr int TILE_WORDS = GBRS_TILE_WORDS, TILE_WORDS_MAX = GBRS_TILE_CAP - 64, TILE_ROUNDS_MIN = 1;
 static_assert(TILE_WORDS <= TILE_WORDS_MAX, "a tile's padded words must fit the dictionary sort");
 // rows with more distinct loci than this go to the long-row path
-__host__ __device__ constexpr int pos_bits(int H) { return H <= 8 ? 5 : 4; }
+// (more than 8 haplotypes: 3 bits - rows of up to 8 loci in the tiles - leave 10 bits of dictionary index beside a 16-bit
+// mask; with 4 + 4 bits the index had 8, and 256 loci per tile is less than the 16-haplotype kernel's LDS holds)
+__host__ __device__ constexpr int pos_bits(int H) { return H <= 8 ? 5 : 3; }
 __host__ __device__ constexpr int max_row_words(int H) { return 1 << pos_bits(H); }
 #ifndef GBRS_LDS_DOUBLES
 #define GBRS_LDS_DOUBLES 3072
 #endif
 #ifndef GBRS_LDS_DOUBLES_WEIGHTED
-#define GBRS_LDS_DOUBLES_WEIGHTED 4096
+#define GBRS_LDS_DOUBLES_WEIGHTED 4608         // round 4: 4,096 -> 4,608 (74 KB per workgroup, two per CU): merged C2 rows 0.0441 -> 0.0435 ms
 #endif
 // theta of the tile (D_MAX * H doubles) and, 64 doubles larger, its privatised partial sums.  Unweighted
 // layouts use 3,072 doubles (49 KB per workgroup with the sums: three workgroups per CU, which the
 // 72-register unweighted kernel fills); the weighted kernels need ~120 registers, two workgroups per CU
 // is all they can have, so their tiles take the larger dictionaries.
-__host__ __device__ constexpr int lds_theta_doubles(bool weighted) { return weighted ? GBRS_LDS_DOUBLES_WEIGHTED : GBRS_LDS_DOUBLES; }
-__host__ __device__ constexpr int lds_acc_doubles(bool weighted) { return lds_theta_doubles(weighted) + 64; }
+// 16 haplotypes, unweighted: the kernel needs ~126 registers, two workgroups per CU is all it can have, and a locus takes 16
+// doubles - with 3,072 doubles a tile held 192 loci and the config-5 shard's tiles 9 k words, half of them prologue and
+// epilogue; 4,800 doubles (78 KB per workgroup with the sums, two per CU) hold 300 loci.
+#ifndef GBRS_LDS_DOUBLES_H16
+#define GBRS_LDS_DOUBLES_H16 4800
+#endif
+// a word is [dictionary index | words left in the row | position in the row | haplotype mask]: 32 - H - 2 pos_bits(H) bits of index
+__host__ __device__ constexpr uint32_t dict_index_limit(int H) { return 1u << (32 - H - 2 * pos_bits(H)); }
+__host__ __device__ constexpr int lds_theta_doubles(bool weighted, int H) {
+    return weighted ? GBRS_LDS_DOUBLES_WEIGHTED : (H == 16 ? GBRS_LDS_DOUBLES_H16 : GBRS_LDS_DOUBLES);
+}
+__host__ __device__ constexpr int lds_acc_doubles(bool weighted, int H) { return lds_theta_doubles(weighted, H) + 64; }
 // deterministic mode (GBRS_EM_DETERMINISTIC): every wavefront of a tile owns a private copy of the tile's
 // sums, so a tile may reference at most this many loci
-__host__ __device__ constexpr uint32_t det_dict_cap(int H, bool weighted) { return (lds_acc_doubles(weighted) / TILE_WAVES - 1) / H; }
+__host__ __device__ constexpr uint32_t det_dict_cap(int H, bool weighted) { return (lds_acc_doubles(weighted, H) / TILE_WAVES - 1) / H; }
 constexpr uint32_t SLOT_DIRECT = 0x80000000u;
 constexpr uint32_t SLOT_SET = 0x40000000u;    // slot_dest of a locus-set entry: offset of its destination list in dest_list
 constexpr uint32_t SLOT_PAIR = 0x20000000u;   // slot_dest of a two-member set: first destination here, second in dest_b

@@ -1164,7 +1164,8 @@ int build_tile_layout(TileLayout &out, uint64_t R, uint32_t L_in, uint32_t H, ui
         GBRS_HIP_CHECK(hipStreamSynchronize(s));
         return GBRS_OK;
     };
-    out.d_max = std::min<uint32_t>(1024, lds_theta_doubles(merge || count != nullptr) / H);
+    out.d_max = std::min<uint32_t>(1024, lds_theta_doubles(merge || count != nullptr, (int)H) / H);
+    out.d_max = std::min<uint32_t>(out.d_max, dict_index_limit((int)H));     // what a word's index field can hold (256 at H = 16)
     out.deterministic = deterministic;
     if (deterministic) out.d_max = std::min<uint32_t>(out.d_max, det_dict_cap(H, merge || count != nullptr));
     if (dict_cap) out.d_max = std::min<uint32_t>(out.d_max, std::max<uint32_t>(dict_cap, (uint32_t)max_row_words(H) + 1));

@@ -720,6 +720,38 @@ def _mask_group_rows_problem(R, H, L, seed, max_loci, n_lists=None):
     return indptr, indices, np.ascontiguousarray(eff)
 
 
+@pytest.mark.parametrize("max_loci,sets", [(1, "0"), (2, "1"), (14, "1")])
+def test_em_sixteen_haplotypes_wide_dictionaries_and_long_rows(max_loci, sets, monkeypatch):
+    """Round 4: a 16-haplotype word keeps 3 + 3 bits for the row position fields and 10 bits of dictionary index (before:
+    4 + 4 and 8), so that a tile can reference the 300 loci its 78 KB of LDS hold.  Many thin loci, so that tiles really fill
+    their dictionaries past 256 entries; rows of up to 14 loci, of which those above 8 now take the long-row path.  Prepare,
+    four steps and the expected counts against the oracle, default and deterministic."""
+    from gbrs_amd.engine import EmEngine
+    from oracle.em_oracle import EMOracle
+    monkeypatch.setenv("GBRS_TUNING_GROUP_SETS", sets)
+    monkeypatch.setenv("GBRS_TUNING_SET_MIN_ROWS", "8")
+    monkeypatch.setenv("GBRS_TUNING_TILE_WORDS", "16000")        # tiles end where their dictionaries are full, not their words
+    R, H, L = 120_000, 16, 40_000
+    indptr, indices, eff = _mask_group_rows_problem(R, H, L, 977 + max_loci, max_loci, n_lists=R // 2)
+    o = EMOracle(R, L, H, indptr, indices, None)
+    o.prepare(0.0, eff)
+    theta0 = o.theta.copy()
+    o.run(tol=0.0, max_iters=4)
+    for flags in (0, 32):
+        eng = EmEngine.from_host(R, L, H, indptr, indices, None, eff, flags=flags)
+        inf = eng.info()
+        assert inf.layout == 1
+        if flags == 0 and max_loci == 1:
+            assert inf.num_slots / inf.num_tiles > 256            # dictionaries wider than the old 8-bit index
+        assert (inf.num_long_rows > 0) == (max_loci > 8)
+        eng.prepare(0.0)
+        close(eng.theta(), theta0)
+        eng.step(4)
+        close(eng.theta(), o.theta)
+        close(eng.expected_counts(), o.expected_read_counts())
+        eng.close()
+
+
 @pytest.mark.parametrize("R,H,L,hi,min_rows", [(6000, 8, 300, 5, 1), (6000, 8, 300, 5, 16), (20000, 8, 3000, 7, 4),
                                                (5000, 16, 400, 6, 2), (3000, 4, 100, 9, 1), (4000, 2, 150, 4, 1)])
 def test_em_mask_group_sets_vs_oracle(R, H, L, hi, min_rows, monkeypatch):
