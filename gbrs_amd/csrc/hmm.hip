@@ -1658,6 +1658,40 @@ __device__ __forceinline__ void mfma_store_row(double *__restrict__ row9, const 
     row9[8] = v[8];
 }
 
+// The same rows, stored coalesced (round 4).  Lane (g, n) holds nine states of sample n: stored straight from the lanes a
+// 16-byte store instruction touches three cache lines of each of the 16 samples' rows, five instructions 240 partial lines per
+// step - two thirds of all the cache-line transactions of a sweep's wavefront, and what the sweeps of a large batch waited for
+// (a timing-only build without these stores: alpha 4.5 -> 3.4 ms alone, 9.3 -> 6.5 side by side).  Staged through LDS as
+// [sample][state], the wavefront writes the 16 rows as 288 consecutive 16-byte pieces: every line once.
+// dst[k]: where piece 64 k + lane goes (its sample's row of gene 0); stage: 16 x 36 doubles of this wavefront.
+constexpr int MF_STAGE_STORES = (16 * MF_S / 2 + 63) / 64;                  // 5
+__device__ __forceinline__ void mfma_stage_targets(double *__restrict__ base /* [sample][gene][state] at the chromosome's first gene */,
+                                                   int first_sample, int n_samples, int64_t genes_per_sample, int lane,
+                                                   double *(&dst)[MF_STAGE_STORES]) {
+#pragma unroll
+    for (int k = 0; k < MF_STAGE_STORES; ++k) {
+        const int c = min(64 * k + lane, 16 * MF_S / 2 - 1);
+        const int sample = min(first_sample + c / (MF_S / 2), n_samples - 1);
+        dst[k] = base + (int64_t)sample * genes_per_sample * MF_S + 2 * (c % (MF_S / 2));
+    }
+}
+__device__ __forceinline__ void mfma_store_rows_staged(double *__restrict__ stage, const double (&v)[MF_Q], int lane,
+                                                       double *const (&dst)[MF_STAGE_STORES], int64_t gene) {
+    double *w = stage + (lane & 15) * MF_S + 9 * (lane >> 4);
+#pragma unroll
+    for (int q = 0; q < MF_Q; ++q) w[q] = v[q];
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+    const double2 *rd = reinterpret_cast<const double2 *>(stage);
+#pragma unroll
+    for (int k = 0; k < MF_STAGE_STORES; ++k)
+        if (64 * k + lane < 16 * MF_S / 2) *reinterpret_cast<double2 *>(dst[k] + gene * MF_S) = rd[64 * k + lane];
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+}
+
 // D = M y for the three row blocks (third first: it carries Z, whose reciprocal the rest waits for)
 __device__ __forceinline__ void mfma_matvec(const double (&a)[2 * MF_PAIRS], const double (&y)[MF_Q], mfma_d4 &d0, mfma_d4 &d1,
                                             mfma_d4 &d2) {
@@ -1717,6 +1751,11 @@ alpha_mfma_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *__re
         }
         mfma_store_row(x_row[cg], x0);
     }
+    __shared__ __attribute__((aligned(16))) double stage[NG][16 * MF_S];
+    double *x_dst[NG][MF_STAGE_STORES];
+#pragma unroll
+    for (int cg = 0; cg < NG; ++cg)
+        mfma_stage_targets(xsum + cd.gene_off * S, ((int)blockIdx.x * NG + cg) * 16, n_samples, genes_per_sample, lane, x_dst[cg]);
     double a[NSET][2 * MF_PAIRS], pe[NSET][NG][MF_Q];
 #pragma unroll
     for (int u = 0; u < NSET; ++u) {
@@ -1738,20 +1777,32 @@ alpha_mfma_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *__re
             for (int q = 0; q < MF_Q; ++q) pe_now[cg][q] = pc[cg][q];
         // refill the set the previous step released (clamped index: past the end it re-reads the last block)
         const int of = min(o + NSET - 1, last_o);
+#if !defined(HMM_ABL_M_LOADS)                    // timing-only builds (HMM_ABL_M_*): what a step of the sweep waits for
         mfma_load_block(BLK + (int64_t)HMM_BLK(of) * MF_BLK, lane, an);
 #pragma unroll
         for (int cg = 0; cg < NG; ++cg) mfma_load_row(pe_row[cg] + (int64_t)(of + 1) * S, pn[cg]);
+#else
+        (void)an; (void)pn; (void)of;
+#endif
 #pragma unroll
         for (int cg = 0; cg < NG; ++cg) {
+#if defined(HMM_ABL_M_RECIP)
+            const double inv_z = __hiloint2double(0x7FE00000 - __double2hiint(d2[cg][1]), 0);
+#else
             const double inv_z = fast_recip_pos(d2[cg][1]);        // Z of the previous vector
+#endif
+#if !defined(HMM_ABL_M_STORES)
             if (g == 0) iz[cg][o] = inv_z;
+#endif
             double x[MF_Q];
 #pragma unroll
             for (int q = 0; q < MF_Q; ++q) {
                 x[q] = mfma_own(d0[cg], d1[cg], d2[cg], q) * inv_z + TINY;
                 y[cg][q] = x[q] * pe_now[cg][q];
             }
-            mfma_store_row(x_row[cg] + (int64_t)(o + 1) * S, x);
+#if !defined(HMM_ABL_M_STORES)
+            mfma_store_rows_staged(stage[cg], x, lane, x_dst[cg], o + 1);
+#endif
         }
     };
     int o = 0;
@@ -1809,6 +1860,11 @@ backward_mfma_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *_
     // order o <-> gene i = n-2-o, transition block i (the host checked n_trans >= n-1)
     const int n_ord = n - 1;
     const int last_o = max(n_ord - 1, 0);
+    __shared__ __attribute__((aligned(16))) double stage[NG][16 * MF_S];
+    double *b_dst[NG][MF_STAGE_STORES];
+#pragma unroll
+    for (int cg = 0; cg < NG; ++cg)
+        mfma_stage_targets(bhat + cd.gene_off * S, ((int)blockIdx.x * NG + cg) * 16, n_samples, genes_per_sample, lane, b_dst[cg]);
     double a[NSET][2 * MF_PAIRS], pe[NSET][NG][MF_Q];
 #pragma unroll
     for (int u = 0; u < NSET; ++u) {
@@ -1843,7 +1899,7 @@ backward_mfma_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *_
                 bh[q] = mfma_own(d0[cg], d1[cg], d2[cg], q) * r;
                 w[cg][q] = bh[q] * pe_now[cg][q];
             }
-            mfma_store_row(b_row[cg] + (int64_t)i * S, bh);
+            mfma_store_rows_staged(stage[cg], bh, lane, b_dst[cg], i);
         }
     };
     int o = 0;
@@ -1922,6 +1978,12 @@ delta_lanes_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *__r
     const int last_o = max(n_ord - 1, 0);
     const double *e_at = eprob + g0 * S + j;                    // + i * S: my state of gene i
     double *d_at = delta + g0 * S + j;
+    // The step's 16 new rows leave through LDS (round 4): the first 288 threads store them as consecutive 16-byte pieces
+    // (every cache line once) instead of each wavefront's 32 bytes of every sample's row (nine partial writes per row).
+    constexpr int ROW_PIECES = S / 2;                            // 18 pieces of 16 bytes
+    const bool storer = tid < DL_SAMPLES * ROW_PIECES;
+    const int st_slot = storer ? tid / ROW_PIECES : 0, st_piece = storer ? tid % ROW_PIECES : 0;
+    double *d_out = delta + ((int64_t)min((int)blockIdx.x * DL_SAMPLES + st_slot, n_samples - 1) * genes_per_sample + cd.gene_off) * S + 2 * st_piece;
     // row j of a block is 36 consecutive entries; register g of slot c holds entry 16 g + c
     const double *TB = tprob + cd.trans_off * (int64_t)BLK + (int64_t)j * S + c;
     const int third = c < S - 32 ? 32 : S - 1 - c;
@@ -1965,9 +2027,11 @@ delta_lanes_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *__r
         const double dn = fmax(fmax(m[0], m[1]), fmax(m[2], m[3])) + e_ring[u];
         fetch_step(o + DL_AHEAD, u);                            // after the last use of the slot: its registers are free again
         dbuf[cur ^ 1][c][j] = dn;
-        d_at[(int64_t)(o + 1) * S] = dn;
         cur ^= 1;
         __syncthreads();
+        // (this buffer is written again two steps on, behind the next barrier: the reads below are done by then)
+        if (storer)
+            *reinterpret_cast<double2 *>(d_out + (int64_t)(o + 1) * S) = *reinterpret_cast<const double2 *>(&dbuf[cur][st_slot][2 * st_piece]);
     };
     int ob = 0;
     for (; ob + DL_AHEAD <= n_ord; ob += DL_AHEAD) {           // whole groups: no branch between a fetch and its use
