@@ -1928,7 +1928,17 @@ backward_mfma_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *_
 // samples, and every double-precision instruction waiting on the one before it.)  Adds and maxima only, in any order:
 // the values are those of the other forms bit for bit.
 // ------------------------------------------------------------------------------------------
-constexpr int DL_WAVES = MF_S / 4, DL_SAMPLES = 16, DL_STRIDE = MF_S + 2;      // 38 doubles per sample: b128 reads of 16 lanes on 64 distinct banks
+// DL_T target states per lane (round 4 experiment).  A lane needs its sample's whole 36-vector in registers whatever it
+// computes, so with one target per lane the 576 threads of a workgroup read 166 KB from LDS per step and nine wavefronts
+// meet at the barrier; with three per lane it is 55 KB and three wavefronts (one 16-lane row = target states 3 r .. 3 r + 2),
+// the same (add, max) pairs - and SLOWER: 4.03 against 3.15 ms alone, 9.5 against 8.2 beside the sweeps (256 samples): the
+// kernel is bound by the dependent double-precision instructions of a wavefront, not by the LDS pipe.  1 stays.
+#ifndef HMM_DL_TARGETS
+#define HMM_DL_TARGETS 1
+#endif
+constexpr int DL_T = HMM_DL_TARGETS;
+static_assert(MF_S % (4 * DL_T) == 0, "rows of DL_T targets, four rows per wavefront");
+constexpr int DL_WAVES = MF_S / (4 * DL_T), DL_SAMPLES = 16, DL_STRIDE = MF_S + 2;   // 38 doubles per sample: b128 reads of 16 lanes on 64 distinct banks
 constexpr int DL_GROUPS = (MF_S + 15) / 16;                                     // 36 entries per row and step, 3 registers
 #ifndef HMM_DL_AHEAD
 #define HMM_DL_AHEAD 4
@@ -1970,42 +1980,48 @@ delta_lanes_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *__r
     const ChromDesc cd = chroms[chrom];
     const int n = cd.n_genes;
     if (n <= 0) return;
-    const int tid = threadIdx.x, c = tid & 15, j = tid >> 4;     // sample slot, target state (row-uniform)
+    const int tid = threadIdx.x, c = tid & 15, j0 = (tid >> 4) * DL_T;   // sample slot, first of the row's DL_T target states
     const int sample_raw = blockIdx.x * DL_SAMPLES + c;
     const int sample = min(sample_raw, n_samples - 1);           // slots past the end shadow the last sample (same values, same stores)
     const int64_t g0 = (int64_t)sample * genes_per_sample + cd.gene_off;
     const int n_ord = min(n, cd.n_trans + 1) - 1;               // step i = o + 1 needs block o
     const int last_o = max(n_ord - 1, 0);
-    const double *e_at = eprob + g0 * S + j;                    // + i * S: my state of gene i
-    double *d_at = delta + g0 * S + j;
-    // The step's 16 new rows leave through LDS (round 4): the first 288 threads store them as consecutive 16-byte pieces
-    // (every cache line once) instead of each wavefront's 32 bytes of every sample's row (nine partial writes per row).
-    constexpr int ROW_PIECES = S / 2;                            // 18 pieces of 16 bytes
-    const bool storer = tid < DL_SAMPLES * ROW_PIECES;
-    const int st_slot = storer ? tid / ROW_PIECES : 0, st_piece = storer ? tid % ROW_PIECES : 0;
-    double *d_out = delta + ((int64_t)min((int)blockIdx.x * DL_SAMPLES + st_slot, n_samples - 1) * genes_per_sample + cd.gene_off) * S + 2 * st_piece;
+    const double *e_at = eprob + g0 * S + j0;                   // + i * S + t: my states of gene i
+    // The step's 16 new rows leave through LDS: the workgroup stores them as consecutive 16-byte pieces (every cache line
+    // once) instead of each row's few bytes of every sample's row.
+    constexpr int ROW_PIECES = S / 2, PIECES = DL_SAMPLES * ROW_PIECES, THREADS = 64 * DL_WAVES;
+    constexpr int ST = (PIECES + THREADS - 1) / THREADS;
+    double *d_out[ST];
+    int st_off[ST];                                             // of the piece in a dbuf plane, in doubles; -1: none
+#pragma unroll
+    for (int q = 0; q < ST; ++q) {
+        const int piece = tid + q * THREADS;
+        const bool on = piece < PIECES;
+        const int slot = on ? piece / ROW_PIECES : 0, pc = on ? piece % ROW_PIECES : 0;
+        st_off[q] = on ? slot * DL_STRIDE + 2 * pc : -1;
+        d_out[q] = delta + ((int64_t)min((int)blockIdx.x * DL_SAMPLES + slot, n_samples - 1) * genes_per_sample + cd.gene_off) * S + 2 * pc;
+    }
     // row j of a block is 36 consecutive entries; register g of slot c holds entry 16 g + c
-    const double *TB = tprob + cd.trans_off * (int64_t)BLK + (int64_t)j * S + c;
+    const double *TB = tprob + cd.trans_off * (int64_t)BLK + (int64_t)j0 * S + c;
     const int third = c < S - 32 ? 32 : S - 1 - c;
-    auto fetch_row = [&](int o, double (&t)[DL_GROUPS]) {
-        const double *src = TB + (int64_t)HMM_BLK(o) * BLK;
-        t[0] = src[0];
-        t[1] = src[16];
-        t[2] = src[third];                                      // entries 32..35 in slots 0..3; the other slots re-read entry 35, unused
-    };
-    // the entries and the emission of a step are fetched DL_AHEAD steps before it: a step is shorter than a trip to HBM
-    double t_ring[DL_AHEAD][DL_GROUPS], e_ring[DL_AHEAD];
+    // the entries and the emissions of a step are fetched DL_AHEAD steps before it: a step is shorter than a trip to HBM
+    double t_ring[DL_AHEAD][DL_T][DL_GROUPS], e_ring[DL_AHEAD][DL_T];
     double one = 1.0;
     asm volatile("" : "+v"(one));                            // a register operand for the DPP form
     auto fetch_step = [&](int o, int slot) {                   // step i = o + 1; clamped: past the end it re-reads the last one
         const int oc = min(o, last_o);
-        e_ring[slot] = e_at[(int64_t)(oc + 1) * S];
-        fetch_row(oc, t_ring[slot]);
+        const double *src = TB + (int64_t)HMM_BLK(oc) * BLK;
+#pragma unroll
+        for (int t = 0; t < DL_T; ++t) {
+            e_ring[slot][t] = e_at[(int64_t)(oc + 1) * S + t];
+            t_ring[slot][t][0] = src[t * S];
+            t_ring[slot][t][1] = src[t * S + 16];
+            t_ring[slot][t][2] = src[t * S + third];            // entries 32..35 in slots 0..3; the other slots re-read entry 35, unused
+        }
     };
     {
-        const double d0 = init_vec[j] + e_at[0];
-        dbuf[0][c][j] = d0;
-        d_at[0] = d0;
+#pragma unroll
+        for (int t = 0; t < DL_T; ++t) dbuf[0][c][j0 + t] = init_vec[j0 + t] + e_at[t];
         if (n_ord > 0) {
 #pragma unroll
             for (int u = 0; u < DL_AHEAD; ++u) fetch_step(u, u);
@@ -2013,25 +2029,36 @@ delta_lanes_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *__r
     }
     __syncthreads();
     int cur = 0;
+    auto store_rows = [&](int gene) {                           // the rows in dbuf[cur], all threads
+#pragma unroll
+        for (int q = 0; q < ST; ++q)
+            if (st_off[q] >= 0)
+                *reinterpret_cast<double2 *>(d_out[q] + (int64_t)gene * S) = *reinterpret_cast<const double2 *>(&dbuf[cur][0][0] + st_off[q]);
+    };
+    store_rows(0);
     auto step = [&](int o, int u) {                            // u: a constant after unrolling (the ring is in registers)
         double dp[S];
-        const mf_pair *src = reinterpret_cast<const mf_pair *>(&dbuf[cur][c][0]);
+        const double2 *src = reinterpret_cast<const double2 *>(&dbuf[cur][c][0]);
 #pragma unroll
         for (int k2 = 0; k2 < S / 2; ++k2) {
-            const mf_pair pr = src[k2];
+            const double2 pr = src[k2];
             dp[2 * k2] = pr.x;
             dp[2 * k2 + 1] = pr.y;
         }
-        double m[4];
-        dl_from<0>(t_ring[u], dp, one, m);
-        const double dn = fmax(fmax(m[0], m[1]), fmax(m[2], m[3])) + e_ring[u];
+        double dn[DL_T];
+#pragma unroll
+        for (int t = 0; t < DL_T; ++t) {
+            double m[4];
+            dl_from<0>(t_ring[u][t], dp, one, m);
+            dn[t] = fmax(fmax(m[0], m[1]), fmax(m[2], m[3])) + e_ring[u][t];
+        }
         fetch_step(o + DL_AHEAD, u);                            // after the last use of the slot: its registers are free again
-        dbuf[cur ^ 1][c][j] = dn;
+#pragma unroll
+        for (int t = 0; t < DL_T; ++t) dbuf[cur ^ 1][c][j0 + t] = dn[t];
         cur ^= 1;
         __syncthreads();
-        // (this buffer is written again two steps on, behind the next barrier: the reads below are done by then)
-        if (storer)
-            *reinterpret_cast<double2 *>(d_out + (int64_t)(o + 1) * S) = *reinterpret_cast<const double2 *>(&dbuf[cur][st_slot][2 * st_piece]);
+        // (this buffer is written again two steps on, behind the next barrier: the reads of store_rows are done by then)
+        store_rows(o + 1);
     };
     int ob = 0;
     for (; ob + DL_AHEAD <= n_ord; ob += DL_AHEAD) {           // whole groups: no branch between a fetch and its use
@@ -2041,7 +2068,7 @@ delta_lanes_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *__r
 #pragma unroll
     for (int u = 0; u < DL_AHEAD - 1; ++u)
         if (ob + u < n_ord) step(ob + u, u);                    // block-uniform
-    if (j == 0 && sample_raw < n_samples) {                     // sid = argmax delta[:, n-1] (first max)
+    if (tid < DL_SAMPLES && sample_raw < n_samples) {           // sid = argmax delta[:, n-1] (first max)
         double bv = dbuf[cur][c][0];
         int bk = 0;
         for (int s2 = 1; s2 < S; ++s2) {
