@@ -151,7 +151,7 @@ def load():
         fn.argtypes = args
     lib.gbrs_em_stream.restype = vp
     lib.gbrs_em_stream.argtypes = [vp]
-    if lib.gbrs_abi_version() != 4:
+    if lib.gbrs_abi_version() != 5:
         raise ImportError("libgbrs_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define GBRS_ABI_VERSION 4
+#define GBRS_ABI_VERSION 5
 
 enum gbrs_status {
     GBRS_OK = 0,

@@ -18,7 +18,7 @@ def test_header_symbols_exported(hip_lib):
     for n in names:
         assert hasattr(hip_lib, n), f"{n} declared in gbrs_hip.h but not exported"
     assert sorted(_lib.EXPORTS) == names
-    assert hip_lib.gbrs_abi_version() == 4
+    assert hip_lib.gbrs_abi_version() == 5
 
 
 def test_header_constants_match_python_mirror():
@@ -42,7 +42,7 @@ def test_struct_sizes(tmp_path):
     import subprocess
     from gbrs_amd import _lib
     assert C.sizeof(_lib.EmInfo) == 8 * 8 + 4 * 4 + 8 * 8
-    assert C.sizeof(_lib.HmmInfo) == 2 * 8 + 4 * 8 + 2 * 4 + 8
+    assert C.sizeof(_lib.HmmInfo) == 2 * 8 + 4 * 8 + 2 * 4 + 8 + 4 * 4
     cc = shutil.which("gcc") or shutil.which("cc")
     if cc is None:
         return
