@@ -630,7 +630,7 @@ def hmm_bench(args, torch, ns=None, with_cpu=True, sample_seed=1):
     inf = hmm.info()
     rank = dict(blocks_fixed_up=int(inf.last_delta_blocks), longest_fixup_genes=int(inf.last_delta_longest_fixup),
                 fallbacks=int(inf.last_delta_fallbacks),
-                note="blocked scan (1-3 samples): Viterbi values by rank convergence - blocks whose values were matched to the "
+                note="blocked scan (1-4 samples): Viterbi values by rank convergence - blocks whose values were matched to the "
                      "block before them, the longest such fix-up, (sample, chromosome) pairs recomputed by the sequential chain")
     ms = float(np.median(tot))
     wall_ms = float(np.median(wall))

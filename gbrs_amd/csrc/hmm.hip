@@ -2554,8 +2554,9 @@ int hmm_make_logs(gbrs_hmm *h) {
 #endif                               // default - measured (round 4): 256 samples 16.3-16.7 ms either way, 128: 9.2 -> 12.0, 64: 6.9 -> 9.3
 
 #ifndef HMM_BLOCKED_MAX
-#define HMM_BLOCKED_MAX 3     // 36 states, at most this many samples: the blocked scan (the sum-product operators cost 36 columns per block and sample;
-                              // round 4, Viterbi values by rank convergence: 0.77 / 1.13 / 1.60 ms at 1 / 2 / 3 samples against 1.9-2.0 on the chains, equal at 4)
+#define HMM_BLOCKED_MAX 4     // 36 states, at most this many samples: the blocked scan (the sum-product operators cost 36 columns per block and sample;
+                              // round 4, Viterbi values by rank convergence: 0.63 / 1.01 / 1.51 / 1.85 ms at 1 / 2 / 3 / 4 samples against 1.9-2.0 on the
+                              // chains; 5 samples 2.25 against 2.0)
 #endif
 #ifndef HMM_DELTA_SPEC
 #define HMM_DELTA_SPEC 1      // blocked scan: Viterbi values by rank convergence (one chain per block + fix-up) instead of max-plus block operators
