@@ -352,7 +352,7 @@ typedef struct gbrs_hmm_info {
     double   last_emission_ms, last_forward_ms, last_backward_ms, last_backtrace_ms;
     int32_t  num_states, n_samples;
     double   last_run_ms;
-    /* Blocked scan (1-2 samples): the Viterbi values of the last run by rank convergence - blocks whose values were
+    /* Blocked scan (1-4 samples): the Viterbi values of the last run by rank convergence - blocks whose values were
      * matched to the block before them, the longest such fix-up in genes, and (sample, chromosome) pairs that were
      * recomputed by the sequential chain because a block did not converge.  0 on every other path. */
     int32_t  last_delta_blocks, last_delta_longest_fixup, last_delta_fallbacks, reserved0;
