@@ -331,6 +331,26 @@ emission_batch_kernel(int64_t n_genes, int n_samples, int samples_per_block, con
 #endif
 #define HMM_CHAIN_WAVES(NSET) ((NSET) <= 2 ? HMM_BLK_WAVES : 1)
 
+// Where the per-(sample, gene) rows of eprob / peprob / xsum / bhat / delta / invz / bscale sit: row = sample * sample_stride +
+// gene * gene_stride.  {genes_per_sample, 1} is [sample][gene] (a sample's genes contiguous: what gbrs_hmm_get copies out);
+// {1, n_samples} is [gene][sample] (the 16 samples of a wavefront's step contiguous).
+struct RowMap {
+    int64_t sample_stride, gene_stride;
+    // XCD-aware 1-D grids of the batch chain kernels (GBRS_TUNING_HMM_XCD): workgroup L runs on XCD L % 8, and all
+    // xcd_groups sample groups of a chromosome are put on one XCD, so that its transition blocks are fetched into one L2
+    // instead of eight: chromosome order index = L % 8 + 8 * ((L / 8) / xcd_groups), group = (L / 8) % xcd_groups.  0: 2-D grid.
+    int32_t xcd_groups = 0, n_order = 0;
+    __device__ __forceinline__ bool place(int &bx, int &by) const {
+        if (xcd_groups > 0) {
+            const int k = bx & 7, sl = bx >> 3;
+            by = k + 8 * (sl / xcd_groups);
+            bx = sl % xcd_groups;
+            return by < n_order;
+        }
+        return true;
+    }
+};
+
 struct ChromDesc {
     int64_t gene_off;     // offset of the chromosome's first gene in the per-sample gene axis
     int64_t trans_off;    // offset (in S*S blocks) of tprob[c][0] in the transition buffer
@@ -1666,13 +1686,13 @@ __device__ __forceinline__ void mfma_store_row(double *__restrict__ row9, const 
 // dst[k]: where piece 64 k + lane goes (its sample's row of gene 0); stage: 16 x 36 doubles of this wavefront.
 constexpr int MF_STAGE_STORES = (16 * MF_S / 2 + 63) / 64;                  // 5
 __device__ __forceinline__ void mfma_stage_targets(double *__restrict__ base /* [sample][gene][state] at the chromosome's first gene */,
-                                                   int first_sample, int n_samples, int64_t genes_per_sample, int lane,
+                                                   int first_sample, int n_samples, int64_t sample_stride /* rows */, int lane,
                                                    double *(&dst)[MF_STAGE_STORES]) {
 #pragma unroll
     for (int k = 0; k < MF_STAGE_STORES; ++k) {
         const int c = min(64 * k + lane, 16 * MF_S / 2 - 1);
         const int sample = min(first_sample + c / (MF_S / 2), n_samples - 1);
-        dst[k] = base + (int64_t)sample * genes_per_sample * MF_S + 2 * (c % (MF_S / 2));
+        dst[k] = base + (int64_t)sample * sample_stride * MF_S + 2 * (c % (MF_S / 2));
     }
 }
 __device__ __forceinline__ void mfma_store_rows_staged(double *__restrict__ stage, const double (&v)[MF_Q], int lane,
@@ -1716,7 +1736,7 @@ __device__ __forceinline__ double mfma_own(const mfma_d4 &d0, const mfma_d4 &d1,
 // twice as long).  GBRS_TUNING_HMM_MFMA_NG=2 selects it; parity-tested at 16-70 samples.
 template <int NSET, int NG>
 __global__ void __launch_bounds__(64)
-alpha_mfma_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *__restrict__ chroms,
+alpha_mfma_kernel(int n_samples, RowMap rm, const ChromDesc *__restrict__ chroms,
                   const int32_t *__restrict__ order, const double *__restrict__ amat,
                   const double *__restrict__ eprob, const double *__restrict__ peprob,
                   const double *__restrict__ init_vec, double *__restrict__ xsum, double *__restrict__ invz) {
@@ -1724,7 +1744,9 @@ alpha_mfma_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *__re
     asm volatile("v_accvgpr_write_b32 a255, 0" ::: "a255");
 #endif
     constexpr int S = MF_S;
-    const ChromDesc cd = chroms[order[blockIdx.y]];
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (!rm.place(bx, by)) return;
+    const ChromDesc cd = chroms[order[by]];
     const int n = cd.n_genes;
     if (n <= 0) return;
     const int lane = threadIdx.x, g = lane >> 4;
@@ -1736,8 +1758,8 @@ alpha_mfma_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *__re
     double y[NG][MF_Q];
 #pragma unroll
     for (int cg = 0; cg < NG; ++cg) {
-        const int sample = min(((int)blockIdx.x * NG + cg) * 16 + (lane & 15), n_samples - 1);   // past the end: shadows the last sample
-        const int64_t g0 = (int64_t)sample * genes_per_sample + cd.gene_off;
+        const int sample = min((bx * NG + cg) * 16 + (lane & 15), n_samples - 1);   // past the end: shadows the last sample
+        const int64_t g0 = (int64_t)sample * rm.sample_stride + cd.gene_off * rm.gene_stride;
         pe_row[cg] = peprob + g0 * S + 9 * g;
         x_row[cg] = xsum + g0 * S + 9 * g;
         iz[cg] = invz + g0;
@@ -1755,7 +1777,7 @@ alpha_mfma_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *__re
     double *x_dst[NG][MF_STAGE_STORES];
 #pragma unroll
     for (int cg = 0; cg < NG; ++cg)
-        mfma_stage_targets(xsum + cd.gene_off * S, ((int)blockIdx.x * NG + cg) * 16, n_samples, genes_per_sample, lane, x_dst[cg]);
+        mfma_stage_targets(xsum + cd.gene_off * rm.gene_stride * S, (bx * NG + cg) * 16, n_samples, rm.sample_stride, lane, x_dst[cg]);
     double a[NSET][2 * MF_PAIRS], pe[NSET][NG][MF_Q];
 #pragma unroll
     for (int u = 0; u < NSET; ++u) {
@@ -1763,7 +1785,7 @@ alpha_mfma_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *__re
         if (n_ord > 0) {
             mfma_load_block(BLK + (int64_t)HMM_BLK(ou) * MF_BLK, lane, a[u]);
 #pragma unroll
-            for (int cg = 0; cg < NG; ++cg) mfma_load_row(pe_row[cg] + (int64_t)(ou + 1) * S, pe[u][cg]);
+            for (int cg = 0; cg < NG; ++cg) mfma_load_row(pe_row[cg] + (int64_t)(ou + 1) * rm.gene_stride * S, pe[u][cg]);
         }
     }
     auto step = [&](int o, const double (&ac)[2 * MF_PAIRS], const double (&pc)[NG][MF_Q], double (&an)[2 * MF_PAIRS], double (&pn)[NG][MF_Q]) {
@@ -1780,7 +1802,7 @@ alpha_mfma_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *__re
 #if !defined(HMM_ABL_M_LOADS)                    // timing-only builds (HMM_ABL_M_*): what a step of the sweep waits for
         mfma_load_block(BLK + (int64_t)HMM_BLK(of) * MF_BLK, lane, an);
 #pragma unroll
-        for (int cg = 0; cg < NG; ++cg) mfma_load_row(pe_row[cg] + (int64_t)(of + 1) * S, pn[cg]);
+        for (int cg = 0; cg < NG; ++cg) mfma_load_row(pe_row[cg] + (int64_t)(of + 1) * rm.gene_stride * S, pn[cg]);
 #else
         (void)an; (void)pn; (void)of;
 #endif
@@ -1792,7 +1814,7 @@ alpha_mfma_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *__re
             const double inv_z = fast_recip_pos(d2[cg][1]);        // Z of the previous vector
 #endif
 #if !defined(HMM_ABL_M_STORES)
-            if (g == 0) iz[cg][o] = inv_z;
+            if (g == 0) iz[cg][o * rm.gene_stride] = inv_z;
 #endif
             double x[MF_Q];
 #pragma unroll
@@ -1801,7 +1823,7 @@ alpha_mfma_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *__re
                 y[cg][q] = x[q] * pe_now[cg][q];
             }
 #if !defined(HMM_ABL_M_STORES)
-            mfma_store_rows_staged(stage[cg], x, lane, x_dst[cg], o + 1);
+            mfma_store_rows_staged(stage[cg], x, lane, x_dst[cg], (o + 1) * rm.gene_stride);
 #endif
         }
     };
@@ -1821,21 +1843,23 @@ alpha_mfma_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *__re
         for (int q = 0; q < MF_Q; ++q) z += y[cg][q];
         z += __shfl_xor(z, 16, 64);
         z += __shfl_xor(z, 32, 64);
-        if (g == 0) iz[cg][n_ord] = fast_recip_pos(z);
+        if (g == 0) iz[cg][n_ord * rm.gene_stride] = fast_recip_pos(z);
     }
 }
 
 // free-running backward sweep (backward_wave_kernel's quantities, rescaled on every step: bscale is general)
 template <int NSET, int NG>
 __global__ void __launch_bounds__(64)
-backward_mfma_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *__restrict__ chroms,
+backward_mfma_kernel(int n_samples, RowMap rm, const ChromDesc *__restrict__ chroms,
                      const int32_t *__restrict__ order, const double *__restrict__ amat_t,
                      const double *__restrict__ peprob, double *__restrict__ bhat, double *__restrict__ bscale) {
 #if defined(HMM_DIAG_EXCL_MFMA)                  // diagnostic builds: the wavefront takes its SIMD's whole register file, nothing runs beside it
     asm volatile("v_accvgpr_write_b32 a255, 0" ::: "a255");
 #endif
     constexpr int S = MF_S;
-    const ChromDesc cd = chroms[order[blockIdx.y]];
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (!rm.place(bx, by)) return;
+    const ChromDesc cd = chroms[order[by]];
     const int n = cd.n_genes;
     if (n <= 0) return;
     const int lane = threadIdx.x, g = lane >> 4;
@@ -1845,17 +1869,17 @@ backward_mfma_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *_
     double w[NG][MF_Q];                               // pe_{i+1} * bt_{i+1}
 #pragma unroll
     for (int cg = 0; cg < NG; ++cg) {
-        const int sample = min(((int)blockIdx.x * NG + cg) * 16 + (lane & 15), n_samples - 1);
-        const int64_t g0 = (int64_t)sample * genes_per_sample + cd.gene_off;
+        const int sample = min((bx * NG + cg) * 16 + (lane & 15), n_samples - 1);
+        const int64_t g0 = (int64_t)sample * rm.sample_stride + cd.gene_off * rm.gene_stride;
         pe_row[cg] = peprob + g0 * S + 9 * g;
         b_row[cg] = bhat + g0 * S + 9 * g;
         bs[cg] = bscale + g0;
         double one[MF_Q];
 #pragma unroll
         for (int q = 0; q < MF_Q; ++q) one[q] = 1.0;
-        mfma_load_row(pe_row[cg] + (int64_t)(n - 1) * S, w[cg]);
-        mfma_store_row(b_row[cg] + (int64_t)(n - 1) * S, one);
-        if (g == 0) bs[cg][n - 1] = 1.0;
+        mfma_load_row(pe_row[cg] + (int64_t)(n - 1) * rm.gene_stride * S, w[cg]);
+        mfma_store_row(b_row[cg] + (int64_t)(n - 1) * rm.gene_stride * S, one);
+        if (g == 0) bs[cg][(n - 1) * rm.gene_stride] = 1.0;
     }
     // order o <-> gene i = n-2-o, transition block i (the host checked n_trans >= n-1)
     const int n_ord = n - 1;
@@ -1864,7 +1888,7 @@ backward_mfma_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *_
     double *b_dst[NG][MF_STAGE_STORES];
 #pragma unroll
     for (int cg = 0; cg < NG; ++cg)
-        mfma_stage_targets(bhat + cd.gene_off * S, ((int)blockIdx.x * NG + cg) * 16, n_samples, genes_per_sample, lane, b_dst[cg]);
+        mfma_stage_targets(bhat + cd.gene_off * rm.gene_stride * S, (bx * NG + cg) * 16, n_samples, rm.sample_stride, lane, b_dst[cg]);
     double a[NSET][2 * MF_PAIRS], pe[NSET][NG][MF_Q];
 #pragma unroll
     for (int u = 0; u < NSET; ++u) {
@@ -1872,7 +1896,7 @@ backward_mfma_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *_
         if (n_ord > 0) {
             mfma_load_block(BLK + (int64_t)HMM_BLK(i) * MF_BLK, lane, a[u]);
 #pragma unroll
-            for (int cg = 0; cg < NG; ++cg) mfma_load_row(pe_row[cg] + (int64_t)i * S, pe[u][cg]);
+            for (int cg = 0; cg < NG; ++cg) mfma_load_row(pe_row[cg] + (int64_t)i * rm.gene_stride * S, pe[u][cg]);
         }
     }
     auto step = [&](int o, const double (&ac)[2 * MF_PAIRS], const double (&pc)[NG][MF_Q], double (&an)[2 * MF_PAIRS], double (&pn)[NG][MF_Q]) {
@@ -1888,18 +1912,18 @@ backward_mfma_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *_
         const int in = n - 2 - min(o + NSET - 1, last_o);
         mfma_load_block(BLK + (int64_t)HMM_BLK(in) * MF_BLK, lane, an);
 #pragma unroll
-        for (int cg = 0; cg < NG; ++cg) mfma_load_row(pe_row[cg] + (int64_t)in * S, pn[cg]);
+        for (int cg = 0; cg < NG; ++cg) mfma_load_row(pe_row[cg] + (int64_t)in * rm.gene_stride * S, pn[cg]);
 #pragma unroll
         for (int cg = 0; cg < NG; ++cg) {
             const double r = fast_recip_pos(d2[cg][1]);
-            if (g == 0) bs[cg][i] = r;
+            if (g == 0) bs[cg][i * rm.gene_stride] = r;
             double bh[MF_Q];
 #pragma unroll
             for (int q = 0; q < MF_Q; ++q) {
                 bh[q] = mfma_own(d0[cg], d1[cg], d2[cg], q) * r;
                 w[cg][q] = bh[q] * pe_now[cg][q];
             }
-            mfma_store_rows_staged(stage[cg], bh, lane, b_dst[cg], i);
+            mfma_store_rows_staged(stage[cg], bh, lane, b_dst[cg], i * rm.gene_stride);
         }
     };
     int o = 0;
@@ -1970,20 +1994,22 @@ __device__ __forceinline__ void dl_from(const double (&t)[DL_GROUPS], const doub
 }
 
 __global__ void __launch_bounds__(64 * DL_WAVES)
-delta_lanes_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *__restrict__ chroms,
+delta_lanes_kernel(int n_samples, RowMap rm, const ChromDesc *__restrict__ chroms,
                    const int32_t *__restrict__ order, const double *__restrict__ tprob, const double *__restrict__ eprob,
                    const double *__restrict__ init_vec, double *__restrict__ delta, int32_t *__restrict__ last_state,
                    int n_chrom /* of the handle: the launch may cover a group of them */) {
     constexpr int S = MF_S, BLK = S * S;
     __shared__ __attribute__((aligned(16))) double dbuf[2][DL_SAMPLES][DL_STRIDE];
-    const int chrom = order[blockIdx.y];
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (!rm.place(bx, by)) return;
+    const int chrom = order[by];
     const ChromDesc cd = chroms[chrom];
     const int n = cd.n_genes;
     if (n <= 0) return;
     const int tid = threadIdx.x, c = tid & 15, j0 = (tid >> 4) * DL_T;   // sample slot, first of the row's DL_T target states
-    const int sample_raw = blockIdx.x * DL_SAMPLES + c;
+    const int sample_raw = bx * DL_SAMPLES + c;
     const int sample = min(sample_raw, n_samples - 1);           // slots past the end shadow the last sample (same values, same stores)
-    const int64_t g0 = (int64_t)sample * genes_per_sample + cd.gene_off;
+    const int64_t g0 = (int64_t)sample * rm.sample_stride + cd.gene_off * rm.gene_stride;
     const int n_ord = min(n, cd.n_trans + 1) - 1;               // step i = o + 1 needs block o
     const int last_o = max(n_ord - 1, 0);
     const double *e_at = eprob + g0 * S + j0;                   // + i * S + t: my states of gene i
@@ -1999,7 +2025,7 @@ delta_lanes_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *__r
         const bool on = piece < PIECES;
         const int slot = on ? piece / ROW_PIECES : 0, pc = on ? piece % ROW_PIECES : 0;
         st_off[q] = on ? slot * DL_STRIDE + 2 * pc : -1;
-        d_out[q] = delta + ((int64_t)min((int)blockIdx.x * DL_SAMPLES + slot, n_samples - 1) * genes_per_sample + cd.gene_off) * S + 2 * pc;
+        d_out[q] = delta + ((int64_t)min(bx * DL_SAMPLES + slot, n_samples - 1) * rm.sample_stride + cd.gene_off * rm.gene_stride) * S + 2 * pc;
     }
     // row j of a block is 36 consecutive entries; register g of slot c holds entry 16 g + c
     const double *TB = tprob + cd.trans_off * (int64_t)BLK + (int64_t)j0 * S + c;
@@ -2013,7 +2039,7 @@ delta_lanes_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *__r
         const double *src = TB + (int64_t)HMM_BLK(oc) * BLK;
 #pragma unroll
         for (int t = 0; t < DL_T; ++t) {
-            e_ring[slot][t] = e_at[(int64_t)(oc + 1) * S + t];
+            e_ring[slot][t] = e_at[(int64_t)(oc + 1) * rm.gene_stride * S + t];
             t_ring[slot][t][0] = src[t * S];
             t_ring[slot][t][1] = src[t * S + 16];
             t_ring[slot][t][2] = src[t * S + third];            // entries 32..35 in slots 0..3; the other slots re-read entry 35, unused
@@ -2033,7 +2059,7 @@ delta_lanes_kernel(int n_samples, int64_t genes_per_sample, const ChromDesc *__r
 #pragma unroll
         for (int q = 0; q < ST; ++q)
             if (st_off[q] >= 0)
-                *reinterpret_cast<double2 *>(d_out[q] + (int64_t)gene * S) = *reinterpret_cast<const double2 *>(&dbuf[cur][0][0] + st_off[q]);
+                *reinterpret_cast<double2 *>(d_out[q] + (int64_t)gene * rm.gene_stride * S) = *reinterpret_cast<const double2 *>(&dbuf[cur][0][0] + st_off[q]);
     };
     store_rows(0);
     auto step = [&](int o, int u) {                            // u: a constant after unrolling (the ring is in registers)
@@ -2558,6 +2584,12 @@ int hmm_make_logs(gbrs_hmm *h) {
                               // round 4, Viterbi values by rank convergence: 0.63 / 1.01 / 1.51 / 1.85 ms at 1 / 2 / 3 / 4 samples against 1.9-2.0 on the
                               // chains; 5 samples 2.25 against 2.0)
 #endif
+#ifndef HMM_BP_AFTER_SWEEPS
+#define HMM_BP_AFTER_SWEEPS 0
+#endif
+#ifndef HMM_XCD_GRIDS
+#define HMM_XCD_GRIDS 0       // batch chain kernels on XCD-aware 1-D grids (GBRS_TUNING_HMM_XCD)
+#endif
 #ifndef HMM_DELTA_SPEC
 #define HMM_DELTA_SPEC 1      // blocked scan: Viterbi values by rank convergence (one chain per block + fix-up) instead of max-plus block operators
 #endif
@@ -2791,14 +2823,14 @@ int hmm_launch_groups(gbrs_hmm *h) {
         GBRS_HIP_CHECK(hipStreamWaitEvent(s1, h->gev_em[g], 0));
         GBRS_HIP_CHECK(hipStreamWaitEvent(s2, h->gev_em[g], 0));
         const dim3 mfma_grid((ns + 15) / 16, ncg);
-        hipLaunchKernelGGL((alpha_mfma_kernel<HMM_NSET_M, 1>), mfma_grid, dim3(64), 0, s0, ns, h->total_genes, h->d_chroms.p, ord,
+        hipLaunchKernelGGL((alpha_mfma_kernel<HMM_NSET_M, 1>), mfma_grid, dim3(64), 0, s0, ns, RowMap{h->total_genes, 1}, h->d_chroms.p, ord,
                            h->amat_f.p, h->eprob.p, h->peprob.p, h->init_vec.p, h->xsum.p, h->invz.p);
         if (g == 0) GBRS_HIP_CHECK(hipEventRecord(h->ev[2], s0));
-        hipLaunchKernelGGL((backward_mfma_kernel<HMM_NSET_M, 1>), mfma_grid, dim3(64), 0, s1, ns, h->total_genes, h->d_chroms.p, ord,
+        hipLaunchKernelGGL((backward_mfma_kernel<HMM_NSET_M, 1>), mfma_grid, dim3(64), 0, s1, ns, RowMap{h->total_genes, 1}, h->d_chroms.p, ord,
                            h->amat_b.p, h->peprob.p, h->bhat.p, h->bscale.p);
         GBRS_HIP_CHECK(hipEventRecord(h->gev_b[g], s1));
         hipLaunchKernelGGL(delta_lanes_kernel, dim3((ns + DL_SAMPLES - 1) / DL_SAMPLES, ncg), dim3(64 * DL_WAVES), 0, s2, ns,
-                           h->total_genes, h->d_chroms.p, ord, h->tprob.p, h->eprob.p, h->init_vec.p, h->delta.p, h->last_state.p,
+                           RowMap{h->total_genes, 1}, h->d_chroms.p, ord, h->tprob.p, h->eprob.p, h->init_vec.p, h->delta.p, h->last_state.p,
                            h->n_chrom);
         if (h->grp_max_bp[g] > 0) {
             if (ns >= bpl_min) {
@@ -2929,10 +2961,25 @@ int hmm_launch(gbrs_hmm *h) {
             int mfma_ng = h->n_samples >= HMM_MFMA_NG2_MIN ? 2 : 1;
             if (const char *env = std::getenv("GBRS_TUNING_HMM_MFMA_NG"); env && (std::atoi(env) == 1 || std::atoi(env) == 2)) mfma_ng = std::atoi(env);
             const dim3 mfma_grid((h->n_samples + 16 * mfma_ng - 1) / (16 * mfma_ng), h->n_chrom);
+            // rows of the per-sample arrays as the batch kernels address them; GBRS_DIAG_HMM_INTERLEAVED=1 (timing only - the
+            // other kernels keep [sample][gene], so the results are wrong): [gene][sample], a step's 16 rows contiguous
+            RowMap chain_rows{h->total_genes, 1};
+            if (const char *env = std::getenv("GBRS_DIAG_HMM_INTERLEAVED"); env && std::atoi(env)) chain_rows = RowMap{1, h->n_samples};
+            // GBRS_TUNING_HMM_XCD=1: the batch chain kernels on XCD-aware 1-D grids (RowMap::place)
+            const int xcd_mask = [] { const char *env = std::getenv("GBRS_TUNING_HMM_XCD"); return env ? std::atoi(env) : HMM_XCD_GRIDS; }();   // 1: sweeps, 2: delta chain
+            auto xcd_grid = [&](unsigned groups, RowMap &rmap) {
+                rmap.xcd_groups = (int32_t)groups;
+                rmap.n_order = h->n_chrom;
+                return dim3(8u * groups * (unsigned)((h->n_chrom + 7) / 8));
+            };
+            RowMap mfma_rows = chain_rows, dl_rows = chain_rows;
+            const dim3 mfma_launch = (xcd_mask & 1) ? xcd_grid(mfma_grid.x, mfma_rows) : mfma_grid;
+            const dim3 dl_grid((h->n_samples + DL_SAMPLES - 1) / DL_SAMPLES, h->n_chrom);
+            const dim3 dl_launch = (xcd_mask & 2) ? xcd_grid(dl_grid.x, dl_rows) : dl_grid;
             launch_alpha = [=](hipStream_t st) {
                 if (mfma) {
                     auto k = mfma_ng == 2 ? &alpha_mfma_kernel<HMM_NSET_M2, 2> : &alpha_mfma_kernel<HMM_NSET_M, 1>;
-                    hipLaunchKernelGGL(k, mfma_grid, dim3(64), 0, st, h->n_samples, h->total_genes,
+                    hipLaunchKernelGGL(k, mfma_launch, dim3(64), 0, st, h->n_samples, mfma_rows,
                                        h->d_chroms.p, h->d_order.p, h->amat_f.p, h->eprob.p, h->peprob.p, h->init_vec.p,
                                        h->xsum.p, h->invz.p);
                     return;
@@ -2969,8 +3016,8 @@ int hmm_launch(gbrs_hmm *h) {
             launch_back = [=](hipStream_t st) {
                 if (mfma) {
                     auto k = mfma_ng == 2 ? &backward_mfma_kernel<HMM_NSET_M2, 2> : &backward_mfma_kernel<HMM_NSET_M, 1>;
-                    hipLaunchKernelGGL(k, mfma_grid, dim3(64), 0, st, h->n_samples,
-                                       h->total_genes, h->d_chroms.p, h->d_order.p, h->amat_b.p, h->peprob.p, h->bhat.p,
+                    hipLaunchKernelGGL(k, mfma_launch, dim3(64), 0, st, h->n_samples,
+                                       mfma_rows, h->d_chroms.p, h->d_order.p, h->amat_b.p, h->peprob.p, h->bhat.p,
                                        h->bscale.p);
                     return;
                 }
@@ -3016,8 +3063,8 @@ int hmm_launch(gbrs_hmm *h) {
             h->last_delta_spec = delta_spec;
             launch_delta = [=](hipStream_t st) {
                 if (dlanes) {
-                    hipLaunchKernelGGL(delta_lanes_kernel, dim3((h->n_samples + DL_SAMPLES - 1) / DL_SAMPLES, h->n_chrom), dim3(64 * DL_WAVES), 0, st,
-                                       h->n_samples, h->total_genes, h->d_chroms.p, h->d_order.p, h->tprob.p, h->eprob.p,
+                    hipLaunchKernelGGL(delta_lanes_kernel, dl_launch, dim3(64 * DL_WAVES), 0, st,
+                                       h->n_samples, dl_rows, h->d_chroms.p, h->d_order.p, h->tprob.p, h->eprob.p,
                                        h->init_vec.p, h->delta.p, h->last_state.p, h->n_chrom);
                     return;
                 }
@@ -3089,14 +3136,24 @@ int hmm_launch(gbrs_hmm *h) {
         GBRS_HIP_CHECK(hipEventRecord(h->ev_fork, sa));
         GBRS_HIP_CHECK(hipStreamWaitEvent(sb, h->ev_fork, 0));
         GBRS_HIP_CHECK(hipStreamWaitEvent(sc, h->ev_fork, 0));
-        launch_alpha(sa);
+        // GBRS_DIAG_HMM_SKIP=<letters of a, b, c, p, v> (timing only: wrong results): leave the alpha / backward / delta chain, the
+        // posterior, the backpointers + backtrace out of the pass
+        const char *skip = std::getenv("GBRS_DIAG_HMM_SKIP");
+        auto skipped = [&](char c) { return skip && std::strchr(skip, c) != nullptr; };
+        if (!skipped('a')) launch_alpha(sa);
         GBRS_HIP_CHECK(hipEventRecord(h->ev[2], sa));
         if (const char *env = std::getenv("GBRS_TUNING_HMM_BACK_AFTER"); env && std::atoi(env))
             GBRS_HIP_CHECK(hipStreamWaitEvent(sb, h->ev[2], 0));
-        launch_back(sb);
+        if (!skipped('b')) launch_back(sb);
         GBRS_HIP_CHECK(hipEventRecord(h->ev_b, sb));
-        launch_delta(sc);
-        if (h->max_bp_rows > 0 && !h->last_blocked) {     // the blocked scan's delta chains write the backpointers themselves
+        if (!skipped('c')) launch_delta(sc);
+        // GBRS_TUNING_HMM_BP_AFTER=1: the backpointer kernel (one sample per lane: a cache line and a page per lane and load)
+        // behind the sweeps instead of beside them
+        if (const char *env = std::getenv("GBRS_TUNING_HMM_BP_AFTER"); env ? std::atoi(env) != 0 : HMM_BP_AFTER_SWEEPS != 0) {
+            GBRS_HIP_CHECK(hipStreamWaitEvent(sc, h->ev[2], 0));
+            GBRS_HIP_CHECK(hipStreamWaitEvent(sc, h->ev_b, 0));
+        }
+        if (h->max_bp_rows > 0 && !h->last_blocked && !skipped('v')) {     // the blocked scan's delta chains write the backpointers themselves
             if constexpr (QUAD)
                 hipLaunchKernelGGL((viterbi_bp_quad_kernel<KMAX>), dim3(h->max_bp_rows, h->n_chrom), dim3(threads), 0,
                                    sc, h->n_samples, h->total_genes, h->total_bp, h->d_chroms.p, h->tprob_q.p,
@@ -3117,14 +3174,14 @@ int hmm_launch(gbrs_hmm *h) {
                                    h->total_bp, h->d_chroms.p, h->tprob.p, h->delta.p, h->bp.p);
         }
         GBRS_HIP_CHECK(hipEventRecord(h->ev_c1, sc));
-        launch_backtrace(sc);
+        if (!skipped('v')) launch_backtrace(sc);
         if (h->last_delta_spec)                       // behind everything that reads the blocks' vectors as the fix-up left them
             hipLaunchKernelGGL(delta_apply_kernel, dim3(h->n_blk[0], h->n_samples), dim3(64), 0, sc, h->total_genes, h->n_vb,
                                h->n_chrom, h->d_ranges[0].p, h->d_first_block[0].p, h->dspec_c.p, h->dspec_g.p,
                                h->dspec_fail.p, h->delta.p);
         GBRS_HIP_CHECK(hipEventRecord(h->ev_c, sc));
         GBRS_HIP_CHECK(hipStreamWaitEvent(sa, h->ev_b, 0));
-        launch_posterior(h, sa);                      // the posterior is scale free: no beta correction needed
+        if (!skipped('p')) launch_posterior(h, sa);   // the posterior is scale free: no beta correction needed
         GBRS_HIP_CHECK(hipEventRecord(h->ev[3], sa));
         GBRS_HIP_CHECK(hipStreamWaitEvent(sa, h->ev_c, 0));
         GBRS_HIP_CHECK(hipEventRecord(h->ev[4], sa));
