@@ -1994,7 +1994,7 @@ __device__ __forceinline__ void dl_from(const double (&t)[DL_GROUPS], const doub
 }
 
 __global__ void __launch_bounds__(64 * DL_WAVES)
-delta_lanes_kernel(int n_samples, RowMap rm, const ChromDesc *__restrict__ chroms,
+delta_lanes_kernel(int n_samples, RowMap rm /* rows of eprob, and the grid's placement */, RowMap drows /* rows of delta */, const ChromDesc *__restrict__ chroms,
                    const int32_t *__restrict__ order, const double *__restrict__ tprob, const double *__restrict__ eprob,
                    const double *__restrict__ init_vec, double *__restrict__ delta, int32_t *__restrict__ last_state,
                    int n_chrom /* of the handle: the launch may cover a group of them */) {
@@ -2025,7 +2025,7 @@ delta_lanes_kernel(int n_samples, RowMap rm, const ChromDesc *__restrict__ chrom
         const bool on = piece < PIECES;
         const int slot = on ? piece / ROW_PIECES : 0, pc = on ? piece % ROW_PIECES : 0;
         st_off[q] = on ? slot * DL_STRIDE + 2 * pc : -1;
-        d_out[q] = delta + ((int64_t)min(bx * DL_SAMPLES + slot, n_samples - 1) * rm.sample_stride + cd.gene_off * rm.gene_stride) * S + 2 * pc;
+        d_out[q] = delta + ((int64_t)min(bx * DL_SAMPLES + slot, n_samples - 1) * drows.sample_stride + cd.gene_off * drows.gene_stride) * S + 2 * pc;
     }
     // row j of a block is 36 consecutive entries; register g of slot c holds entry 16 g + c
     const double *TB = tprob + cd.trans_off * (int64_t)BLK + (int64_t)j0 * S + c;
@@ -2059,7 +2059,7 @@ delta_lanes_kernel(int n_samples, RowMap rm, const ChromDesc *__restrict__ chrom
 #pragma unroll
         for (int q = 0; q < ST; ++q)
             if (st_off[q] >= 0)
-                *reinterpret_cast<double2 *>(d_out[q] + (int64_t)gene * rm.gene_stride * S) = *reinterpret_cast<const double2 *>(&dbuf[cur][0][0] + st_off[q]);
+                *reinterpret_cast<double2 *>(d_out[q] + (int64_t)gene * drows.gene_stride * S) = *reinterpret_cast<const double2 *>(&dbuf[cur][0][0] + st_off[q]);
     };
     store_rows(0);
     auto step = [&](int o, int u) {                            // u: a constant after unrolling (the ring is in registers)
@@ -2309,7 +2309,7 @@ backtrace_write_kernel(int S, int64_t genes_per_sample, int64_t bp_per_sample, i
 constexpr int BPL_WAVES = 4;
 template <int SS>
 __global__ void __launch_bounds__(64 * BPL_WAVES)
-viterbi_bp_lanes_kernel(int n_samples, int64_t genes_per_sample, int64_t bp_per_sample,
+viterbi_bp_lanes_kernel(int n_samples, RowMap drows /* of delta */, int64_t bp_per_sample,
                         const ChromDesc *__restrict__ chroms, const double *__restrict__ tprob,
                         const double *__restrict__ delta, uint16_t *__restrict__ bp) {
     static_assert(SS % 4 == 0, "four backpointers per store");
@@ -2321,7 +2321,7 @@ viterbi_bp_lanes_kernel(int n_samples, int64_t genes_per_sample, int64_t bp_per_
     for (int x = threadIdx.x; x < SS * SS / 2; x += blockDim.x) reinterpret_cast<double2 *>(tl)[x] = T[x];
     const int sample = blockIdx.z * blockDim.x + threadIdx.x;
     const bool act = sample < n_samples;
-    const int64_t row = (int64_t)(act ? sample : n_samples - 1) * genes_per_sample + cd.gene_off + t;
+    const int64_t row = (int64_t)(act ? sample : n_samples - 1) * drows.sample_stride + (cd.gene_off + t) * drows.gene_stride;
     const double2 *d2 = reinterpret_cast<const double2 *>(delta + row * SS);
     double d[SS];
 #pragma unroll
@@ -2434,6 +2434,7 @@ struct gbrs_hmm {
     int n_vb = 0, blk_samples = 0;            // n_vb: the larger of the two block counts (buffers are sized by it)
     int n_blk[2] = {0, 0}, n_head[2] = {0, 0};
     bool last_blocked = false;                // the last run's backward chains started from injected vectors
+    RowMap delta_rows{0, 1};                  // how the last run laid `delta` out ([sample][gene], or [gene][sample] for the large batches)
     bool last_delta_spec = false;             // the last run's delta came from the rank-convergence scheme: delta_apply_kernel is due
     DevBuf<BlockRange> d_ranges[2];
     DevBuf<int32_t> d_first_block[2];         // blocks of chromosome c: first_block[c] .. first_block[c+1]
@@ -2583,6 +2584,9 @@ int hmm_make_logs(gbrs_hmm *h) {
 #define HMM_BLOCKED_MAX 4     // 36 states, at most this many samples: the blocked scan (the sum-product operators cost 36 columns per block and sample;
                               // round 4, Viterbi values by rank convergence: 0.63 / 1.01 / 1.51 / 1.85 ms at 1 / 2 / 3 / 4 samples against 1.9-2.0 on the
                               // chains; 5 samples 2.25 against 2.0)
+#endif
+#ifndef HMM_DELTA_INTERLEAVED
+#define HMM_DELTA_INTERLEAVED 0     // delta as [gene][sample] for the large batches: parity-green, no gain (15.72 against 15.73 ms), off
 #endif
 #ifndef HMM_BP_AFTER_SWEEPS
 #define HMM_BP_AFTER_SWEEPS 0
@@ -2789,6 +2793,7 @@ int hmm_prepare_groups(gbrs_hmm *h) {
 int hmm_launch_groups(gbrs_hmm *h) {
     constexpr int S = MF_S;
     GBRS_TRY(hmm_prepare_groups(h));
+    h->delta_rows = RowMap{(int64_t)h->total_genes, 1};
     hipStream_t sa = h->stream;
     if (!h->amat_f.p) {
         GBRS_TRY(h->amat_f.alloc((size_t)h->total_trans * MF_BLK));
@@ -2830,13 +2835,13 @@ int hmm_launch_groups(gbrs_hmm *h) {
                            h->amat_b.p, h->peprob.p, h->bhat.p, h->bscale.p);
         GBRS_HIP_CHECK(hipEventRecord(h->gev_b[g], s1));
         hipLaunchKernelGGL(delta_lanes_kernel, dim3((ns + DL_SAMPLES - 1) / DL_SAMPLES, ncg), dim3(64 * DL_WAVES), 0, s2, ns,
-                           RowMap{h->total_genes, 1}, h->d_chroms.p, ord, h->tprob.p, h->eprob.p, h->init_vec.p, h->delta.p, h->last_state.p,
+                           RowMap{h->total_genes, 1}, RowMap{h->total_genes, 1}, h->d_chroms.p, ord, h->tprob.p, h->eprob.p, h->init_vec.p, h->delta.p, h->last_state.p,
                            h->n_chrom);
         if (h->grp_max_bp[g] > 0) {
             if (ns >= bpl_min) {
                 const int per_wg = std::min(64 * BPL_WAVES, ((ns + 63) / 64) * 64);
                 hipLaunchKernelGGL((viterbi_bp_lanes_kernel<MF_S>), dim3(h->grp_max_bp[g], ncg, (ns + per_wg - 1) / per_wg), dim3(per_wg), 0,
-                                   s2, ns, h->total_genes, h->total_bp, h->d_chroms.p + c_lo, h->tprob.p, h->delta.p, h->bp.p);
+                                   s2, ns, RowMap{h->total_genes, 1}, h->total_bp, h->d_chroms.p + c_lo, h->tprob.p, h->delta.p, h->bp.p);
             } else {
                 hipLaunchKernelGGL(viterbi_bp_kernel, dim3(h->grp_max_bp[g], ncg), dim3(256), (size_t)S * (S + 1) * sizeof(double), s2,
                                    S, ns, h->total_genes, h->total_bp, h->d_chroms.p + c_lo, h->tprob.p, h->delta.p, h->bp.p);
@@ -2976,6 +2981,18 @@ int hmm_launch(gbrs_hmm *h) {
             const dim3 mfma_launch = (xcd_mask & 1) ? xcd_grid(mfma_grid.x, mfma_rows) : mfma_grid;
             const dim3 dl_grid((h->n_samples + DL_SAMPLES - 1) / DL_SAMPLES, h->n_chrom);
             const dim3 dl_launch = (xcd_mask & 2) ? xcd_grid(dl_grid.x, dl_rows) : dl_grid;
+            // delta as [gene][sample] when both its writer and its reader are the samples-on-lanes kernels (a step's / a
+            // gene's rows contiguous: the backpointer kernel reads one page per gene instead of one per lane); gbrs_hmm_get
+            // copies a sample's rows out with a stride.  GBRS_TUNING_HMM_DELTA_ROWS=1 switches it on (measured: no gain).
+            {
+                int bplm = HMM_BPL_MIN;
+                if (const char *env = std::getenv("GBRS_TUNING_HMM_BPLANES"); env) bplm = std::atoi(env) > 0 ? std::atoi(env) : INT_MAX;
+                bool il = HMM_DELTA_INTERLEAVED != 0;
+                if (const char *env = std::getenv("GBRS_TUNING_HMM_DELTA_ROWS"); env) il = std::atoi(env) != 0;
+                const bool both = SS == MF_S && h->total_trans > 0 && h->n_samples >= bplm &&
+                                  h->n_samples >= [] { int d = HMM_DLANES_MIN; if (const char *e = std::getenv("GBRS_TUNING_HMM_DLANES"); e) d = std::atoi(e) > 0 ? std::atoi(e) : INT_MAX; return d; }();
+                h->delta_rows = il && both ? RowMap{1, h->n_samples} : RowMap{chain_rows.sample_stride, chain_rows.gene_stride};
+            }
             launch_alpha = [=](hipStream_t st) {
                 if (mfma) {
                     auto k = mfma_ng == 2 ? &alpha_mfma_kernel<HMM_NSET_M2, 2> : &alpha_mfma_kernel<HMM_NSET_M, 1>;
@@ -3064,7 +3081,7 @@ int hmm_launch(gbrs_hmm *h) {
             launch_delta = [=](hipStream_t st) {
                 if (dlanes) {
                     hipLaunchKernelGGL(delta_lanes_kernel, dl_launch, dim3(64 * DL_WAVES), 0, st,
-                                       h->n_samples, dl_rows, h->d_chroms.p, h->d_order.p, h->tprob.p, h->eprob.p,
+                                       h->n_samples, dl_rows, h->delta_rows, h->d_chroms.p, h->d_order.p, h->tprob.p, h->eprob.p,
                                        h->init_vec.p, h->delta.p, h->last_state.p, h->n_chrom);
                     return;
                 }
@@ -3166,7 +3183,7 @@ int hmm_launch(gbrs_hmm *h) {
             } else if (WAVE && SS_WAVE == MF_S && h->n_samples >= bpl_min) {
                 const int per_wg = std::min(64 * BPL_WAVES, ((h->n_samples + 63) / 64) * 64);
                 hipLaunchKernelGGL((viterbi_bp_lanes_kernel<MF_S>), dim3(h->max_bp_rows, h->n_chrom, (h->n_samples + per_wg - 1) / per_wg),
-                                   dim3(per_wg), 0, sc, h->n_samples, h->total_genes, h->total_bp, h->d_chroms.p, h->tprob.p,
+                                   dim3(per_wg), 0, sc, h->n_samples, h->delta_rows, h->total_bp, h->d_chroms.p, h->tprob.p,
                                    h->delta.p, h->bp.p);
             } else
                 hipLaunchKernelGGL(viterbi_bp_kernel, dim3(h->max_bp_rows, h->n_chrom), dim3(256),
@@ -3467,7 +3484,19 @@ int gbrs_hmm_get(gbrs_hmm_t *h, int sample, int chrom, double *gamma, int32_t *s
     if (gamma) GBRS_TRY(fetch_t(h->gamma.p, gamma));
     if (alpha) GBRS_TRY(fetch_t(h->alpha.p, alpha));
     if (beta) GBRS_TRY(fetch_t(h->beta.p, beta));
-    if (delta) GBRS_TRY(fetch_t(h->delta.p, delta));
+    if (delta) {
+        if (h->delta_rows.gene_stride > 1) {         // [gene][sample]: the sample's rows are gene_stride rows apart
+            const RowMap &m = h->delta_rows;
+            GBRS_HIP_CHECK(hipMemcpy2D(tmp.data(), (size_t)S * sizeof(double),
+                                       h->delta.p + ((size_t)sample * m.sample_stride + (size_t)cd.gene_off * m.gene_stride) * S,
+                                       (size_t)m.gene_stride * S * sizeof(double), (size_t)S * sizeof(double), (size_t)n,
+                                       hipMemcpyDeviceToHost));
+            for (int i = 0; i < n; ++i)
+                for (int st = 0; st < S; ++st) delta[(size_t)st * n + i] = tmp[(size_t)i * S + st];
+        } else {
+            GBRS_TRY(fetch_t(h->delta.p, delta));
+        }
+    }
     if (scaler) GBRS_HIP_CHECK(hipMemcpy(scaler, h->scaler.p + goff, n * sizeof(double), hipMemcpyDeviceToHost));
     if (eprob) GBRS_HIP_CHECK(hipMemcpy(eprob, h->eprob.p + goff * S, (size_t)n * S * sizeof(double), hipMemcpyDeviceToHost));
     if (calls) GBRS_HIP_CHECK(hipMemcpy(calls, h->calls.p + goff, n * sizeof(int32_t), hipMemcpyDeviceToHost));

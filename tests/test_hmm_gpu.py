@@ -306,6 +306,9 @@ def test_hmm_sample_batches_and_short_chromosomes(n_samples, mfma_ng, pipeline, 
     monkeypatch.setenv("GBRS_TUNING_HMM_PIPELINE", str(pipeline))
     monkeypatch.setenv("GBRS_TUNING_HMM_DLANES", "16")       # and the samples-on-lanes delta chain
     monkeypatch.setenv("GBRS_TUNING_HMM_BPLANES", "5")       # and the samples-on-lanes backpointers (partly filled wavefronts)
+    # round 4 switches, off by default: delta as [gene][sample] between those two kernels, XCD-aware 1-D grids of the chain kernels
+    monkeypatch.setenv("GBRS_TUNING_HMM_DELTA_ROWS", "1" if n_samples in (25, 70) else "0")
+    monkeypatch.setenv("GBRS_TUNING_HMM_XCD", "3" if n_samples == 40 else "0")
     lens = [1, 2, 3, 4, 5, 7, 63, 64, 65, 129, 200]
     probs = [synth.make_hmm_problem(H=8, genes_per_chrom=lens, seed=1234 + s, tprob_len_minus_one=minus_one)
              for s in range(n_samples)]
