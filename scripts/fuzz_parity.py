@@ -67,12 +67,18 @@ def hmm_case(rng):
     nch = int(rng.integers(1, 6))
     lens = [int(x) for x in rng.integers(1, 90 if H == 16 else 400, size=nch)]
     ns = int(rng.choice([1, 1, 2, 3, 4, 5, 7, 16, 25, 40]))   # from 16 on: the MFMA sweeps (GBRS_TUNING_HMM_MFMA below)
-    # the blocked scan (1-2 samples, 36 states) with blocks short enough to cut these small chromosomes many times, and
+    # the blocked scan (1-4 samples, 36 states) with blocks short enough to cut these small chromosomes many times, and
     # the samples-on-lanes backpointers with partly filled wavefronts
     tuning = {"GBRS_TUNING_HMM_BLOCK_GENES": str(int(rng.choice([2, 3, 5, 9, 17, 40]))),
               "GBRS_TUNING_HMM_BLOCKS_MAX": str(int(rng.choice([2, 5, 64]))),
               "GBRS_TUNING_HMM_BLOCKED": str(int(rng.choice([0, 2, 2, 4]))),
-              "GBRS_TUNING_HMM_BPLANES": str(int(rng.choice([5, 32])))}
+              "GBRS_TUNING_HMM_BPLANES": str(int(rng.choice([5, 32]))),
+              # round 4: Viterbi values of the blocked scan by rank convergence (default) / max-plus operators / a tolerance no
+              # block meets (every chromosome through the fallback chain); the batch kernels' layout and grid switches
+              "GBRS_TUNING_HMM_DELTA_SPEC": str(int(rng.choice([1, 1, 0]))),
+              "GBRS_TUNING_HMM_DELTA_TOL": str(rng.choice(["1e-9", "1e-9", "-1"])),
+              "GBRS_TUNING_HMM_DELTA_ROWS": str(int(rng.integers(0, 2))),
+              "GBRS_TUNING_HMM_XCD": str(int(rng.choice([0, 0, 1, 2, 3])))}
     os.environ.update(tuning)
     style = str(rng.choice(["benign", "do"])) if H == 8 else "benign"
     minus_one = bool(rng.integers(0, 2))
