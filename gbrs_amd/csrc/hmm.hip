@@ -1800,6 +1800,9 @@ alpha_mfma_kernel(int n_samples, RowMap rm, const ChromDesc *__restrict__ chroms
         // refill the set the previous step released (clamped index: past the end it re-reads the last block)
         const int of = min(o + NSET - 1, last_o);
 #if !defined(HMM_ABL_M_LOADS)                    // timing-only builds (HMM_ABL_M_*): what a step of the sweep waits for
+#if defined(HMM_ABL_M_QUARTER)                   // ... the operand block of every fourth step only (what four wavefronts sharing
+        if ((o & 3) == 0)                        //     their operands through LDS would fetch)
+#endif
         mfma_load_block(BLK + (int64_t)HMM_BLK(of) * MF_BLK, lane, an);
 #pragma unroll
         for (int cg = 0; cg < NG; ++cg) mfma_load_row(pe_row[cg] + (int64_t)(of + 1) * rm.gene_stride * S, pn[cg]);
@@ -1910,6 +1913,9 @@ backward_mfma_kernel(int n_samples, RowMap rm, const ChromDesc *__restrict__ chr
 #pragma unroll
             for (int q = 0; q < MF_Q; ++q) pe_now[cg][q] = pc[cg][q];
         const int in = n - 2 - min(o + NSET - 1, last_o);
+#if defined(HMM_ABL_M_QUARTER)
+        if ((o & 3) == 0)
+#endif
         mfma_load_block(BLK + (int64_t)HMM_BLK(in) * MF_BLK, lane, an);
 #pragma unroll
         for (int cg = 0; cg < NG; ++cg) mfma_load_row(pe_row[cg] + (int64_t)in * rm.gene_stride * S, pn[cg]);
