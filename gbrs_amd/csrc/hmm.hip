@@ -2972,10 +2972,12 @@ int hmm_launch(gbrs_hmm *h) {
             int mfma_ng = h->n_samples >= HMM_MFMA_NG2_MIN ? 2 : 1;
             if (const char *env = std::getenv("GBRS_TUNING_HMM_MFMA_NG"); env && (std::atoi(env) == 1 || std::atoi(env) == 2)) mfma_ng = std::atoi(env);
             const dim3 mfma_grid((h->n_samples + 16 * mfma_ng - 1) / (16 * mfma_ng), h->n_chrom);
-            // rows of the per-sample arrays as the batch kernels address them; GBRS_DIAG_HMM_INTERLEAVED=1 (timing only - the
+            // rows of the per-sample arrays as the batch kernels address them; GBRS_DIAG_HMM_INTERLEAVED=1 (diagnostic builds; timing only - the
             // other kernels keep [sample][gene], so the results are wrong): [gene][sample], a step's 16 rows contiguous
             RowMap chain_rows{h->total_genes, 1};
+#if defined(GBRS_DIAG_BUILD)                     // never in the product library: the switch gives wrong results
             if (const char *env = std::getenv("GBRS_DIAG_HMM_INTERLEAVED"); env && std::atoi(env)) chain_rows = RowMap{1, h->n_samples};
+#endif
             // GBRS_TUNING_HMM_XCD=1: the batch chain kernels on XCD-aware 1-D grids (RowMap::place)
             const int xcd_mask = [] { const char *env = std::getenv("GBRS_TUNING_HMM_XCD"); return env ? std::atoi(env) : HMM_XCD_GRIDS; }();   // 1: sweeps, 2: delta chain
             auto xcd_grid = [&](unsigned groups, RowMap &rmap) {
@@ -3159,9 +3161,13 @@ int hmm_launch(gbrs_hmm *h) {
         GBRS_HIP_CHECK(hipEventRecord(h->ev_fork, sa));
         GBRS_HIP_CHECK(hipStreamWaitEvent(sb, h->ev_fork, 0));
         GBRS_HIP_CHECK(hipStreamWaitEvent(sc, h->ev_fork, 0));
-        // GBRS_DIAG_HMM_SKIP=<letters of a, b, c, p, v> (timing only: wrong results): leave the alpha / backward / delta chain, the
+        // GBRS_DIAG_HMM_SKIP=<letters of a, b, c, p, v> (diagnostic builds, -DGBRS_DIAG_BUILD; timing only: wrong results): leave the alpha / backward / delta chain, the
         // posterior, the backpointers + backtrace out of the pass
+#if defined(GBRS_DIAG_BUILD)                         // never in the product library: the switch gives wrong results
         const char *skip = std::getenv("GBRS_DIAG_HMM_SKIP");
+#else
+        const char *skip = nullptr;
+#endif
         auto skipped = [&](char c) { return skip && std::strchr(skip, c) != nullptr; };
         if (!skipped('a')) launch_alpha(sa);
         GBRS_HIP_CHECK(hipEventRecord(h->ev[2], sa));
