@@ -2411,6 +2411,7 @@ struct gbrs_hmm {
     hipStream_t stream = nullptr, stream_b = nullptr, stream_c = nullptr;   // see hmm_launch
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_b = nullptr, ev_c1 = nullptr, ev_c = nullptr;
+    hipEvent_t ev_ops[2] = {nullptr, nullptr};   // blocked scan: the alpha / backward operator kernels are done
     int H = 0, S = 0, n_chrom = 0, n_samples = 0;
     std::vector<ChromDesc> chroms;
     int64_t total_genes = 0, total_trans = 0, total_bp = 0, total_chunks = 0;
@@ -2590,6 +2591,9 @@ int hmm_make_logs(gbrs_hmm *h) {
 #define HMM_BLOCKED_MAX 4     // 36 states, at most this many samples: the blocked scan (the sum-product operators cost 36 columns per block and sample;
                               // round 4, Viterbi values by rank convergence: 0.63 / 1.01 / 1.51 / 1.85 ms at 1 / 2 / 3 / 4 samples against 1.9-2.0 on the
                               // chains; 5 samples 2.25 against 2.0)
+#endif
+#ifndef HMM_DELTA_AFTER_OPS
+#define HMM_DELTA_AFTER_OPS 0     // measured: 0.653 against 0.630 ms (the operators do not get faster without the delta chains beside them)
 #endif
 #ifndef HMM_DELTA_INTERLEAVED
 #define HMM_DELTA_INTERLEAVED 0     // delta as [gene][sample] for the large batches: parity-green, no gain (15.72 against 15.73 ms), off
@@ -3026,6 +3030,7 @@ int hmm_launch(gbrs_hmm *h) {
                     }
                     hipLaunchKernelGGL((blockmat_mfma_kernel<0>), dim3(h->n_blk[0], h->n_samples), dim3(64), 0, st, h->total_genes,
                                        h->n_vb, h->d_ranges[0].p, h->amat_f.p, h->peprob.p, h->g_f.p, h->e_f.p);
+                    (void)hipEventRecord(h->ev_ops[0], st);
                     if (h->n_head[0]) (void)hipStreamWaitEvent(st, h->ev_head[0], 0);
                     hipLaunchKernelGGL((combine_sumprod_kernel<0>), dim3(h->n_chrom, h->n_samples), dim3(64), 0, st, h->total_genes,
                                        h->n_vb, h->d_ranges[0].p, h->d_first_block[0].p, h->g_f.p, h->e_f.p, h->init_vec.p, h->eprob.p,
@@ -3060,6 +3065,7 @@ int hmm_launch(gbrs_hmm *h) {
                     }
                     hipLaunchKernelGGL((blockmat_mfma_kernel<1>), dim3(h->n_blk[1], h->n_samples), dim3(64), 0, st, h->total_genes,
                                        h->n_vb, h->d_ranges[1].p, h->amat_b.p, h->peprob.p, h->g_b.p, h->e_b.p);
+                    (void)hipEventRecord(h->ev_ops[1], st);
                     if (h->n_head[1]) (void)hipStreamWaitEvent(st, h->ev_head[1], 0);
                     hipLaunchKernelGGL((combine_sumprod_kernel<1>), dim3(h->n_chrom, h->n_samples), dim3(64), 0, st, h->total_genes,
                                        h->n_vb, h->d_ranges[1].p, h->d_first_block[1].p, h->g_b.p, h->e_b.p, h->init_vec.p, h->eprob.p,
@@ -3105,6 +3111,13 @@ int hmm_launch(gbrs_hmm *h) {
                         // rank convergence instead of block operators (hmm_blocked.inc): guess -> chains in all blocks -> fix-up in
                         // all blocks -> the unblocked chain for the chromosomes whose flag a fix-up raised (idle otherwise)
                         const dim3 bgrid(h->n_blk[0], h->n_samples);
+                        // GBRS_TUNING_HMM_DELTA_AFTER_OPS=1: the delta side (the short one) behind the two operator kernels instead
+                        // of beside them - measured: the operators are no faster alone (backward side 0.556 against 0.563 ms) and
+                        // the forward side gets longer (0.549 against 0.496): off.
+                        if (const char *env = std::getenv("GBRS_TUNING_HMM_DELTA_AFTER_OPS"); env ? std::atoi(env) != 0 : HMM_DELTA_AFTER_OPS != 0) {
+                            (void)hipStreamWaitEvent(st, h->ev_ops[0], 0);
+                            (void)hipStreamWaitEvent(st, h->ev_ops[1], 0);
+                        }
                         hipLaunchKernelGGL(delta_guess_kernel, bgrid, dim3(64), 0, st, h->total_genes, h->n_vb, h->n_chrom,
                                            h->d_ranges[0].p, h->eprob.p, h->inj_d.p, h->dspec_c.p, h->dspec_g.p, h->dspec_fail.p);
                         chains(st, 0, h->n_blk[0]);
@@ -3300,6 +3313,7 @@ int gbrs_hmm_create(int num_haps, int n_chrom, const int32_t *n_genes, const int
     }
     for (auto &e : h->ev) GBRS_HIP_CHECK(hipEventCreate(&e));
     for (hipEvent_t *e : {&h->ev_fork, &h->ev_b, &h->ev_c1, &h->ev_c}) GBRS_HIP_CHECK(hipEventCreate(e));
+    for (hipEvent_t *e : {&h->ev_ops[0], &h->ev_ops[1]}) GBRS_HIP_CHECK(hipEventCreateWithFlags(e, hipEventDisableTiming));
     GBRS_TRY(h->d_chroms.alloc(n_chrom));
     GBRS_HIP_CHECK(hipMemcpy(h->d_chroms.p, h->chroms.data(), n_chrom * sizeof(ChromDesc), hipMemcpyHostToDevice));
     {
@@ -3613,7 +3627,7 @@ int gbrs_hmm_destroy(gbrs_hmm_t *h) {
         if (st) (void)hipStreamSynchronize(st);
     for (auto &e : h->ev)
         if (e) (void)hipEventDestroy(e);
-    for (hipEvent_t e : {h->ev_fork, h->ev_b, h->ev_c1, h->ev_c})
+    for (hipEvent_t e : {h->ev_fork, h->ev_b, h->ev_c1, h->ev_c, h->ev_ops[0], h->ev_ops[1]})
         if (e) (void)hipEventDestroy(e);
     for (hipStream_t st : {h->stream, h->stream_b, h->stream_c, h->stream_h[0], h->stream_h[1], h->stream_h[2]})
         if (st) (void)hipStreamDestroy(st);
