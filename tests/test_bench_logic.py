@@ -26,7 +26,7 @@ def test_timed_region_counts_steps_and_reports_both_regions():
     dt, region = bench.timed_region(_args(), run_steps, lambda: barriers.append(len(calls)), 1, None, None, "cpu")
     # cold region: 5 + 20; pre-roll: ~40 ms / 0.1 ms; reported region: 5 + 20 again
     assert calls[0] == 5 and calls[1] == 20 and calls[3] == 5 and calls[4] == 20 and len(calls) == 5
-    assert 100 <= calls[2] <= 450                       # sleep granularity makes a step look longer than 0.1 ms
+    assert 10 <= calls[2] <= 450                        # (sleep granularity and a busy host make a step look longer than 0.1 ms)
     assert region["preroll"]["steps"] == calls[2] and region["preroll"]["asked_ms"] == 40.0
     assert region["cold_start"]["unit"] == "iters/s" and region["cold_start"]["ms_per_step"] > 0
     assert 20 * 0.9e-4 <= dt <= 20 * 1e-3               # the K steps of the second region only
