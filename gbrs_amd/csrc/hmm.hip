@@ -336,16 +336,19 @@ emission_batch_kernel(int64_t n_genes, int n_samples, int samples_per_block, con
 // {1, n_samples} is [gene][sample] (the 16 samples of a wavefront's step contiguous).
 struct RowMap {
     int64_t sample_stride, gene_stride;
-    // XCD-aware 1-D grids of the batch chain kernels (GBRS_TUNING_HMM_XCD): workgroup L runs on XCD L % 8, and all
-    // xcd_groups sample groups of a chromosome are put on one XCD, so that its transition blocks are fetched into one L2
-    // instead of eight: chromosome order index = L % 8 + 8 * ((L / 8) / xcd_groups), group = (L / 8) % xcd_groups.  0: 2-D grid.
-    int32_t xcd_groups = 0, n_order = 0;
+    // XCD-aware 1-D grids of the batch chain kernels (GBRS_TUNING_HMM_XCD): workgroup L runs on XCD L % 8.  The chromosomes are
+    // dealt to 8 / xcd_span sets of xcd_span XCDs each (chromosome order index o -> set o % (8 / span)), and a chromosome's
+    // xcd_groups sample groups round-robin over the XCDs of its set: its transition blocks are fetched into xcd_span L2s
+    // instead of eight.  0 groups: plain 2-D grid (blockIdx.x = group, blockIdx.y = order index).
+    int32_t xcd_groups = 0, n_order = 0, xcd_span = 1;
     __device__ __forceinline__ bool place(int &bx, int &by) const {
         if (xcd_groups > 0) {
-            const int k = bx & 7, sl = bx >> 3;
-            by = k + 8 * (sl / xcd_groups);
-            bx = sl % xcd_groups;
-            return by < n_order;
+            const int xcd = bx & 7, slot = bx >> 3;
+            const int sets = 8 / xcd_span, set = xcd / xcd_span, lane = xcd % xcd_span;
+            const int per = (xcd_groups + xcd_span - 1) / xcd_span;          // groups of a chromosome on one XCD
+            by = set + sets * (slot / per);
+            bx = lane + xcd_span * (slot % per);
+            return by < n_order && bx < xcd_groups;
         }
         return true;
     }
@@ -2601,6 +2604,9 @@ int hmm_make_logs(gbrs_hmm *h) {
 #ifndef HMM_BP_AFTER_SWEEPS
 #define HMM_BP_AFTER_SWEEPS 0
 #endif
+#ifndef HMM_XCD_SPAN
+#define HMM_XCD_SPAN 2        // XCDs a chromosome's sample groups are spread over under GBRS_TUNING_HMM_XCD (1, 2 or 4)
+#endif
 #ifndef HMM_XCD_GRIDS
 #define HMM_XCD_GRIDS 0       // batch chain kernels on XCD-aware 1-D grids (GBRS_TUNING_HMM_XCD)
 #endif
@@ -2984,10 +2990,14 @@ int hmm_launch(gbrs_hmm *h) {
 #endif
             // GBRS_TUNING_HMM_XCD=1: the batch chain kernels on XCD-aware 1-D grids (RowMap::place)
             const int xcd_mask = [] { const char *env = std::getenv("GBRS_TUNING_HMM_XCD"); return env ? std::atoi(env) : HMM_XCD_GRIDS; }();   // 1: sweeps, 2: delta chain
+            int xcd_span = HMM_XCD_SPAN;
+            if (const char *env = std::getenv("GBRS_TUNING_HMM_XCD_SPAN"); env && (std::atoi(env) == 1 || std::atoi(env) == 2 || std::atoi(env) == 4)) xcd_span = std::atoi(env);
             auto xcd_grid = [&](unsigned groups, RowMap &rmap) {
                 rmap.xcd_groups = (int32_t)groups;
                 rmap.n_order = h->n_chrom;
-                return dim3(8u * groups * (unsigned)((h->n_chrom + 7) / 8));
+                rmap.xcd_span = xcd_span;
+                const unsigned sets = 8u / (unsigned)xcd_span, per = (groups + xcd_span - 1) / xcd_span;
+                return dim3(8u * per * (unsigned)((h->n_chrom + sets - 1) / sets));
             };
             RowMap mfma_rows = chain_rows, dl_rows = chain_rows;
             const dim3 mfma_launch = (xcd_mask & 1) ? xcd_grid(mfma_grid.x, mfma_rows) : mfma_grid;
