@@ -664,6 +664,16 @@ def hmm_bench(args, torch, ns=None, with_cpu=True, sample_seed=1):
                                   "transition tables are priced once per batch (SURVEY 8d), the per-sample "
                                   "vectors once per sample"))
     hmm.close()
+    try:                                              # measured HBM traffic of this exact workload, from the committed counter passes
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+            pt = json.load(fh).get(f"hmm_S{S_}_G{prob.num_genes}_N{ns}")
+        if pt:
+            out["roofline"].update(traffic=pt["bytes_per_pass"], traffic_source=pt["source"],
+                                   traffic_rate_GBs=pt["bytes_per_pass"] / (ms * 1e-3) / 1e9,
+                                   traffic_frac_of_peak=pt["bytes_per_pass"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                   measured_in_run={"achieved": True, "traffic": False})
+    except (OSError, ValueError):
+        pass
     if with_cpu and args.hmm_batch > 0 and args.hmm_batch != ns:
         b = hmm_bench(args, torch, ns=args.hmm_batch, with_cpu=False)
         out["batched"] = {k: b[k] for k in ("value", "unit", "ms_per_pass", "n_samples", "wall_clock", "kernels_ms", "roofline")}
