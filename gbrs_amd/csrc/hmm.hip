@@ -2342,26 +2342,36 @@ viterbi_bp_lanes_kernel(int n_samples, RowMap drows /* of delta */, int64_t bp_p
     __syncthreads();
     uint2 *out = reinterpret_cast<uint2 *>(bp + ((int64_t)(act ? sample : n_samples - 1) * bp_per_sample + cd.bp_off + t) * SS);
     uint64_t packed = 0;                          // the last four backpointers, 16 bits each
-#pragma unroll 1
-    for (int j = 0; j < SS; ++j) {
-        const double2 *tr = reinterpret_cast<const double2 *>(tl + j * SS);
-        double best = 0.0;
-        uint32_t best_k = 0;
+    // the row's 72 bytes are stored together at the end: written as they came (8 bytes every fourth state, hundreds of
+    // cycles apart) the counters showed 3.3 GB of HBM writes for 0.74 GB of backpointers
+    uint2 res[SS / 4];
 #pragma unroll
-        for (int m = 0; m < SS / 2; ++m) {
-            const double2 tv = tr[m];
-            const double a = d[2 * m] + tv.x, c = d[2 * m + 1] + tv.y;
-            if (m == 0) {
-                best = a;
-            } else {
-                best_k = a > best ? 2 * m : best_k;
-                best = max_f64(best, a);
+    for (int q4 = 0; q4 < SS / 4; ++q4) {          // (nine register slots; the four states of a slot in a rolled loop)
+#pragma unroll 1
+        for (int j = 4 * q4; j < 4 * q4 + 4; ++j) {
+            const double2 *tr = reinterpret_cast<const double2 *>(tl + j * SS);
+            double best = 0.0;
+            uint32_t best_k = 0;
+#pragma unroll
+            for (int m = 0; m < SS / 2; ++m) {
+                const double2 tv = tr[m];
+                const double a = d[2 * m] + tv.x, c = d[2 * m + 1] + tv.y;
+                if (m == 0) {
+                    best = a;
+                } else {
+                    best_k = a > best ? 2 * m : best_k;
+                    best = max_f64(best, a);
+                }
+                best_k = c > best ? 2 * m + 1 : best_k;
+                best = max_f64(best, c);
             }
-            best_k = c > best ? 2 * m + 1 : best_k;
-            best = max_f64(best, c);
+            packed = (packed >> 16) | ((uint64_t)best_k << 48);
         }
-        packed = (packed >> 16) | ((uint64_t)best_k << 48);
-        if ((j & 3) == 3 && act) out[j >> 2] = make_uint2((uint32_t)packed, (uint32_t)(packed >> 32));
+        res[q4] = make_uint2((uint32_t)packed, (uint32_t)(packed >> 32));
+    }
+    if (act) {
+#pragma unroll
+        for (int q = 0; q < SS / 4; ++q) out[q] = res[q];
     }
 }
 
