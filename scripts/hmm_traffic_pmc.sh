@@ -29,7 +29,7 @@ print(f"# {ns} samples x 40,000 genes x 36 states; per launch (last launches of 
 tot = 0.0
 for k in sorted(fe, key=lambda k: -max(fe[k])):
     f = fe[k][-1] * 2 * 1024; w = (wr.get(k) or [0])[-1] * 1024
-    if f + w < 50e6: continue
+    if f + w < (50e6 if ns >= 16 else 2e6): continue
     d = dur.get(k, (0, 0))[0]
     tot += f + w
     print(f"{k[:44]:44s} read {f / 1e9:7.2f} GB  written {w / 1e9:6.2f} GB  side by side {d:9.1f} us  -> {(f + w) / max(d, 1e-9) / 1e6:6.2f} TB/s if it ran alone at that time")
